@@ -1,0 +1,113 @@
+"""Pins the CPU oracle against the reference's own known-answer tests
+(tests/golden/reference_vectors.json, transcribed from jcjohnson/densecap test/*.lua)."""
+import numpy as np
+import pytest
+
+from oracle import densecap_oracle as O
+
+
+@pytest.mark.parametrize("impl", ["c", "py"])
+def test_nms_golden(golden, impl):
+    f = O.nms if impl == "c" else O.nms_py
+    for case in golden["nms"]:
+        pick = f(np.array(case["boxes"], np.float32), case["thresh"])
+        assert pick.tolist() == case["expected"], case["cite"]
+
+
+def test_nms_max_boxes_and_empty():
+    b = np.array([[0, 0, 10, 10, 1], [100, 100, 110, 110, 2], [200, 200, 210, 210, 3]], np.float32)
+    assert O.nms(b, 0.5, 2).tolist() == [2, 1]
+    assert O.nms_py(b, 0.5, 2).tolist() == [2, 1]
+    assert O.nms(np.zeros((0, 5), np.float32), 0.5).size == 0
+
+
+def test_nms_c_equals_py_random():
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 17, 300):
+        xy = rng.uniform(0, 200, (n, 2)); wh = rng.uniform(5, 120, (n, 2))
+        s = np.round(rng.uniform(0, 1, (n, 1)), 2)  # rounding forces score ties
+        b = np.concatenate([xy, xy + wh, s], 1).astype(np.float32)
+        for thr in (0.3, 0.7):
+            assert O.nms(b, thr, 50).tolist() == O.nms_py(b, thr, 50).tolist()
+
+
+def test_apply_box_transform_golden(golden):
+    g = golden["apply_box_transform"]
+    out = O.apply_box_transform(np.array(g["boxes"], np.float32), np.array(g["trans"], np.float32))
+    np.testing.assert_allclose(out, np.array(g["expected"]), atol=g["tol"] * 10, rtol=1e-6)
+
+
+def test_box_to_affine_golden(golden):
+    g = golden["box_to_affine"]
+    out = O.box_to_affine(np.array(g["boxes"], np.float32), g["H"], g["W"])
+    np.testing.assert_allclose(out, np.array(g["expected"]), atol=g["tol"])
+
+
+def test_make_boxes_golden(golden):
+    for case in golden["make_boxes"]:
+        N, k, H, W = case["N"], case["k"], case["H"], case["W"]
+        anchors = np.array(case["anchors"], np.float32)
+        head = np.zeros((N, 4 * k, H, W), np.float32)
+        for (n, a, y, x), v in case["inputs"]:
+            head[n, 4 * a:4 * a + 4, y, x] = v
+        for n in range(N):
+            boxes = O.make_boxes(head[n], case["x0"], case["y0"], case["sx"], case["sy"], anchors)
+            for (nn, y, x, a), v in case["expected"]:
+                if nn != n:
+                    continue
+                np.testing.assert_allclose(boxes[a * H * W + y * W + x], v, atol=1e-4)
+
+
+def test_reshape_consistency_golden(golden):
+    g = golden["reshape_consistency"]
+    k, D, H, W = g["k"], g["D"], g["H"], g["W"]
+    anchors = np.array(g["anchors"], np.float32).T.copy()  # Lua fills columns: anchors[:,a] = (w,h)
+    head = np.zeros((4 * k, H, W), np.float32)
+    t = g["set_transform"]
+    head[4 * t["a"]:4 * t["a"] + 4, t["y"], t["x"]] = t["value"]
+    feats = np.zeros((D * k, H, W), np.float32)
+    fz = g["set_feature"]
+    feats[D * fz["a"]:D * fz["a"] + D, fz["y"], fz["x"]] = fz["value"]
+    boxes = O.make_boxes(head, g["x0"], g["y0"], g["sx"], g["sy"], anchors)
+    np.testing.assert_array_equal(boxes[g["expected_row"]], np.array(g["expected_box"], np.float32))
+    np.testing.assert_array_equal(O.reshape_box_features(feats, k)[g["expected_row"]], np.full(D, 100, np.float32))
+
+
+def test_decode_sequence_golden(golden):
+    g = golden["decode_sequence"]
+    itt = {int(k): v for k, v in g["idx_to_token"].items()}
+    assert O.decode_sequence(np.array(g["seq"]), itt, g["vocab_size"]) == g["expected"]
+
+
+def test_box_conversion_roundtrip():
+    # test/box_conversion_test.lua:12-23
+    rng = np.random.default_rng(1)
+    xywh = rng.standard_normal((100, 4)).astype(np.float32)
+    xywh[:, 2:] = np.abs(xywh[:, 2:])
+    a = O.xywh_to_x1y1x2y2(xywh)
+    b = O.x1y1x2y2_to_xywh(a)
+    np.testing.assert_allclose(O.xywh_to_x1y1x2y2(b), a, atol=1e-6)
+    np.testing.assert_allclose(b, xywh, atol=1e-6)
+
+
+def test_clip_loses_one_pixel_and_keeps_oob_valid():
+    # code-as-written behaviour: box_utils.lua:486-523
+    boxes = np.array([[50, 40, 21, 11], [-500, -500, 10, 10]], np.float32)
+    c, v = O.clip_boxes_xcycwh(boxes, 1, 1, 720, 600)
+    np.testing.assert_array_equal(c[0], [50, 40, 20, 10])
+    assert v.tolist() == [True, True]
+    np.testing.assert_array_equal(c[1], [1.5, 1.5, 1, 1])
+
+
+def test_roi_pool_c_equals_numpy_and_identity_property():
+    rng = np.random.default_rng(2)
+    feat = rng.standard_normal((16, 9, 11)).astype(np.float32)
+    H, W = 144, 176
+    boxes = np.array([[88.5, 72.5, 176, 144], [30, 40, 50, 60], [170, 10, 40, 40], [-20, 160, 30, 30]], np.float32)
+    a = O.bilinear_roi_pool(feat, boxes, H, W)
+    b = O.bilinear_roi_pool_np(feat, boxes, H, W)
+    np.testing.assert_allclose(a, b, atol=1e-6)
+    # pixel-correspondence property (BoxToAffine_visual_test.ipynb): the whole-image box
+    # sampled at the feature map's own resolution returns the feature map.
+    full = O.bilinear_roi_pool(feat, boxes[:1], H, W, HH=9, WW=11)
+    np.testing.assert_allclose(full[0], feat, atol=1e-5)
