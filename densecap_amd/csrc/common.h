@@ -1,0 +1,91 @@
+// Shared declarations for libdensecap_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/densecap.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- MFMA contraction engine (mfma_gemm.hip) --------------------------------
+struct GemmDesc {
+  const float* A = nullptr;   // dense: (M,K) row-major; conv: (nimg,H,W,Cin) HWC activations
+  const float* W = nullptr;   // (N,K) row-major, K contiguous
+  const float* bias = nullptr;  // (N) or null
+  float* C = nullptr;         // (M,ldc)
+  int M = 0, N = 0, K = 0, ldc = 0;
+  int relu = 0;
+  // conv3x3 implicit GEMM (mode 1): M = nimg*H*Wd, K = 9*Cin
+  int conv = 0, H = 0, Wd = 0, Cin = 0;
+  // optional gathered row term (LSTM input gates): C[m][n] += rowterm[rowidx[m]*rowterm_ld + n]
+  const float* rowterm = nullptr;
+  const int32_t* rowidx = nullptr;   // values are 1-based token ids -> row = id-1
+  int rowterm_ld = 0;
+};
+// Launches the fp32 MFMA kernel on `stream`; returns hipSuccess or the launch error.
+hipError_t launch_mfma_gemm(const GemmDesc& d, hipStream_t stream);
+double gemm_flops(const GemmDesc& d);
+
+// ---- element-wise / layout kernels (elementwise.hip) ---------------------------
+hipError_t launch_chw_to_hwc(const float* in, float* out, int C, int H, int W, hipStream_t s);
+hipError_t launch_hwc_to_chw(const float* in, float* out, int C, int H, int W, hipStream_t s);
+hipError_t launch_pack_conv3x3(const float* w_oihw, float* w_packed, int Cout, int Cin, hipStream_t s);
+hipError_t launch_conv3x3_c3(const float* in_chw, const float* w_oihw, const float* bias, float* out_hwc,
+                             int H, int W, int Cout, int relu, hipStream_t s);
+hipError_t launch_maxpool2x2_ceil(const float* in, float* out, int nimg, int H, int W, int C, hipStream_t s);
+hipError_t launch_transpose2d(const float* in, float* out, int rows, int cols, hipStream_t s);
+// fc6 weight (N, C*HH*WW) with k = c*HW + p  ->  k' = p*C + c
+hipError_t launch_permute_fc6(const float* in, float* out, int N, int C, int HW, hipStream_t s);
+// LSTM pointwise: gates (n,4Hd) [i f o g], c (n,Hd) in/out, h (n,Hd) out
+hipError_t launch_lstm_pointwise(const float* gates, float* c, float* h, int n, int Hd, int zero_c, hipStream_t s);
+// row argmax (first max on ties) -> tok (n) 1-based, also seq[m*T + t]
+hipError_t launch_row_argmax(const float* logits, int n, int N, int ld, int32_t* tok, int32_t* seq, int T, int t,
+                             hipStream_t s);
+hipError_t launch_fill_i32(int32_t* p, int32_t v, int n, hipStream_t s);
+// objectness + box regression heads + final ApplyBoxTransform (DenseCapModel.lua:134,139-140)
+hipError_t launch_recog_heads(const float* codes, const float* w5 /*(5,D): obj, 4 boxreg*/, const float* b5,
+                              const float* roi_boxes, float* obj, float* trans, float* final_boxes, int n, int D,
+                              hipStream_t s);
+
+// ---- box pipeline (boxes.hip) ------------------------------------------------------
+hipError_t launch_make_anchors(float* out, int h, int w, float x0, float y0, float sx, float sy,
+                               const float* anchors, int k, hipStream_t s);
+hipError_t launch_apply_box_transform(const float* boxes, const float* trans, float* out, int n, hipStream_t s);
+hipError_t launch_clip_boxes(const float* boxes, float* clipped, uint8_t* valid, int n, float x_min, float y_min,
+                             float x_max, float y_max, hipStream_t s);
+hipError_t launch_xcycwh_to_x1y1x2y2(const float* boxes, float* out, int n, hipStream_t s);
+hipError_t launch_box_iou(const float* b1, const float* b2, float* out, int B1, int B2, int convention,
+                          hipStream_t s);
+hipError_t launch_rpn_decode(const float* heads, int h, int w, int k, const float* anchors, float x0, float y0,
+                             float sx, float sy, int img_h, int img_w, float* boxes, float* anchors_out,
+                             float* trans, float* x1y1x2y2, float* p, uint8_t* valid, hipStream_t s);
+struct NmsWorkspace {
+  // device scratch, sized for n_cap boxes
+  int n_cap = 0;
+  uint32_t* rank = nullptr;       // (n)
+  int32_t* order = nullptr;       // (n) sorted position -> original index
+  float* sboxes = nullptr;        // (n,4) boxes in sorted order
+  float* sarea = nullptr;         // (n)
+  int32_t* nvalid = nullptr;      // (1)
+  unsigned long long* mask = nullptr;  // (n, nwords)
+  size_t mask_words = 0;
+};
+size_t nms_workspace_bytes(int n);
+hipError_t nms_workspace_bind(NmsWorkspace& ws, void* base, int n);
+// n_dev (optional device int32) overrides n at run time (n is then the capacity)
+hipError_t launch_nms(NmsWorkspace& ws, const float* boxes, const float* scores, const uint8_t* valid, int n,
+                      const int32_t* n_dev, float thresh, int max_boxes, int32_t* picks, int32_t* count,
+                      hipStream_t s);
+// out[i] = src[idx[i]] rows of `width` floats for i < *count (rows >= *count zero-filled up to cap)
+hipError_t launch_gather_rows(const float* src, const int32_t* idx, const int32_t* count, int cap, int width,
+                              float* out, hipStream_t s);
+hipError_t launch_gather_rows_i32(const int32_t* src, const int32_t* idx, const int32_t* count, int cap, int width,
+                                  int32_t* out, hipStream_t s);
+
+// ---- bilinear RoI pooling (roipool.hip) ---------------------------------------------
+hipError_t launch_bilinear_roi_pool(const float* feat_hwc, int h, int w, int C, const float* boxes, int B,
+                                    const int32_t* B_dev, int img_h, int img_w, int HH, int WW, float* out,
+                                    int out_layout, hipStream_t s);

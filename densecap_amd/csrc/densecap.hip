@@ -1,0 +1,822 @@
+// libdensecap_hip.so -- C ABI (include/densecap.h) over the gfx950 kernels.
+//
+// A dc_ctx owns: the repacked weights, `lanes` (stream + workspace for one in-flight image,
+// used to software-pipeline run_model.lua's image loop), and the per-stage HIP events.
+// The whole forward of one image is enqueued on one stream without host round trips
+// (box counts stay on the device); the host waits once, for the result copy.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+
+#include "common.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct VggItem { int cin, cout; bool pool_after; };
+const VggItem kVgg[DC_NUM_VGG_CONVS] = {
+    {3, 64, false},    {64, 64, true},    {64, 128, false},  {128, 128, true},  {128, 256, false},
+    {256, 256, false}, {256, 256, true},  {256, 512, false}, {512, 512, false}, {512, 512, true},
+    {512, 512, false}, {512, 512, false}, {512, 512, false}};  // no pool5 (DenseCapModel.lua:61-63)
+
+enum Stage { ST_TRUNK = 0, ST_RPN, ST_NMS1, ST_ROIPOOL, ST_FC, ST_HEADS, ST_LSTM, ST_NMS2, ST_COUNT };
+const char* kStageNames[ST_COUNT] = {"vgg16_trunk", "rpn_conv_heads_decode", "rpn_nms",   "bilinear_roi_pool",
+                                     "fc6_fc7",     "recog_heads",           "lstm_decode", "final_nms_gather"};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct Lane {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[ST_COUNT + 1] = {};
+  int H = 0, W = 0, P = 0;  // sizes the workspace is built for
+  int fh = 0, fw = 0, A = 0;
+  DevBuf arena;               // one allocation, carved below
+  float *img = nullptr, *act[2] = {nullptr, nullptr}, *feat = nullptr, *rpn_hidden = nullptr, *heads = nullptr;
+  float *rpn_boxes = nullptr, *rpn_xyxy = nullptr, *rpn_p = nullptr;
+  uint8_t* rpn_valid = nullptr;
+  NmsWorkspace nms;
+  void* nms_base = nullptr;
+  int32_t *picks1 = nullptr, *count1 = nullptr, *picks2 = nullptr, *count2 = nullptr;
+  float *roi_boxes = nullptr, *roi_feats = nullptr, *fc6_out = nullptr, *codes = nullptr;
+  float *obj = nullptr, *final_trans = nullptr, *final_boxes = nullptr, *final_xyxy = nullptr;
+  float *enc = nullptr, *gates = nullptr, *hstate = nullptr, *cstate = nullptr, *logits = nullptr;
+  int32_t *tok = nullptr, *seq = nullptr;
+  float *out_boxes = nullptr, *out_scores = nullptr, *out_feats = nullptr;
+  int32_t* out_tokens = nullptr;
+  // pinned host staging
+  void* host_stage = nullptr;
+  size_t host_stage_bytes = 0;
+  bool busy = false;
+  dc_result* pending = nullptr;
+  bool pending_feats = false;
+  float* pending_feat_dst = nullptr; float* pending_box_dst = nullptr; int32_t* pending_k_dst = nullptr;
+  int pending_capacity = 0;
+  float stage_ms[ST_COUNT] = {};
+  bool have_times = false;
+};
+
+struct ProfEvt { hipEvent_t a, b; double flops; };
+
+}  // namespace
+
+struct dc_ctx {
+  int device = 0;
+  std::string err;
+  bool have_weights = false;
+  float rpn_nms_thresh = 0.7f, final_nms_thresh = 0.3f;
+  int num_proposals = 300;  // LocalizationLayer default (LocalizationLayer.lua:237); run_model sets 1000
+  // dims
+  int k = 0, R = 0, V = 0, T = 0, E = 0, Hd = 0, D = 0;
+  float fc[4] = {0, 0, 0, 0};
+  // device weights
+  std::vector<void*> owned;
+  float* conv_w[DC_NUM_VGG_CONVS] = {};
+  float* conv_b[DC_NUM_VGG_CONVS] = {};
+  float *rpn_w = nullptr, *rpn_b = nullptr, *heads_w = nullptr, *heads_b = nullptr;
+  float *fc6_w = nullptr, *fc6_b = nullptr, *fc7_w = nullptr, *fc7_b = nullptr, *head5_w = nullptr, *head5_b = nullptr;
+  float *enc_w = nullptr, *enc_b = nullptr, *wxT = nullptr, *whT = nullptr, *lstm_b = nullptr, *xg = nullptr;
+  float *out_w = nullptr, *out_b = nullptr, *anchors = nullptr;
+  std::vector<std::unique_ptr<Lane>> lanes;
+  // MFMA profile
+  bool prof = false;
+  std::vector<ProfEvt> prof_pending;
+  std::vector<hipEvent_t> prof_pool;
+  int64_t prof_launches = 0;
+  double prof_ms = 0, prof_flops = 0;
+
+  int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    g_last_error = buf;
+    return code;
+  }
+};
+
+namespace {
+
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess) return ctx->fail(DC_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                           __FILE__, __LINE__);                                      \
+  } while (0)
+#define DCCHK(expr)            \
+  do {                         \
+    int _r = (expr);           \
+    if (_r != DC_OK) return _r; \
+  } while (0)
+
+int dev_alloc(dc_ctx* ctx, void** p, size_t bytes) {
+  HIPCHK(hipMalloc(p, bytes ? bytes : 16));
+  ctx->owned.push_back(*p);
+  return DC_OK;
+}
+int upload(dc_ctx* ctx, float** dst, const float* host, size_t n) {
+  if (!host) return ctx->fail(DC_E_INVALID, "dc_load_weights: null weight pointer");
+  DCCHK(dev_alloc(ctx, reinterpret_cast<void**>(dst), n * sizeof(float)));
+  HIPCHK(hipMemcpy(*dst, host, n * sizeof(float), hipMemcpyHostToDevice));
+  return DC_OK;
+}
+
+hipEvent_t prof_event(dc_ctx* ctx) {
+  if (!ctx->prof_pool.empty()) {
+    hipEvent_t e = ctx->prof_pool.back();
+    ctx->prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  hipEventCreate(&e);
+  return e;
+}
+
+// every MFMA contraction goes through here (optionally bracketed by HIP events)
+int run_gemm(dc_ctx* ctx, const GemmDesc& d, hipStream_t s) {
+  if (ctx->prof) {
+    ProfEvt pe{prof_event(ctx), prof_event(ctx), gemm_flops(d)};
+    hipEventRecord(pe.a, s);
+    hipError_t e = launch_mfma_gemm(d, s);
+    hipEventRecord(pe.b, s);
+    ctx->prof_pending.push_back(pe);
+    if (e != hipSuccess) return ctx->fail(DC_E_HIP, "mfma gemm launch failed: %s", hipGetErrorString(e));
+    return DC_OK;
+  }
+  hipError_t e = launch_mfma_gemm(d, s);
+  if (e != hipSuccess)
+    return ctx->fail(DC_E_HIP, "mfma gemm launch failed: %s (M=%d N=%d K=%d conv=%d)", hipGetErrorString(e), d.M,
+                     d.N, d.K, d.conv);
+  return DC_OK;
+}
+void prof_collect(dc_ctx* ctx) {
+  for (auto& pe : ctx->prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+      ctx->prof_ms += ms;
+      ctx->prof_flops += pe.flops;
+      ctx->prof_launches += 1;
+    }
+    ctx->prof_pool.push_back(pe.a);
+    ctx->prof_pool.push_back(pe.b);
+  }
+  ctx->prof_pending.clear();
+}
+
+int linear(dc_ctx* ctx, hipStream_t s, const float* A, const float* W, const float* bias, float* C, int M, int N,
+           int K, int relu) {
+  GemmDesc d;
+  d.A = A; d.W = W; d.bias = bias; d.C = C; d.M = M; d.N = N; d.K = K; d.ldc = N; d.relu = relu;
+  return run_gemm(ctx, d, s);
+}
+int conv3x3(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, const float* b, float* out, int nimg, int H,
+            int W, int Cin, int Cout, int relu) {
+  GemmDesc d;
+  d.A = in; d.W = w; d.bias = b; d.C = out; d.M = nimg * H * W; d.N = Cout; d.K = 9 * Cin; d.ldc = Cout;
+  d.relu = relu; d.conv = 1; d.H = H; d.Wd = W; d.Cin = Cin;
+  return run_gemm(ctx, d, s);
+}
+
+size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// (Re)build a lane's workspace for image size (H,W) and proposal capacity P.
+int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P) {
+  if (L.stream == nullptr) {
+    HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    for (auto& e : L.ev) HIPCHK(hipEventCreate(&e));
+  }
+  if (L.H == H && L.W == W && L.P == P && L.arena.p) return DC_OK;
+  if (L.arena.p) {
+    HIPCHK(hipStreamSynchronize(L.stream));
+    HIPCHK(hipFree(L.arena.p));
+    L.arena = DevBuf();
+  }
+  int fh = H, fw = W;
+  for (int i = 0; i < DC_NUM_VGG_CONVS; ++i)
+    if (kVgg[i].pool_after) { fh = (fh + 1) / 2; fw = (fw + 1) / 2; }
+  const int A = ctx->k * fh * fw;
+  const int Tn = ctx->T, V1 = ctx->V + 1, Dm = ctx->D, E = ctx->E, Hd = ctx->Hd;
+  const int nms_n = std::max(A, P);
+  struct Carve { void** p; size_t bytes; };
+  const size_t act_bytes = (size_t)H * W * 64 * sizeof(float);
+  std::vector<Carve> cv = {
+      {(void**)&L.img, (size_t)3 * H * W * 4},
+      {(void**)&L.act[0], act_bytes},
+      {(void**)&L.act[1], act_bytes},
+      {(void**)&L.rpn_hidden, (size_t)fh * fw * ctx->R * 4},
+      {(void**)&L.heads, (size_t)fh * fw * 6 * ctx->k * 4},
+      {(void**)&L.rpn_boxes, (size_t)A * 16},
+      {(void**)&L.rpn_xyxy, (size_t)A * 16},
+      {(void**)&L.rpn_p, (size_t)A * 4},
+      {(void**)&L.rpn_valid, (size_t)A},
+      {(void**)&L.nms_base, nms_workspace_bytes(nms_n)},
+      {(void**)&L.picks1, (size_t)P * 4},
+      {(void**)&L.count1, 256},
+      {(void**)&L.picks2, (size_t)P * 4},
+      {(void**)&L.count2, 256},
+      {(void**)&L.roi_boxes, (size_t)P * 16},
+      {(void**)&L.roi_feats, (size_t)P * 49 * 512 * 4},
+      {(void**)&L.fc6_out, (size_t)P * Dm * 4},
+      {(void**)&L.codes, (size_t)P * Dm * 4},
+      {(void**)&L.obj, (size_t)P * 4},
+      {(void**)&L.final_trans, (size_t)P * 16},
+      {(void**)&L.final_boxes, (size_t)P * 16},
+      {(void**)&L.final_xyxy, (size_t)P * 16},
+      {(void**)&L.enc, (size_t)P * E * 4},
+      {(void**)&L.gates, (size_t)P * 4 * Hd * 4},
+      {(void**)&L.hstate, (size_t)P * Hd * 4},
+      {(void**)&L.cstate, (size_t)P * Hd * 4},
+      {(void**)&L.logits, (size_t)P * V1 * 4},
+      {(void**)&L.tok, (size_t)P * 4},
+      {(void**)&L.seq, (size_t)P * Tn * 4},
+      {(void**)&L.out_boxes, (size_t)P * 16},
+      {(void**)&L.out_scores, (size_t)P * 4},
+      {(void**)&L.out_tokens, (size_t)P * Tn * 4},
+      {(void**)&L.out_feats, (size_t)P * Dm * 4},
+  };
+  size_t total = 0;
+  for (auto& c : cv) total += al(c.bytes);
+  HIPCHK(hipMalloc(&L.arena.p, total));
+  L.arena.bytes = total;
+  char* p = static_cast<char*>(L.arena.p);
+  for (auto& c : cv) { *c.p = p; p += al(c.bytes); }
+  nms_workspace_bind(L.nms, L.nms_base, nms_n);
+  const size_t hs = 256 + (size_t)P * (16 + 4 + Tn * 4 + Dm * 4);
+  if (L.host_stage_bytes < hs) {
+    if (L.host_stage) HIPCHK(hipHostFree(L.host_stage));
+    HIPCHK(hipHostMalloc(&L.host_stage, hs, hipHostMallocDefault));
+    L.host_stage_bytes = hs;
+  }
+  L.H = H; L.W = W; L.P = P; L.fh = fh; L.fw = fw; L.A = A;
+  return DC_OK;
+}
+
+#define KCHK(expr)                                                                                      \
+  do {                                                                                                  \
+    hipError_t _e = (expr);                                                                             \
+    if (_e != hipSuccess) return ctx->fail(DC_E_HIP, "%s: %s", #expr, hipGetErrorString(_e));           \
+  } while (0)
+
+// LanguageModel:sample greedy decode (LanguageModel.lua:293-348) for n rows of `codes`.
+int lm_sample(dc_ctx* ctx, Lane& L, const float* codes, int n, int32_t* seq_out) {
+  hipStream_t s = L.stream;
+  const int E = ctx->E, Hd = ctx->Hd, V1 = ctx->V + 1, T = ctx->T;
+  // image_encoder: Linear(4096,E)+ReLU (:27-30)
+  DCCHK(linear(ctx, s, codes, ctx->enc_w, ctx->enc_b, L.enc, n, E, ctx->D, 1));
+  // step 0: gates = (b + enc.Wx) + 0.Wh ; c0 = 0 (output ignored, no vocab projection needed)
+  DCCHK(linear(ctx, s, L.enc, ctx->wxT, ctx->lstm_b, L.gates, n, 4 * Hd, E, 0));
+  KCHK(launch_lstm_pointwise(L.gates, L.cstate, L.hstate, n, Hd, 1, s));
+  KCHK(launch_fill_i32(L.tok, V1, n, s));  // START token = V+1 (:32,320)
+  for (int t = 0; t < T; ++t) {
+    // gates = (b + Emb[tok].Wx) + h.Wh ; the first term is the precomputed table xg[tok]
+    GemmDesc d;
+    d.A = L.hstate; d.W = ctx->whT; d.C = L.gates; d.M = n; d.N = 4 * Hd; d.K = Hd; d.ldc = 4 * Hd;
+    d.rowterm = ctx->xg; d.rowidx = L.tok; d.rowterm_ld = 4 * Hd;
+    DCCHK(run_gemm(ctx, d, s));
+    KCHK(launch_lstm_pointwise(L.gates, L.cstate, L.hstate, n, Hd, 0, s));
+    DCCHK(linear(ctx, s, L.hstate, ctx->out_w, ctx->out_b, L.logits, n, V1, Hd, 0));
+    KCHK(launch_row_argmax(L.logits, n, V1, V1, L.tok, seq_out, T, t, s));
+  }
+  return DC_OK;
+}
+
+// Enqueue the whole forward of one image on the lane's stream (no host sync).
+int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int img_on_device, bool features_only) {
+  hipStream_t s = L.stream;
+  const int H = L.H, W = L.W, P = L.P;
+  if (img_on_device) HIPCHK(hipMemcpyAsync(L.img, img, (size_t)3 * H * W * 4, hipMemcpyDeviceToDevice, s));
+  else HIPCHK(hipMemcpyAsync(L.img, img, (size_t)3 * H * W * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipEventRecord(L.ev[0], s));
+  // ---- VGG-16 trunk (DenseCapModel.lua:73-76) -------------------------------------------
+  int h = H, w = W, cur = 0;
+  KCHK(launch_conv3x3_c3(L.img, ctx->conv_w[0], ctx->conv_b[0], L.act[0], H, W, 64, 1, s));
+  for (int i = 1; i < DC_NUM_VGG_CONVS; ++i) {
+    if (kVgg[i - 1].pool_after) {
+      KCHK(launch_maxpool2x2_ceil(L.act[cur], L.act[cur ^ 1], 1, h, w, kVgg[i - 1].cout, s));
+      h = (h + 1) / 2; w = (w + 1) / 2; cur ^= 1;
+    }
+    DCCHK(conv3x3(ctx, s, L.act[cur], ctx->conv_w[i], ctx->conv_b[i], L.act[cur ^ 1], 1, h, w, kVgg[i].cin,
+                  kVgg[i].cout, 1));
+    cur ^= 1;
+  }
+  L.feat = L.act[cur];
+  HIPCHK(hipEventRecord(L.ev[1], s));
+  // ---- RPN (LocalizationLayer.lua:265, build_rpn :609-690) ----------------------------------
+  DCCHK(conv3x3(ctx, s, L.feat, ctx->rpn_w, ctx->rpn_b, L.rpn_hidden, 1, h, w, 512, ctx->R, 1));
+  DCCHK(linear(ctx, s, L.rpn_hidden, ctx->heads_w, ctx->heads_b, L.heads, h * w, 6 * ctx->k, ctx->R, 0));
+  KCHK(launch_rpn_decode(L.heads, h, w, ctx->k, ctx->anchors, ctx->fc[0], ctx->fc[1], ctx->fc[2], ctx->fc[3], H, W,
+                         L.rpn_boxes, nullptr, nullptr, L.rpn_xyxy, L.rpn_p, L.rpn_valid, s));
+  HIPCHK(hipEventRecord(L.ev[2], s));
+  // ---- RPN NMS (LocalizationLayer.lua:318-338) ------------------------------------------------
+  KCHK(launch_nms(L.nms, L.rpn_xyxy, L.rpn_p, L.rpn_valid, L.A, nullptr, ctx->rpn_nms_thresh, P, L.picks1, L.count1,
+                  s));
+  KCHK(launch_gather_rows(L.rpn_boxes, L.picks1, L.count1, P, 4, L.roi_boxes, s));
+  HIPCHK(hipEventRecord(L.ev[3], s));
+  // ---- bilinear RoI pooling (LocalizationLayer.lua:346-349) -----------------------------------
+  KCHK(launch_bilinear_roi_pool(L.feat, h, w, 512, L.roi_boxes, P, L.count1, H, W, 7, 7, L.roi_feats, 1, s));
+  HIPCHK(hipEventRecord(L.ev[4], s));
+  // ---- recog_base fc6/fc7 (DenseCapModel.lua:133) ------------------------------------------------
+  DCCHK(linear(ctx, s, L.roi_feats, ctx->fc6_w, ctx->fc6_b, L.fc6_out, P, ctx->D, 49 * 512, 1));
+  DCCHK(linear(ctx, s, L.fc6_out, ctx->fc7_w, ctx->fc7_b, L.codes, P, ctx->D, ctx->D, 1));
+  HIPCHK(hipEventRecord(L.ev[5], s));
+  // ---- objectness / box regression / final boxes (DenseCapModel.lua:134,139-140) -----------------
+  KCHK(launch_recog_heads(L.codes, ctx->head5_w, ctx->head5_b, L.roi_boxes, L.obj, L.final_trans, L.final_boxes, P,
+                          ctx->D, s));
+  HIPCHK(hipEventRecord(L.ev[6], s));
+  // ---- language model ---------------------------------------------------------------------------
+  if (!features_only) DCCHK(lm_sample(ctx, L, L.codes, P, L.seq));
+  HIPCHK(hipEventRecord(L.ev[7], s));
+  // ---- final NMS + gather (DenseCapModel.lua:261-275) ----------------------------------------------
+  KCHK(launch_xcycwh_to_x1y1x2y2(L.final_boxes, L.final_xyxy, P, s));
+  if (ctx->final_nms_thresh > 0.f) {
+    KCHK(launch_nms(L.nms, L.final_xyxy, L.obj, nullptr, P, L.count1, ctx->final_nms_thresh, -1, L.picks2, L.count2,
+                    s));
+  } else {
+    return ctx->fail(DC_E_UNSUPPORTED, "final_nms_thresh <= 0 is not supported");
+  }
+  KCHK(launch_gather_rows(L.final_boxes, L.picks2, L.count2, P, 4, L.out_boxes, s));
+  KCHK(launch_gather_rows(L.obj, L.picks2, L.count2, P, 1, L.out_scores, s));
+  if (features_only) KCHK(launch_gather_rows(L.codes, L.picks2, L.count2, P, ctx->D, L.out_feats, s));
+  else KCHK(launch_gather_rows_i32(L.seq, L.picks2, L.count2, P, ctx->T, L.out_tokens, s));
+  HIPCHK(hipEventRecord(L.ev[8], s));
+  // ---- results -> pinned host staging ----------------------------------------------------------------
+  char* hs = static_cast<char*>(L.host_stage);
+  HIPCHK(hipMemcpyAsync(hs, L.count2, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(hs + 256, L.out_boxes, (size_t)P * 16, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(hs + 256 + (size_t)P * 16, L.out_scores, (size_t)P * 4, hipMemcpyDeviceToHost, s));
+  if (features_only)
+    HIPCHK(hipMemcpyAsync(hs + 256 + (size_t)P * 20, L.out_feats, (size_t)P * ctx->D * 4, hipMemcpyDeviceToHost, s));
+  else
+    HIPCHK(hipMemcpyAsync(hs + 256 + (size_t)P * 20, L.out_tokens, (size_t)P * ctx->T * 4, hipMemcpyDeviceToHost, s));
+  L.busy = true;
+  L.pending_feats = features_only;
+  return DC_OK;
+}
+
+// Wait for the lane's in-flight image and hand the result to the caller's buffers.
+int harvest(dc_ctx* ctx, Lane& L) {
+  if (!L.busy) return DC_OK;
+  HIPCHK(hipStreamSynchronize(L.stream));
+  L.busy = false;
+  for (int i = 0; i < ST_COUNT; ++i) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, L.ev[i], L.ev[i + 1]);
+    L.stage_ms[i] = ms;
+  }
+  L.have_times = true;
+  const char* hs = static_cast<const char*>(L.host_stage);
+  int K = *reinterpret_cast<const int32_t*>(hs);
+  const int P = L.P;
+  if (L.pending_feats) {
+    K = std::min(K, L.pending_capacity);
+    if (L.pending_k_dst) *L.pending_k_dst = K;
+    if (L.pending_box_dst) memcpy(L.pending_box_dst, hs + 256, (size_t)K * 16);
+    if (L.pending_feat_dst) memcpy(L.pending_feat_dst, hs + 256 + (size_t)P * 20, (size_t)K * ctx->D * 4);
+  } else if (L.pending) {
+    dc_result* r = L.pending;
+    K = std::min(K, (int)r->capacity);
+    r->K = K;
+    r->T = ctx->T;
+    if (r->boxes) memcpy(r->boxes, hs + 256, (size_t)K * 16);
+    if (r->scores) memcpy(r->scores, hs + 256 + (size_t)P * 16, (size_t)K * 4);
+    if (r->tokens) memcpy(r->tokens, hs + 256 + (size_t)P * 20, (size_t)K * ctx->T * 4);
+  }
+  L.pending = nullptr;
+  return DC_OK;
+}
+
+Lane& lane0(dc_ctx* ctx) {
+  if (ctx->lanes.empty()) ctx->lanes.emplace_back(new Lane());
+  return *ctx->lanes[0];
+}
+int lane0_stream(dc_ctx* ctx, hipStream_t* s) {
+  Lane& L = lane0(ctx);
+  if (L.stream == nullptr) {
+    HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    for (auto& e : L.ev) HIPCHK(hipEventCreate(&e));
+  }
+  *s = L.stream;
+  return DC_OK;
+}
+
+}  // namespace
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+extern "C" {
+
+int dc_create(dc_ctx** out, int hip_device) {
+  if (!out) { g_last_error = "dc_create: null out"; return DC_E_INVALID; }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_last_error = std::string("dc_create: no HIP device available (") + hipGetErrorString(e) +
+                   "); this library has no CPU fallback";
+    return DC_E_HIP;
+  }
+  if (hip_device < 0 || hip_device >= ndev) { g_last_error = "dc_create: bad device index"; return DC_E_INVALID; }
+  e = hipSetDevice(hip_device);
+  if (e != hipSuccess) { g_last_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return DC_E_HIP; }
+  dc_ctx* ctx = new dc_ctx();
+  ctx->device = hip_device;
+  *out = ctx;
+  return DC_OK;
+}
+
+void dc_destroy(dc_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipDeviceSynchronize();
+  for (auto& lp : ctx->lanes) {
+    Lane& L = *lp;
+    if (L.arena.p) hipFree(L.arena.p);
+    if (L.host_stage) hipHostFree(L.host_stage);
+    for (auto& ev : L.ev) if (ev) hipEventDestroy(ev);
+    if (L.stream) hipStreamDestroy(L.stream);
+  }
+  for (void* p : ctx->owned) hipFree(p);
+  for (auto e : ctx->prof_pool) hipEventDestroy(e);
+  delete ctx;
+}
+
+const char* dc_last_error(const dc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int dc_set_test_args(dc_ctx* ctx, float rpn_nms_thresh, float final_nms_thresh, int num_proposals) {
+  if (!ctx) return DC_E_INVALID;
+  if (num_proposals <= 0 || num_proposals > 65536)
+    return ctx->fail(DC_E_UNSUPPORTED, "num_proposals must be in [1,65536] (got %d)", num_proposals);
+  ctx->rpn_nms_thresh = rpn_nms_thresh;
+  ctx->final_nms_thresh = final_nms_thresh;
+  ctx->num_proposals = num_proposals;
+  return DC_OK;
+}
+
+int dc_load_weights(dc_ctx* ctx, const dc_weights* w) {
+  if (!ctx || !w) return DC_E_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->have_weights) return ctx->fail(DC_E_STATE, "weights already loaded; create a new ctx");
+  if (w->num_anchors <= 0 || w->rpn_hidden % 32 || w->fc_dim % 256 || w->enc_size % 32 || w->rnn_size % 32 ||
+      w->vocab_size <= 0 || w->seq_length <= 0)
+    return ctx->fail(DC_E_INVALID, "dc_load_weights: unsupported dimensions");
+  ctx->k = w->num_anchors; ctx->R = w->rpn_hidden; ctx->V = w->vocab_size; ctx->T = w->seq_length;
+  ctx->E = w->enc_size; ctx->Hd = w->rnn_size; ctx->D = w->fc_dim;
+  memcpy(ctx->fc, w->field_centers, sizeof ctx->fc);
+  hipStream_t s;
+  DCCHK(lane0_stream(ctx, &s));
+  const int k = ctx->k, R = ctx->R, V = ctx->V, E = ctx->E, Hd = ctx->Hd, D = ctx->D;
+  float* tmp = nullptr;
+  // VGG convs: conv1_1 stays OIHW (direct kernel); the rest are repacked to (Cout, 9*Cin)
+  DCCHK(upload(ctx, &ctx->conv_w[0], w->conv_w[0], (size_t)64 * 27));
+  DCCHK(upload(ctx, &ctx->conv_b[0], w->conv_b[0], 64));
+  for (int i = 1; i < DC_NUM_VGG_CONVS; ++i) {
+    const size_t n = (size_t)kVgg[i].cout * kVgg[i].cin * 9;
+    if (!w->conv_w[i] || !w->conv_b[i]) return ctx->fail(DC_E_INVALID, "null conv weight %d", i);
+    HIPCHK(hipMalloc(&tmp, n * 4));
+    HIPCHK(hipMemcpy(tmp, w->conv_w[i], n * 4, hipMemcpyHostToDevice));
+    DCCHK(dev_alloc(ctx, (void**)&ctx->conv_w[i], n * 4));
+    KCHK(launch_pack_conv3x3(tmp, ctx->conv_w[i], kVgg[i].cout, kVgg[i].cin, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(tmp));
+    DCCHK(upload(ctx, &ctx->conv_b[i], w->conv_b[i], kVgg[i].cout));
+  }
+  {  // RPN conv
+    const size_t n = (size_t)R * 512 * 9;
+    if (!w->rpn_conv_w) return ctx->fail(DC_E_INVALID, "null rpn_conv_w");
+    HIPCHK(hipMalloc(&tmp, n * 4));
+    HIPCHK(hipMemcpy(tmp, w->rpn_conv_w, n * 4, hipMemcpyHostToDevice));
+    DCCHK(dev_alloc(ctx, (void**)&ctx->rpn_w, n * 4));
+    KCHK(launch_pack_conv3x3(tmp, ctx->rpn_w, R, 512, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(tmp));
+    DCCHK(upload(ctx, &ctx->rpn_b, w->rpn_conv_b, R));
+  }
+  {  // fused 1x1 heads: rows [0,4k) box, [4k,6k) score
+    if (!w->rpn_box_w || !w->rpn_score_w || !w->rpn_box_b || !w->rpn_score_b)
+      return ctx->fail(DC_E_INVALID, "null rpn head weight");
+    std::vector<float> hw((size_t)6 * k * R), hb((size_t)6 * k);
+    memcpy(hw.data(), w->rpn_box_w, (size_t)4 * k * R * 4);
+    memcpy(hw.data() + (size_t)4 * k * R, w->rpn_score_w, (size_t)2 * k * R * 4);
+    memcpy(hb.data(), w->rpn_box_b, (size_t)4 * k * 4);
+    memcpy(hb.data() + 4 * k, w->rpn_score_b, (size_t)2 * k * 4);
+    DCCHK(upload(ctx, &ctx->heads_w, hw.data(), hw.size()));
+    DCCHK(upload(ctx, &ctx->heads_b, hb.data(), hb.size()));
+  }
+  {  // fc6: permute K from (c,i,j) to (i,j,c) to match the channels-last RoI features
+    const size_t n = (size_t)D * 512 * 49;
+    if (!w->fc6_w) return ctx->fail(DC_E_INVALID, "null fc6_w");
+    HIPCHK(hipMalloc(&tmp, n * 4));
+    HIPCHK(hipMemcpy(tmp, w->fc6_w, n * 4, hipMemcpyHostToDevice));
+    DCCHK(dev_alloc(ctx, (void**)&ctx->fc6_w, n * 4));
+    KCHK(launch_permute_fc6(tmp, ctx->fc6_w, D, 512, 49, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(tmp));
+    DCCHK(upload(ctx, &ctx->fc6_b, w->fc6_b, D));
+  }
+  DCCHK(upload(ctx, &ctx->fc7_w, w->fc7_w, (size_t)D * D));
+  DCCHK(upload(ctx, &ctx->fc7_b, w->fc7_b, D));
+  {
+    if (!w->obj_w || !w->boxreg_w || !w->obj_b || !w->boxreg_b) return ctx->fail(DC_E_INVALID, "null head weight");
+    std::vector<float> h5((size_t)5 * D), b5(5);
+    memcpy(h5.data(), w->obj_w, (size_t)D * 4);
+    memcpy(h5.data() + D, w->boxreg_w, (size_t)4 * D * 4);
+    b5[0] = w->obj_b[0];
+    memcpy(b5.data() + 1, w->boxreg_b, 16);
+    DCCHK(upload(ctx, &ctx->head5_w, h5.data(), h5.size()));
+    DCCHK(upload(ctx, &ctx->head5_b, b5.data(), 5));
+  }
+  DCCHK(upload(ctx, &ctx->enc_w, w->lm_enc_w, (size_t)E * D));
+  DCCHK(upload(ctx, &ctx->enc_b, w->lm_enc_b, E));
+  DCCHK(upload(ctx, &ctx->lstm_b, w->lstm_b, (size_t)4 * Hd));
+  {  // torch-rnn weight (E+Hd, 4Hd): rows [0,E) = Wx, [E,E+Hd) = Wh; kernels want (N,K)
+    float* lw = nullptr;
+    DCCHK(upload(ctx, &lw, w->lstm_w, (size_t)(E + Hd) * 4 * Hd));
+    DCCHK(dev_alloc(ctx, (void**)&ctx->wxT, (size_t)4 * Hd * E * 4));
+    DCCHK(dev_alloc(ctx, (void**)&ctx->whT, (size_t)4 * Hd * Hd * 4));
+    KCHK(launch_transpose2d(lw, ctx->wxT, E, 4 * Hd, s));
+    KCHK(launch_transpose2d(lw + (size_t)E * 4 * Hd, ctx->whT, Hd, 4 * Hd, s));
+    // xg[v] = b + Emb[v].Wx for every token of the LookupTable (V+2 rows): the input half of the
+    // gate pre-activation of every decode step becomes a row gather.
+    float* emb = nullptr;
+    DCCHK(upload(ctx, &emb, w->lm_emb, (size_t)(V + 2) * E));
+    DCCHK(dev_alloc(ctx, (void**)&ctx->xg, (size_t)(V + 2) * 4 * Hd * 4));
+    DCCHK(linear(ctx, s, emb, ctx->wxT, ctx->lstm_b, ctx->xg, V + 2, 4 * Hd, E, 0));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  DCCHK(upload(ctx, &ctx->out_w, w->lm_out_w, (size_t)(V + 1) * Hd));
+  DCCHK(upload(ctx, &ctx->out_b, w->lm_out_b, (size_t)V + 1));
+  DCCHK(upload(ctx, &ctx->anchors, w->anchors, (size_t)2 * k));
+  HIPCHK(hipStreamSynchronize(s));
+  prof_collect(ctx);
+  ctx->have_weights = true;
+  return DC_OK;
+}
+
+static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, int on_dev, dc_result* outs) {
+  if (!ctx) return DC_E_INVALID;
+  if (!ctx->have_weights) return ctx->fail(DC_E_STATE, "dc_forward_*: weights not loaded");
+  if (!imgs || !outs || n <= 0 || H < 32 || W < 32) return ctx->fail(DC_E_INVALID, "dc_forward_*: bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int P = ctx->num_proposals;
+  for (int i = 0; i < n; ++i)
+    if (outs[i].capacity <= 0) return ctx->fail(DC_E_INVALID, "dc_result.capacity must be > 0");
+  const int nl = std::min(n, 3);
+  while ((int)ctx->lanes.size() < nl) ctx->lanes.emplace_back(new Lane());
+  for (int l = 0; l < nl; ++l) DCCHK(lane_prepare(ctx, *ctx->lanes[l], H, W, P));
+  const size_t img_elems = (size_t)3 * H * W;
+  for (int i = 0; i < n; ++i) {
+    Lane& L = *ctx->lanes[i % nl];
+    DCCHK(harvest(ctx, L));
+    L.pending = &outs[i];
+    DCCHK(enqueue_forward(ctx, L, imgs + img_elems * i, on_dev, false));
+  }
+  for (int l = 0; l < nl; ++l) DCCHK(harvest(ctx, *ctx->lanes[l]));
+  prof_collect(ctx);
+  return DC_OK;
+}
+
+int dc_forward_test(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_device, dc_result* out) {
+  return forward_common(ctx, img_chw, 1, H, W, img_on_device, out);
+}
+int dc_forward_batch(dc_ctx* ctx, const float* imgs, int n, int H, int W, int imgs_on_device, dc_result* outs) {
+  return forward_common(ctx, imgs, n, H, W, imgs_on_device, outs);
+}
+
+int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_device, int capacity,
+                        float* boxes, float* feats, int32_t* K) {
+  if (!ctx) return DC_E_INVALID;
+  if (!ctx->have_weights) return ctx->fail(DC_E_STATE, "dc_extract_features: weights not loaded");
+  if (!img_chw || capacity <= 0) return ctx->fail(DC_E_INVALID, "dc_extract_features: bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  Lane& L = lane0(ctx);
+  DCCHK(harvest(ctx, L));
+  DCCHK(lane_prepare(ctx, L, H, W, ctx->num_proposals));
+  L.pending = nullptr;
+  L.pending_capacity = capacity; L.pending_box_dst = boxes; L.pending_feat_dst = feats; L.pending_k_dst = K;
+  DCCHK(enqueue_forward(ctx, L, img_chw, img_on_device, true));
+  DCCHK(harvest(ctx, L));
+  prof_collect(ctx);
+  return DC_OK;
+}
+
+int dc_stage_times(dc_ctx* ctx, const char** names, float* ms, int max_stages) {
+  if (!ctx) return DC_E_INVALID;
+  if (ctx->lanes.empty() || !ctx->lanes[0]->have_times) return 0;
+  const int n = std::min(max_stages, (int)ST_COUNT);
+  for (int i = 0; i < n; ++i) {
+    if (names) names[i] = kStageNames[i];
+    if (ms) ms[i] = ctx->lanes[0]->stage_ms[i];
+  }
+  return n;
+}
+
+int dc_mfma_profile(dc_ctx* ctx, int reset, int64_t* launches, double* total_ms, double* total_flops) {
+  if (!ctx) return DC_E_INVALID;
+  if (launches) *launches = ctx->prof_launches;
+  if (total_ms) *total_ms = ctx->prof_ms;
+  if (total_flops) *total_flops = ctx->prof_flops;
+  if (reset) {
+    ctx->prof_launches = 0; ctx->prof_ms = 0; ctx->prof_flops = 0;
+    ctx->prof = reset > 0;   // reset=1: (re)start profiling; reset=-1: stop
+  }
+  return DC_OK;
+}
+
+int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t capacity_bytes) {
+  if (!ctx || !name || !host_buf) return DC_E_INVALID;
+  if (ctx->lanes.empty() || !ctx->lanes[0]->arena.p) return ctx->fail(DC_E_STATE, "no forward has run yet");
+  Lane& L = *ctx->lanes[0];
+  const int P = L.P;
+  struct Ent { const char* n; const void* p; int64_t elems; int esize; };
+  const Ent tab[] = {
+      {"feat_hwc", L.feat, (int64_t)L.fh * L.fw * 512, 4},
+      {"rpn_heads", L.heads, (int64_t)L.fh * L.fw * 6 * ctx->k, 4},
+      {"rpn_boxes", L.rpn_boxes, (int64_t)L.A * 4, 4},
+      {"rpn_x1y1x2y2", L.rpn_xyxy, (int64_t)L.A * 4, 4},
+      {"rpn_p", L.rpn_p, (int64_t)L.A, 4},
+      {"rpn_valid", L.rpn_valid, (int64_t)L.A, 1},
+      {"rpn_nms_idx", L.picks1, (int64_t)P, 4},
+      {"rpn_nms_count", L.count1, 1, 4},
+      {"roi_boxes", L.roi_boxes, (int64_t)P * 4, 4},
+      {"roi_feats", L.roi_feats, (int64_t)P * 49 * 512, 4},
+      {"codes", L.codes, (int64_t)P * ctx->D, 4},
+      {"obj", L.obj, (int64_t)P, 4},
+      {"final_trans", L.final_trans, (int64_t)P * 4, 4},
+      {"final_boxes", L.final_boxes, (int64_t)P * 4, 4},
+      {"seq", L.seq, (int64_t)P * ctx->T, 4},
+      {"final_nms_idx", L.picks2, (int64_t)P, 4},
+      {"final_nms_count", L.count2, 1, 4},
+  };
+  for (const Ent& e : tab) {
+    if (strcmp(e.n, name) == 0) {
+      const int64_t bytes = e.elems * e.esize;
+      if (bytes > capacity_bytes) return ctx->fail(DC_E_INVALID, "dc_debug_fetch: buffer too small (%lld needed)", (long long)bytes);
+      HIPCHK(hipSetDevice(ctx->device));
+      HIPCHK(hipStreamSynchronize(L.stream));
+      HIPCHK(hipMemcpy(host_buf, e.p, bytes, hipMemcpyDeviceToHost));
+      return e.elems;
+    }
+  }
+  return ctx->fail(DC_E_INVALID, "dc_debug_fetch: unknown name '%s'", name);
+}
+
+// ---- memory helpers ----------------------------------------------------------------------
+int dc_malloc(dc_ctx* ctx, void** dev_ptr, size_t bytes) {
+  if (!ctx || !dev_ptr) return DC_E_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMalloc(dev_ptr, bytes ? bytes : 16));
+  return DC_OK;
+}
+int dc_free(dc_ctx* ctx, void* dev_ptr) {
+  if (!ctx) return DC_E_INVALID;
+  HIPCHK(hipFree(dev_ptr));
+  return DC_OK;
+}
+int dc_memcpy_h2d(dc_ctx* ctx, void* d, const void* h, size_t bytes) {
+  if (!ctx) return DC_E_INVALID;
+  HIPCHK(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
+  return DC_OK;
+}
+int dc_memcpy_d2h(dc_ctx* ctx, void* h, const void* d, size_t bytes) {
+  if (!ctx) return DC_E_INVALID;
+  HIPCHK(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost));
+  return DC_OK;
+}
+int dc_synchronize(dc_ctx* ctx) {
+  if (!ctx) return DC_E_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipDeviceSynchronize());
+  return DC_OK;
+}
+
+// ---- per-op entry points --------------------------------------------------------------------
+#define OP_PROLOGUE()                         \
+  if (!ctx) return DC_E_INVALID;              \
+  HIPCHK(hipSetDevice(ctx->device));          \
+  hipStream_t s;                              \
+  DCCHK(lane0_stream(ctx, &s));
+#define OP_EPILOGUE()                 \
+  HIPCHK(hipStreamSynchronize(s));    \
+  prof_collect(ctx);                  \
+  return DC_OK;
+
+int dc_op_chw_to_hwc(dc_ctx* ctx, const float* in, float* out, int C, int H, int W) {
+  OP_PROLOGUE(); KCHK(launch_chw_to_hwc(in, out, C, H, W, s)); OP_EPILOGUE();
+}
+int dc_op_hwc_to_chw(dc_ctx* ctx, const float* in, float* out, int C, int H, int W) {
+  OP_PROLOGUE(); KCHK(launch_hwc_to_chw(in, out, C, H, W, s)); OP_EPILOGUE();
+}
+int dc_op_pack_conv3x3_weights(dc_ctx* ctx, const float* w, float* out, int Cout, int Cin) {
+  OP_PROLOGUE(); KCHK(launch_pack_conv3x3(w, out, Cout, Cin, s)); OP_EPILOGUE();
+}
+int dc_op_conv3x3(dc_ctx* ctx, const float* in, const float* w, const float* b, float* out, int n_img, int H, int W,
+                  int Cin, int Cout, int relu) {
+  OP_PROLOGUE();
+  if (Cin % 32 || n_img <= 0 || H <= 0 || W <= 0 || Cout <= 0)
+    return ctx->fail(DC_E_INVALID, "dc_op_conv3x3: need Cin %% 32 == 0 and positive sizes");
+  DCCHK(conv3x3(ctx, s, in, w, b, out, n_img, H, W, Cin, Cout, relu));
+  OP_EPILOGUE();
+}
+int dc_op_conv3x3_c3(dc_ctx* ctx, const float* in, const float* w, const float* b, float* out, int H, int W, int Cout,
+                     int relu) {
+  OP_PROLOGUE();
+  if (Cout != 64) return ctx->fail(DC_E_UNSUPPORTED, "dc_op_conv3x3_c3: Cout must be 64");
+  KCHK(launch_conv3x3_c3(in, w, b, out, H, W, Cout, relu, s));
+  OP_EPILOGUE();
+}
+int dc_op_maxpool2x2_ceil(dc_ctx* ctx, const float* in, float* out, int n_img, int H, int W, int C) {
+  OP_PROLOGUE(); KCHK(launch_maxpool2x2_ceil(in, out, n_img, H, W, C, s)); OP_EPILOGUE();
+}
+int dc_op_linear(dc_ctx* ctx, const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
+                 int relu) {
+  OP_PROLOGUE();
+  if (K % 32 || M <= 0 || N <= 0) return ctx->fail(DC_E_INVALID, "dc_op_linear: need K %% 32 == 0");
+  DCCHK(linear(ctx, s, A, W, bias, C, M, N, K, relu));
+  OP_EPILOGUE();
+}
+int dc_op_make_anchors(dc_ctx* ctx, float* out, int h, int w, float x0, float y0, float sx, float sy,
+                       const float* anchors_dev, int k) {
+  OP_PROLOGUE(); KCHK(launch_make_anchors(out, h, w, x0, y0, sx, sy, anchors_dev, k, s)); OP_EPILOGUE();
+}
+int dc_op_apply_box_transform(dc_ctx* ctx, const float* boxes, const float* trans, float* out, int n) {
+  OP_PROLOGUE(); KCHK(launch_apply_box_transform(boxes, trans, out, n, s)); OP_EPILOGUE();
+}
+int dc_op_clip_boxes(dc_ctx* ctx, const float* boxes, float* clipped, uint8_t* valid, int n, float x_min, float y_min,
+                     float x_max, float y_max) {
+  OP_PROLOGUE(); KCHK(launch_clip_boxes(boxes, clipped, valid, n, x_min, y_min, x_max, y_max, s)); OP_EPILOGUE();
+}
+int dc_op_xcycwh_to_x1y1x2y2(dc_ctx* ctx, const float* boxes, float* out, int n) {
+  OP_PROLOGUE(); KCHK(launch_xcycwh_to_x1y1x2y2(boxes, out, n, s)); OP_EPILOGUE();
+}
+int dc_op_box_iou(dc_ctx* ctx, const float* b1, const float* b2, float* out, int B1, int B2, int convention) {
+  OP_PROLOGUE(); KCHK(launch_box_iou(b1, b2, out, B1, B2, convention, s)); OP_EPILOGUE();
+}
+int dc_op_rpn_decode(dc_ctx* ctx, const float* heads, int h, int w, int k, const float* anchors_dev, float x0,
+                     float y0, float sx, float sy, int img_h, int img_w, float* boxes, float* anchors_out,
+                     float* trans, float* x1y1x2y2, float* p, uint8_t* valid) {
+  OP_PROLOGUE();
+  KCHK(launch_rpn_decode(heads, h, w, k, anchors_dev, x0, y0, sx, sy, img_h, img_w, boxes, anchors_out, trans,
+                         x1y1x2y2, p, valid, s));
+  OP_EPILOGUE();
+}
+int dc_op_nms(dc_ctx* ctx, const float* boxes, const float* scores, const uint8_t* valid, int n, float thresh,
+              int max_boxes, int32_t* picks, int32_t* count) {
+  OP_PROLOGUE();
+  if (n < 0 || n > 65536) return ctx->fail(DC_E_INVALID, "dc_op_nms: n must be in [0,65536]");
+  if (n == 0) { HIPCHK(hipMemsetAsync(count, 0, 4, s)); OP_EPILOGUE(); }
+  void* base = nullptr;
+  HIPCHK(hipMalloc(&base, nms_workspace_bytes(n)));
+  NmsWorkspace ws;
+  nms_workspace_bind(ws, base, n);
+  hipError_t e = launch_nms(ws, boxes, scores, valid, n, nullptr, thresh, max_boxes, picks, count, s);
+  hipError_t e2 = hipStreamSynchronize(s);
+  hipFree(base);
+  if (e != hipSuccess) return ctx->fail(DC_E_HIP, "nms launch: %s", hipGetErrorString(e));
+  if (e2 != hipSuccess) return ctx->fail(DC_E_HIP, "nms sync: %s", hipGetErrorString(e2));
+  return DC_OK;
+}
+int dc_op_bilinear_roi_pool(dc_ctx* ctx, const float* feat_hwc, int h, int w, int C, const float* boxes, int B,
+                            int img_h, int img_w, int HH, int WW, float* out, int out_layout) {
+  OP_PROLOGUE();
+  if (C % 4 || B <= 0 || HH < 2 || WW < 2) return ctx->fail(DC_E_INVALID, "dc_op_bilinear_roi_pool: bad shape");
+  KCHK(launch_bilinear_roi_pool(feat_hwc, h, w, C, boxes, B, nullptr, img_h, img_w, HH, WW, out, out_layout, s));
+  OP_EPILOGUE();
+}
+int dc_op_lm_sample(dc_ctx* ctx, const float* codes, int n, int32_t* tokens) {
+  OP_PROLOGUE();
+  if (!ctx->have_weights) return ctx->fail(DC_E_STATE, "dc_op_lm_sample: weights not loaded");
+  if (n <= 0) return ctx->fail(DC_E_INVALID, "dc_op_lm_sample: n must be > 0");
+  Lane& L = lane0(ctx);
+  // private scratch for n rows
+  const int E = ctx->E, Hd = ctx->Hd, V1 = ctx->V + 1;
+  struct Sav { float *enc, *gates, *h, *c, *logits; int32_t* tok; } sv{L.enc, L.gates, L.hstate, L.cstate, L.logits, L.tok};
+  const size_t bytes = al((size_t)n * E * 4) + al((size_t)n * 4 * Hd * 4) + 2 * al((size_t)n * Hd * 4) +
+                       al((size_t)n * V1 * 4) + al((size_t)n * 4);
+  char* base = nullptr;
+  HIPCHK(hipMalloc((void**)&base, bytes));
+  char* p = base;
+  L.enc = (float*)p; p += al((size_t)n * E * 4);
+  L.gates = (float*)p; p += al((size_t)n * 4 * Hd * 4);
+  L.hstate = (float*)p; p += al((size_t)n * Hd * 4);
+  L.cstate = (float*)p; p += al((size_t)n * Hd * 4);
+  L.logits = (float*)p; p += al((size_t)n * V1 * 4);
+  L.tok = (int32_t*)p;
+  int rc = lm_sample(ctx, L, codes, n, tokens);
+  hipError_t e2 = hipStreamSynchronize(s);
+  L.enc = sv.enc; L.gates = sv.gates; L.hstate = sv.h; L.cstate = sv.c; L.logits = sv.logits; L.tok = sv.tok;
+  hipFree(base);
+  prof_collect(ctx);
+  if (rc != DC_OK) return rc;
+  if (e2 != hipSuccess) return ctx->fail(DC_E_HIP, "lm_sample sync: %s", hipGetErrorString(e2));
+  return DC_OK;
+}
+
+}  // extern "C"

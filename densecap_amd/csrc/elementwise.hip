@@ -1,0 +1,284 @@
+// Layout, pooling, conv1_1, LSTM point-wise, arg-max and recognition-head kernels (gfx950).
+// All of these are HBM- or latency-bound byte movers: coalesced 16-byte accesses along the
+// channels-last axis, wavefront (64-lane) reductions, no MFMA.
+#include "common.h"
+
+// every fp32 op rounds once, in source order (integer decisions depend on it)
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- (C,H,W) <-> (H,W,C) ---------------------------------------------------------------
+// Tiled 32x32 transpose through LDS of the (C, H*W) matrix.
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    if (r < rows && c < cols) tile[j][tx] = in[(size_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;  // out is (cols, rows)
+    if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][j];
+  }
+}
+
+// OIHW (Cout,Cin,3,3) -> (Cout, 9*Cin), k = (kh*3+kw)*Cin + c
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin) {
+  const size_t total = (size_t)Cout * Cin * 9;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cin);
+    const size_t t = i / Cin;
+    const int tap = (int)(t % 9);
+    const int o = (int)(t / 9);
+    out[i] = w[((size_t)o * Cin + c) * 9 + tap];
+  }
+}
+
+// fc6: (N, C*HW) k = c*HW + p  ->  k' = p*C + c  (matches the (B,HH,WW,C) RoI-pool output)
+__global__ void permute_fc6_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C, int HW) {
+  const size_t total = (size_t)N * C * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t t = i / C;
+    const int p = (int)(t % HW);
+    const size_t n = t / HW;
+    out[i] = in[(n * C + c) * HW + p];
+  }
+}
+
+// ---- conv1_1: Cin=3 direct convolution (VALU), CHW in -> HWC out --------------------------
+// One thread = one pixel x 16 output channels; the 27 taps stay in registers, weights are
+// broadcast from LDS.  4 consecutive lanes write one pixel's 256 contiguous bytes.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         int H, int W, int relu) {
+  __shared__ float ws[27 * COUT];  // [k][o], k = c*9 + kh*3 + kw  (k-order c, kh, kw as im2col does)
+  __shared__ float bs[COUT];
+  for (int i = threadIdx.x; i < 27 * COUT; i += 256) {
+    const int o = i % COUT, k = i / COUT;
+    ws[i] = w[o * 27 + k];
+  }
+  for (int i = threadIdx.x; i < COUT; i += 256) bs[i] = bias[i];
+  __syncthreads();
+  constexpr int G = COUT / 16;  // channel groups per pixel
+  const size_t npix = (size_t)H * W;
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t pix = gid / G;
+  const int grp = (int)(gid % G);
+  if (pix >= npix) return;
+  const int y = (int)(pix / W), x = (int)(pix % W);
+  float v[27];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int yy = y + kh - 1, xx = x + kw - 1;
+        const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        v[c * 9 + kh * 3 + kw] = ok ? in[((size_t)c * H + yy) * W + xx] : 0.f;
+      }
+  float acc[16];
+#pragma unroll
+  for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = fmaf(v[k], ws[k * COUT + grp * 16 + o], acc[o]);
+  }
+  float* op = out + pix * COUT + grp * 16;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = acc[q * 4 + e] + bs[grp * 16 + q * 4 + e];
+      r[e] = (relu && t < 0.f) ? 0.f : t;
+    }
+    *reinterpret_cast<f32x4*>(op + q * 4) = r;
+  }
+}
+
+// ---- 2x2/2 max-pool, ceil mode, HWC -----------------------------------------------------
+__global__ void maxpool2x2_ceil_kernel(const float* __restrict__ in, float* __restrict__ out, int nimg, int H,
+                                       int W, int C) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C4 = C / 4;
+  const size_t total = (size_t)nimg * Ho * Wo * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    size_t t = i / C4;
+    const int xo = (int)(t % Wo); t /= Wo;
+    const int yo = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const int y0 = 2 * yo, x0 = 2 * xo;
+    const float* base = in + ((size_t)n * H * W) * C + (size_t)c4 * 4;
+    f32x4 m = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x0) * C);
+    const bool hx = x0 + 1 < W, hy = y0 + 1 < H;
+    auto mx = [&](const f32x4& a) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = a[e] > m[e] ? a[e] : m[e];
+    };
+    if (hx) mx(*reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x0 + 1) * C));
+    if (hy) mx(*reinterpret_cast<const f32x4*>(base + ((size_t)(y0 + 1) * W + x0) * C));
+    if (hx && hy) mx(*reinterpret_cast<const f32x4*>(base + ((size_t)(y0 + 1) * W + x0 + 1) * C));
+    *reinterpret_cast<f32x4*>(out + i * 4) = m;
+  }
+}
+
+// ---- LSTM point-wise (torch-rnn nn.LSTM step; gate order i,f,o,g) ----------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__global__ void lstm_pointwise_kernel(const float* __restrict__ gates, float* __restrict__ c, float* __restrict__ h,
+                                      int n, int Hd, int zero_c) {
+  const size_t total = (size_t)n * Hd;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = i / Hd;
+    const int j = (int)(i % Hd);
+    const float* g = gates + m * 4 * Hd;
+    const float ig = sigmoidf_(g[j]), fg = sigmoidf_(g[Hd + j]), og = sigmoidf_(g[2 * Hd + j]);
+    const float gg = tanhf(g[3 * Hd + j]);
+    const float cp = zero_c ? 0.f : c[i];
+    const float cn = fg * cp + ig * gg;
+    c[i] = cn;
+    h[i] = og * tanhf(cn);
+  }
+}
+
+// ---- row arg-max: one wave per row, first max on ties (torch.max semantics) --------------------
+__global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict__ logits, int n, int N, int ld,
+                                                         int32_t* __restrict__ tok, int32_t* __restrict__ seq,
+                                                         int T, int t) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float* p = logits + (size_t)row * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = lane; j < N; j += 64) {
+    const float v = p[j];
+    if (v > best || (bi == 0x7fffffff)) { best = v; bi = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) {
+    tok[row] = bi + 1;
+    seq[(size_t)row * T + t] = bi + 1;
+  }
+}
+
+__global__ void fill_i32_kernel(int32_t* p, int32_t v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// ---- recognition heads: objectness (4096->1), box regression (4096->4), final box transform ------
+// One wave per RoI row: 5 dot products of length D, wave reduction.
+__global__ __launch_bounds__(256) void recog_heads_kernel(const float* __restrict__ codes, const float* __restrict__ w5,
+                                                          const float* __restrict__ b5, const float* __restrict__ roi,
+                                                          float* __restrict__ obj, float* __restrict__ trans,
+                                                          float* __restrict__ fin, int n, int D) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float* x = codes + (size_t)row * D;
+  float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k = lane * 4; k < D; k += 256) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k);
+#pragma unroll
+    for (int o = 0; o < 5; ++o) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w5 + (size_t)o * D + k);
+      s[o] += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 5; ++o) s[o] = wave_sum(s[o]) + b5[o];
+  if (lane == 0) {
+    obj[row] = s[0];
+    const float xa = roi[row * 4 + 0], ya = roi[row * 4 + 1], wa = roi[row * 4 + 2], ha = roi[row * 4 + 3];
+    trans[row * 4 + 0] = s[1]; trans[row * 4 + 1] = s[2]; trans[row * 4 + 2] = s[3]; trans[row * 4 + 3] = s[4];
+    // nn.ApplyBoxTransform (ApplyBoxTransform.lua:85-88); no FMA contraction to keep op order
+    fin[row * 4 + 0] = __fadd_rn(__fmul_rn(s[1], wa), xa);
+    fin[row * 4 + 1] = __fadd_rn(__fmul_rn(s[2], ha), ya);
+    fin[row * 4 + 2] = __fmul_rn(expf(s[3]), wa);
+    fin[row * 4 + 3] = __fmul_rn(expf(s[4]), ha);
+  }
+}
+
+inline int grid_for(size_t total, int block = 256, int cap = 256 * 8) {
+  size_t g = (total + block - 1) / block;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+hipError_t launch_transpose2d(const float* in, float* out, int rows, int cols, hipStream_t s) {
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols);
+  return hipGetLastError();
+}
+hipError_t launch_chw_to_hwc(const float* in, float* out, int C, int H, int W, hipStream_t s) {
+  return launch_transpose2d(in, out, C, H * W, s);
+}
+hipError_t launch_hwc_to_chw(const float* in, float* out, int C, int H, int W, hipStream_t s) {
+  return launch_transpose2d(in, out, H * W, C, s);
+}
+hipError_t launch_pack_conv3x3(const float* w, float* out, int Cout, int Cin, hipStream_t s) {
+  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for((size_t)Cout * Cin * 9)), dim3(256), 0, s, w, out, Cout, Cin);
+  return hipGetLastError();
+}
+hipError_t launch_permute_fc6(const float* in, float* out, int N, int C, int HW, hipStream_t s) {
+  hipLaunchKernelGGL(permute_fc6_kernel, dim3(grid_for((size_t)N * C * HW, 256, 256 * 16)), dim3(256), 0, s, in, out,
+                     N, C, HW);
+  return hipGetLastError();
+}
+hipError_t launch_conv3x3_c3(const float* in, const float* w, const float* bias, float* out, int H, int W, int Cout,
+                             int relu, hipStream_t s) {
+  if (Cout != 64) return hipErrorInvalidValue;
+  const size_t threads = (size_t)H * W * (Cout / 16);
+  hipLaunchKernelGGL((conv3x3_c3_kernel<64>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, in, w, bias,
+                     out, H, W, relu);
+  return hipGetLastError();
+}
+hipError_t launch_maxpool2x2_ceil(const float* in, float* out, int nimg, int H, int W, int C, hipStream_t s) {
+  if (C % 4) return hipErrorInvalidValue;
+  const size_t total = (size_t)nimg * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2x2_ceil_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s, in, out, nimg, H,
+                     W, C);
+  return hipGetLastError();
+}
+hipError_t launch_lstm_pointwise(const float* gates, float* c, float* h, int n, int Hd, int zero_c, hipStream_t s) {
+  hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(grid_for((size_t)n * Hd)), dim3(256), 0, s, gates, c, h, n, Hd,
+                     zero_c);
+  return hipGetLastError();
+}
+hipError_t launch_row_argmax(const float* logits, int n, int N, int ld, int32_t* tok, int32_t* seq, int T, int t,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(row_argmax_kernel, dim3((n + 3) / 4), dim3(256), 0, s, logits, n, N, ld, tok, seq, T, t);
+  return hipGetLastError();
+}
+hipError_t launch_fill_i32(int32_t* p, int32_t v, int n, hipStream_t s) {
+  hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n);
+  return hipGetLastError();
+}
+hipError_t launch_recog_heads(const float* codes, const float* w5, const float* b5, const float* roi_boxes,
+                              float* obj, float* trans, float* final_boxes, int n, int D, hipStream_t s) {
+  if (D % 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(recog_heads_kernel, dim3((n + 3) / 4), dim3(256), 0, s, codes, w5, b5, roi_boxes, obj, trans,
+                     final_boxes, n, D);
+  return hipGetLastError();
+}

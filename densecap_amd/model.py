@@ -1,0 +1,188 @@
+"""Host-side mirror of the reference's `DenseCapModel` for the test-time path.
+
+Same method names, argument meaning and error behaviour as
+densecap/DenseCapModel.lua (setTestArgs :185-191, convert :198-208, evaluate,
+forward_test :319-327, extractFeatures :285-304) and LanguageModel:decodeSequence
+(LanguageModel.lua:86-103), so the callers `run_model.lua:145-164`,
+`webcam/daemon.lua:46-85` and `eval/eval_utils.lua:62` change only their constructor
+line.  All numerics run in libdensecap_hip.so (HIP, gfx950); this file only marshals
+pointers.  The LuaJIT twin of this class is lua/DenseCapModelHIP.lua.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import DcResult, DcWeights, check
+from .ops import Context
+
+
+def _np32(t):
+    if hasattr(t, "detach"):
+        t = t.detach().cpu().numpy()
+    return np.ascontiguousarray(t, dtype=np.float32)
+
+
+class DenseCapModel:
+    def __init__(self, weights, device=0, ctx=None):
+        """weights: dict in checkpoint layouts (see densecap_amd/weights.py); device: HIP index
+        (utils.setup_gpus(gpu) with gpu >= 0; there is no `-gpu -1` CPU mode here)."""
+        self.ctx = ctx or Context(device)
+        self.lib = self.ctx.lib
+        self.opt = dict(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=300)
+        self.vocab_size = int(weights["vocab_size"])
+        self.seq_length = int(weights["seq_length"])
+        self.idx_to_token = weights.get("idx_to_token")
+        self._keep = []  # host arrays referenced by the struct during dc_load_weights
+        w = DcWeights()
+
+        def ptr(a):
+            a = _np32(a)
+            self._keep.append(a)
+            return a.ctypes.data_as(_lib.c_float_p)
+
+        for i in range(_lib.DC_NUM_VGG_CONVS):
+            w.conv_w[i] = ptr(weights["conv_w"][i])
+            w.conv_b[i] = ptr(weights["conv_b"][i])
+        for name in ("rpn_conv_w", "rpn_conv_b", "rpn_box_w", "rpn_box_b", "rpn_score_w", "rpn_score_b", "fc6_w",
+                     "fc6_b", "fc7_w", "fc7_b", "obj_w", "obj_b", "boxreg_w", "boxreg_b", "lm_enc_w", "lm_enc_b",
+                     "lm_emb", "lstm_w", "lstm_b", "lm_out_w", "lm_out_b", "anchors"):
+            setattr(w, name, ptr(weights[name]))
+        for i, v in enumerate(weights["field_centers"]):
+            w.field_centers[i] = float(v)
+        w.num_anchors = int(_np32(weights["anchors"]).shape[1])
+        w.rpn_hidden = int(_np32(weights["rpn_conv_w"]).shape[0])
+        w.vocab_size = self.vocab_size
+        w.seq_length = self.seq_length
+        w.enc_size = int(_np32(weights["lm_enc_w"]).shape[0])
+        w.rnn_size = int(_np32(weights["lstm_w"]).shape[1] // 4)
+        w.fc_dim = int(_np32(weights["fc7_w"]).shape[0])
+        self.fc_dim = w.fc_dim
+        check(self.ctx.h, self.lib.dc_load_weights(self.ctx.h, C.byref(w)), "dc_load_weights")
+        self._keep = []
+        self.setTestArgs()
+
+    # ---- reference API ---------------------------------------------------------------------
+    def setTestArgs(self, args=None, **kw):
+        """DenseCapModel:setTestArgs{rpn_nms_thresh=,final_nms_thresh=,num_proposals=}."""
+        args = dict(args or {}, **kw)
+        for k in args:
+            if k not in ("rpn_nms_thresh", "final_nms_thresh", "num_proposals"):
+                raise KeyError("unknown test arg %r" % k)
+        self.opt.update(args)
+        check(self.ctx.h, self.lib.dc_set_test_args(self.ctx.h, float(self.opt["rpn_nms_thresh"]),
+                                                    float(self.opt["final_nms_thresh"]),
+                                                    int(self.opt["num_proposals"])), "dc_set_test_args")
+        return self
+
+    def convert(self, dtype=None, use_cudnn=None):
+        """model:convert(dtype, use_cudnn): the HIP path is always fp32 on the ctx's device."""
+        return self
+
+    def evaluate(self):
+        return self
+
+    def _check_input(self, img):
+        img = np.asarray(img)
+        if img.ndim == 4:
+            assert img.shape[0] == 1 and img.shape[1] == 3, "input must be (1,3,H,W)"  # DenseCapModel.lua:244
+            img = img[0]
+        assert img.ndim == 3 and img.shape[0] == 3, "input must be (1,3,H,W)"
+        return np.ascontiguousarray(img, dtype=np.float32)
+
+    def _new_result(self, P):
+        T = self.seq_length
+        boxes = np.zeros((P, 4), np.float32); scores = np.zeros((P,), np.float32)
+        tokens = np.zeros((P, T), np.int32)
+        r = DcResult()
+        r.capacity = P
+        r.boxes = boxes.ctypes.data_as(_lib.c_float_p)
+        r.scores = scores.ctypes.data_as(_lib.c_float_p)
+        r.tokens = tokens.ctypes.data_as(_lib.c_int32_p)
+        return r, boxes, scores, tokens
+
+    def forward_raw(self, img):
+        """forward_test without string decoding: (boxes (K,4) xcycwh, scores (K,), tokens (K,T))."""
+        img = self._check_input(img)
+        P = int(self.opt["num_proposals"])
+        r, boxes, scores, tokens = self._new_result(P)
+        check(self.ctx.h, self.lib.dc_forward_test(self.ctx.h, img.ctypes.data, img.shape[1], img.shape[2], 0,
+                                                   C.byref(r)), "dc_forward_test")
+        K = r.K
+        return boxes[:K].copy(), scores[:K].copy(), tokens[:K].copy()
+
+    def forward_test(self, img):
+        """Returns final_boxes (K,4), objectness_scores (K,1), captions (list of K strings)."""
+        boxes, scores, tokens = self.forward_raw(img)
+        return boxes, scores[:, None], self.decodeSequence(tokens)
+
+    def forward_batch_device(self, imgs_dev_ptr, n, H, W):
+        """run_model.lua's image loop over n device-resident images of one size; returns a list of
+        (boxes, scores, tokens).  imgs_dev_ptr: device pointer to (n,3,H,W) fp32."""
+        P = int(self.opt["num_proposals"])
+        arr = (DcResult * n)()
+        keep = []
+        for i in range(n):
+            r, b, s, t = self._new_result(P)
+            arr[i] = r
+            keep.append((b, s, t))
+        check(self.ctx.h, self.lib.dc_forward_batch(self.ctx.h, imgs_dev_ptr, n, H, W, 1, arr), "dc_forward_batch")
+        return [(b[:arr[i].K], s[:arr[i].K], t[:arr[i].K]) for i, (b, s, t) in enumerate(keep)]
+
+    def forward_batch(self, imgs):
+        imgs = np.ascontiguousarray(imgs, dtype=np.float32)
+        n, c, H, W = imgs.shape
+        assert c == 3
+        P = int(self.opt["num_proposals"])
+        arr = (DcResult * n)()
+        keep = []
+        for i in range(n):
+            r, b, s, t = self._new_result(P)
+            arr[i] = r
+            keep.append((b, s, t))
+        check(self.ctx.h, self.lib.dc_forward_batch(self.ctx.h, imgs.ctypes.data, n, H, W, 0, arr), "dc_forward_batch")
+        return [(b[:arr[i].K].copy(), s[:arr[i].K].copy(), t[:arr[i].K].copy()) for i, (b, s, t) in enumerate(keep)]
+
+    def extractFeatures(self, img):
+        """DenseCapModel:extractFeatures -> (boxes_xcycwh (K,4), feats (K,fc_dim))."""
+        img = self._check_input(img)
+        P = int(self.opt["num_proposals"])
+        boxes = np.zeros((P, 4), np.float32); feats = np.zeros((P, self.fc_dim), np.float32)
+        K = C.c_int32(0)
+        check(self.ctx.h, self.lib.dc_extract_features(self.ctx.h, img.ctypes.data, img.shape[1], img.shape[2], 0, P,
+                                                       boxes.ctypes.data, feats.ctypes.data, C.byref(K)),
+              "dc_extract_features")
+        return boxes[:K.value].copy(), feats[:K.value].copy()
+
+    def decodeSequence(self, seq):
+        """LanguageModel:decodeSequence (LanguageModel.lua:86-103)."""
+        end = self.vocab_size + 1
+        caps = []
+        for row in np.asarray(seq):
+            words = []
+            for tok in row:
+                tok = int(tok)
+                if tok == end or tok == 0:
+                    break
+                words.append(self.idx_to_token[tok] if self.idx_to_token else str(tok))
+            caps.append(" ".join(words))
+        return caps
+
+    # ---- instrumentation ---------------------------------------------------------------------
+    def stage_times(self):
+        names = (C.c_char_p * 16)(); ms = (C.c_float * 16)()
+        n = self.lib.dc_stage_times(self.ctx.h, names, ms, 16)
+        return {names[i].decode(): float(ms[i]) for i in range(max(n, 0))}
+
+    def mfma_profile(self, reset=0):
+        l = C.c_int64(0); ms = C.c_double(0); fl = C.c_double(0)
+        check(self.ctx.h, self.lib.dc_mfma_profile(self.ctx.h, reset, C.byref(l), C.byref(ms), C.byref(fl)))
+        return dict(launches=l.value, ms=ms.value, flops=fl.value)
+
+    def debug_fetch(self, name, shape, dtype=np.float32):
+        out = np.empty(shape, dtype)
+        n = self.lib.dc_debug_fetch(self.ctx.h, name.encode(), out.ctypes.data, out.nbytes)
+        check(self.ctx.h, int(min(n, 0)), "dc_debug_fetch(%s)" % name)
+        return out, int(n)

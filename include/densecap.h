@@ -1,0 +1,206 @@
+/* densecap.h -- C ABI of libdensecap_hip.so
+ *
+ * MI355X (gfx950) native replacement for the test-time hot path of
+ * jcjohnson/densecap:  image -> (boxes, scores, caption tokens), i.e. what
+ * `DenseCapModel:forward_test()` (densecap/DenseCapModel.lua:319-327) computes
+ * when driven by `run_model.lua:64-87`.
+ *
+ * The reference has no FFI/plugin registry: its "operator API" is the duck-typed
+ * Lua nn.Module protocol.  Each entry point below names the reference interface
+ * it replaces (file:line, relative to the reference repo).  The library has no
+ * Lua, Python or torch dependency: plain pointers and sizes only.  Host-side
+ * mirrors of the reference classes live in lua/ (LuaJIT FFI) and densecap_amd/
+ * (Python ctypes); see INTEGRATION.md.
+ *
+ * Conventions
+ *  - all tensors fp32, row-major; token ids int32, 1-based (END = START = V+1)
+ *    exactly as the reference's LongTensor `seq` (LanguageModel.lua:30-33);
+ *  - box coordinates are 1-based image pixels like the reference; INDEX outputs
+ *    (NMS picks) are 0-based;
+ *  - every function returns DC_OK (0) or a negative DC_E_* code and never aborts;
+ *    dc_last_error() returns the message (replaces Lua assert/error());
+ *  - a dc_ctx is bound to one HIP device, owns its stream(s), weights and
+ *    workspaces, and is NOT thread-safe (the reference is single-threaded Lua);
+ *  - "dev" pointers are HIP device pointers on the ctx's device.  Per-op entry
+ *    points (dc_op_*) run on the ctx's primary stream and are synchronous on
+ *    return unless stated.
+ */
+#ifndef DENSECAP_H
+#define DENSECAP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DC_OK 0
+#define DC_E_INVALID (-1)     /* bad argument / shape            */
+#define DC_E_HIP (-2)         /* HIP runtime error               */
+#define DC_E_STATE (-3)       /* call order (e.g. no weights)    */
+#define DC_E_NOMEM (-4)
+#define DC_E_UNSUPPORTED (-5)
+
+#define DC_NUM_VGG_CONVS 13
+
+typedef struct dc_ctx dc_ctx;
+
+/* Weights in the checkpoint's (Torch7) layouts, HOST pointers, fp32.
+ * Shapes follow DenseCapModel.lua:61-67,93-100, LocalizationLayer.lua:627-673,
+ * LanguageModel.lua:27-61.  The library repacks them into kernel layouts. */
+typedef struct dc_weights {
+  const float* conv_w[DC_NUM_VGG_CONVS]; /* OIHW (Cout,Cin,3,3): VGG-16 conv1_1..conv5_3 */
+  const float* conv_b[DC_NUM_VGG_CONVS]; /* (Cout)                                         */
+  const float* rpn_conv_w;  /* (R,512,3,3)  R = rpn_hidden (256)                           */
+  const float* rpn_conv_b;  /* (R)                                                         */
+  const float* rpn_box_w;   /* (4k,R,1,1)  channel = a*4+d                                 */
+  const float* rpn_box_b;   /* (4k)                                                        */
+  const float* rpn_score_w; /* (2k,R,1,1)  channel = a*2+{pos,neg}                         */
+  const float* rpn_score_b; /* (2k)                                                        */
+  const float* fc6_w;       /* (4096, 512*7*7) input index c*49+i*7+j                      */
+  const float* fc6_b;
+  const float* fc7_w;       /* (4096,4096) */
+  const float* fc7_b;
+  const float* obj_w;       /* (1,4096)  objectness_branch */
+  const float* obj_b;       /* (1) */
+  const float* boxreg_w;    /* (4,4096)  box_reg_branch */
+  const float* boxreg_b;    /* (4) */
+  const float* lm_enc_w;    /* (E,4096)  image_encoder Linear, E = 512 */
+  const float* lm_enc_b;    /* (E) */
+  const float* lm_emb;      /* (V+2,E)   LookupTable */
+  const float* lstm_w;      /* (E+Hd,4*Hd) torch-rnn nn.LSTM weight, gate order i,f,o,g */
+  const float* lstm_b;      /* (4*Hd) */
+  const float* lm_out_w;    /* (V+1,Hd) */
+  const float* lm_out_b;    /* (V+1) */
+  const float* anchors;     /* (2,k): row 0 widths, row 1 heights (LocalizationLayer.lua:613-619) */
+  float field_centers[4];   /* x0,y0,sx,sy (net_utils.lua:106-140) = 8.5,8.5,16,16 for VGG-16 */
+  int32_t num_anchors;      /* k  */
+  int32_t rpn_hidden;       /* R  */
+  int32_t vocab_size;       /* V  */
+  int32_t seq_length;       /* T  */
+  int32_t enc_size;         /* E  */
+  int32_t rnn_size;         /* Hd */
+  int32_t fc_dim;           /* 4096 */
+} dc_weights;
+
+/* Result of one image.  Caller owns the buffers (HOST memory) and sets
+ * `capacity` >= num_proposals; the library writes K <= capacity rows.
+ * Replaces the three return values of DenseCapModel:forward_test
+ * (DenseCapModel.lua:319-327): final_boxes (K,4) xcycwh, objectness_scores (K,1)
+ * raw logits in decreasing order, and the token matrix `seq` (K,T) that
+ * LanguageModel:decodeSequence (LanguageModel.lua:86-103) turns into strings. */
+typedef struct dc_result {
+  int32_t capacity;  /* in  */
+  int32_t K;         /* out */
+  int32_t T;         /* out */
+  float* boxes;      /* out (capacity,4) xc,yc,w,h */
+  float* scores;     /* out (capacity)   */
+  int32_t* tokens;   /* out (capacity,T) */
+} dc_result;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+/* utils.setup_gpus(gpu, use_cudnn) (densecap/utils.lua:22-36): bind to a device. */
+int dc_create(dc_ctx** out, int hip_device);
+void dc_destroy(dc_ctx* ctx);
+/* Lua error()/assert message equivalent. ctx may be NULL (last global error). */
+const char* dc_last_error(const dc_ctx* ctx);
+/* torch.load(checkpoint).model + model:convert(dtype) (run_model.lua:146-148,
+ * DenseCapModel.lua:198-208): upload + repack weights for the kernels. */
+int dc_load_weights(dc_ctx* ctx, const dc_weights* w);
+/* DenseCapModel:setTestArgs{rpn_nms_thresh,final_nms_thresh,num_proposals}
+ * (DenseCapModel.lua:185-191). num_proposals = -1 is not supported (cap needed). */
+int dc_set_test_args(dc_ctx* ctx, float rpn_nms_thresh, float final_nms_thresh, int num_proposals);
+
+/* ---- the hot path ------------------------------------------------------- */
+/* DenseCapModel:forward_test(input) (DenseCapModel.lua:319-327) for one image
+ * (3,H,W) BGR, mean-subtracted (run_model.lua:67-74).  img_on_device != 0 means
+ * `img_chw` is a device pointer (inputs resident in HBM).  Synchronous. */
+int dc_forward_test(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_device, dc_result* out);
+/* run_model.lua:160-180 host loop over images, n images of identical size laid out
+ * back to back; images are software-pipelined over the ctx's lanes (streams). */
+int dc_forward_batch(dc_ctx* ctx, const float* imgs, int n, int H, int W, int imgs_on_device,
+                     dc_result* outs);
+/* DenseCapModel:extractFeatures (DenseCapModel.lua:285-304): boxes (K,4) and fc7
+ * codes (K,fc_dim) after the final NMS; the LSTM decode is skipped. Host outputs. */
+int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_device,
+                        int capacity, float* boxes, float* feats, int32_t* K);
+
+/* Per-stage GPU time of the most recent dc_forward_test on this ctx, measured with
+ * HIP events on the ctx's stream (replaces LocalizationLayer:timeit,
+ * LocalizationLayer.lua:219-230).  names[i] are static strings.  Returns the
+ * number of stages written (<= max_stages). */
+int dc_stage_times(dc_ctx* ctx, const char** names, float* ms, int max_stages);
+/* Accumulated [launch count, total ms, total algorithmic FLOPs] of the MFMA
+ * contraction kernel family since the last reset (HIP events around every launch).
+ * Used by bench.py for the live roofline figure. */
+int dc_mfma_profile(dc_ctx* ctx, int reset, int64_t* launches, double* total_ms, double* total_flops);
+/* Copy an intermediate of the most recent forward to the host for stage-wise parity:
+ * name in {"feat_hwc","rpn_heads","rpn_boxes","rpn_x1y1x2y2","rpn_p","rpn_valid",
+ * "rpn_nms_idx","roi_boxes","roi_feats","codes","obj","final_trans","final_boxes",
+ * "seq","final_nms_idx"}.  Returns the number of elements copied (or <0). */
+int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t capacity_bytes);
+
+/* ---- device memory helpers (for hosts without a GPU allocator, e.g. LuaJIT) -- */
+int dc_malloc(dc_ctx* ctx, void** dev_ptr, size_t bytes);
+int dc_free(dc_ctx* ctx, void* dev_ptr);
+int dc_memcpy_h2d(dc_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
+int dc_memcpy_d2h(dc_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+int dc_synchronize(dc_ctx* ctx);
+
+/* ---- per-op entry points (device pointers) ------------------------------ */
+/* layout changes: the kernels keep activations channels-last (HWC). */
+int dc_op_chw_to_hwc(dc_ctx* ctx, const float* in_chw, float* out_hwc, int C, int H, int W);
+int dc_op_hwc_to_chw(dc_ctx* ctx, const float* in_hwc, float* out_chw, int C, int H, int W);
+/* Repack OIHW (Cout,Cin,3,3) -> (Cout, 9*Cin) with k = (kh*3+kw)*Cin + c. */
+int dc_op_pack_conv3x3_weights(dc_ctx* ctx, const float* w_oihw, float* w_packed, int Cout, int Cin);
+/* nn.SpatialConvolution(Cin,Cout,3,3,1,1,1,1) [+ nn.ReLU] (VGG layers,
+ * DenseCapModel.lua:73-76; RPN conv LocalizationLayer.lua:627-636), fp32 MFMA
+ * implicit GEMM.  in: (n_img,H,W,Cin) HWC, Cin % 32 == 0; w_packed from
+ * dc_op_pack_conv3x3_weights; out (n_img,H,W,Cout). */
+int dc_op_conv3x3(dc_ctx* ctx, const float* in_hwc, const float* w_packed, const float* bias,
+                  float* out_hwc, int n_img, int H, int W, int Cin, int Cout, int relu);
+/* conv1_1: Cin = 3, reads the (3,H,W) CHW boundary image, writes (H,W,Cout) HWC. */
+int dc_op_conv3x3_c3(dc_ctx* ctx, const float* in_chw, const float* w_oihw, const float* bias,
+                     float* out_hwc, int H, int W, int Cout, int relu);
+/* nn.SpatialMaxPooling(2,2,2,2):ceil() as loadcaffe builds it: (H,W,C)->(ceil(H/2),ceil(W/2),C). */
+int dc_op_maxpool2x2_ceil(dc_ctx* ctx, const float* in_hwc, float* out_hwc, int n_img, int H, int W, int C);
+/* nn.Linear [+ReLU]: C(M,N) = A(M,K) . W(N,K)^T + bias(N); K % 32 == 0. fp32 MFMA. */
+int dc_op_linear(dc_ctx* ctx, const float* A, const float* W, const float* bias, float* C,
+                 int M, int N, int K, int relu);
+/* nn.MakeAnchors (MakeAnchors.lua:40-67) + nn.ReshapeBoxFeatures order: out (k*h*w,4). */
+int dc_op_make_anchors(dc_ctx* ctx, float* out, int h, int w, float x0, float y0, float sx, float sy,
+                       const float* anchors_dev /*(2,k)*/, int k);
+/* nn.ApplyBoxTransform (ApplyBoxTransform.lua:63-90): (n,4),(n,4)->(n,4). */
+int dc_op_apply_box_transform(dc_ctx* ctx, const float* boxes, const float* trans, float* out, int n);
+/* box_utils.clip_boxes(boxes,{x_min=1,y_min=1,x_max=W,y_max=H},'xcycwh') (box_utils.lua:486-523). */
+int dc_op_clip_boxes(dc_ctx* ctx, const float* boxes, float* clipped, uint8_t* valid, int n,
+                     float x_min, float y_min, float x_max, float y_max);
+/* box_utils.xcycwh_to_x1y1x2y2 (box_utils.lua:270-298). */
+int dc_op_xcycwh_to_x1y1x2y2(dc_ctx* ctx, const float* boxes, float* out, int n);
+/* nn.BoxIoU (BoxIoU.lua:40-73): (B1,4),(B2,4) xcycwh -> (B1,B2).  convention 0 =
+ * module as written ((w-1)/2 corners, no +1), 1 = NMS inline (+1) convention. */
+int dc_op_box_iou(dc_ctx* ctx, const float* b1, const float* b2, float* out, int B1, int B2, int convention);
+/* Fused LocalizationLayer._forward_test lines 265-308 after the head convs: heads (h,w,6k)
+ * HWC with channels [0,4k) box (a*4+d) and [4k,6k) score (a*2+d) -> per anchor-row
+ * b = a*h*w + y*w + x: boxes (clipped xcycwh), anchors, trans, x1y1x2y2, p, valid. Any out may be NULL. */
+int dc_op_rpn_decode(dc_ctx* ctx, const float* heads_hwc, int h, int w, int k, const float* anchors_dev,
+                     float x0, float y0, float sx, float sy, int img_h, int img_w,
+                     float* boxes, float* anchors_out, float* trans, float* x1y1x2y2, float* p, uint8_t* valid);
+/* box_utils.nms (box_utils.lua:154-256).  boxes (n,4) x1y1x2y2, scores (n), valid (n) or
+ * NULL; max_boxes < 0 = uncapped.  Writes 0-based picks (capacity >= min(n,max_boxes))
+ * in decreasing score order (ties: lower index first) and their count (device int32). */
+int dc_op_nms(dc_ctx* ctx, const float* boxes, const float* scores, const uint8_t* valid, int n,
+              float thresh, int max_boxes, int32_t* picks, int32_t* count);
+/* nn.BilinearRoiPooling forward (BilinearRoiPooling.lua:42-60): feat (h,w,C) HWC, boxes (B,4)
+ * xcycwh image px -> out.  out_layout 0: (B,C,HH,WW) as the reference; 1: (B,HH,WW,C). */
+int dc_op_bilinear_roi_pool(dc_ctx* ctx, const float* feat_hwc, int h, int w, int C, const float* boxes,
+                            int B, int img_h, int img_w, int HH, int WW, float* out, int out_layout);
+/* LanguageModel:sample, greedy (LanguageModel.lua:293-348) with the ctx's loaded language
+ * model: codes (n,fc_dim) -> tokens (n,T) int32 1-based. */
+int dc_op_lm_sample(dc_ctx* ctx, const float* codes, int n, int32_t* tokens);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DENSECAP_H */

@@ -1,0 +1,150 @@
+"""End-to-end and language-model parity of the HIP path against the CPU oracle on the
+synthetic 720x600 / 1000-proposal configuration (BASELINE.json configs[1]) and a small one.
+
+Greedy NMS and arg-max are discontinuous: an fp32 rounding difference upstream (device expf
+vs glibc, MFMA summation order vs BLAS) can flip a near-tie.  Exact integer parity is asserted
+under teacher forcing in test_gpu_ops.py; here the comparison is flip-aware: rows are matched
+by box identity and every mismatch must be explained by a near-tie margin in the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def weights():
+    from densecap_amd.weights import make_synthetic_weights
+    return make_synthetic_weights(seed=1234)
+
+
+@pytest.fixture(scope="module")
+def model(weights):
+    from densecap_amd import DenseCapModel
+    m = DenseCapModel(weights, device=0)
+    yield m
+    m.ctx.close()
+
+
+def _oracle(weights, img, P, T=15):
+    import torch
+    from oracle import densecap_oracle as O
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    st = {}
+    out = O.forward_test(img, weights, 0.7, 0.3, P, T, stages=st)
+    return out, st
+
+
+def _rel_err(a, b):
+    return float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-30)
+
+
+def _check_against_oracle(model, weights, H, W, P, seed):
+    from densecap_amd.weights import make_synthetic_image
+    from oracle import densecap_oracle as O
+    img = make_synthetic_image(H, W, seed)
+    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
+    boxes, scores, tokens = model.forward_raw(img)
+    (oboxes, oscores, oseq), st = _oracle(weights, img, P)
+    fh, fw = st["feat"].shape[1:]
+    # -- trunk features (MFMA conv trunk) : 1e-4 relative
+    feat, _ = model.debug_fetch("feat_hwc", (fh, fw, 512))
+    assert _rel_err(feat.transpose(2, 0, 1), st["feat"]) < REL
+    # -- RPN scores / boxes for every anchor
+    A = 12 * fh * fw
+    p, _ = model.debug_fetch("rpn_p", (A,))
+    assert st["rpn"]["valid"].all()
+    np.testing.assert_allclose(p, st["rpn"]["p"], rtol=2e-4, atol=1e-6)
+    rb, _ = model.debug_fetch("rpn_boxes", (A, 4))
+    np.testing.assert_allclose(rb, st["rpn"]["boxes"], rtol=1e-4, atol=1e-2)
+    # -- RPN NMS picks: identical up to near-tie flips
+    idx, _ = model.debug_fetch("rpn_nms_idx", (P,), np.int32)
+    cnt, _ = model.debug_fetch("rpn_nms_count", (1,), np.int32)
+    assert cnt[0] == len(st["rpn_nms_idx"])
+    same = np.intersect1d(idx[:cnt[0]], st["rpn_nms_idx"]).size / float(cnt[0])
+    assert same >= 0.98, "RPN NMS pick overlap %.4f" % same
+    # -- final outputs, matched by box identity
+    assert abs(len(boxes) - len(oboxes)) <= max(2, len(oboxes) // 50)
+    matched = 0
+    tok_same = 0
+    for i, ob in enumerate(oboxes):
+        d = np.abs(boxes - ob).max(axis=1) if len(boxes) else np.array([np.inf])
+        j = int(np.argmin(d))
+        if d[j] <= 1e-4 * max(1.0, np.abs(ob).max()) * 10:
+            matched += 1
+            assert abs(scores[j] - oscores[i]) <= REL * max(1.0, abs(oscores[i])) * 10
+            tok_same += int((tokens[j] == oseq[i]).all())
+    assert matched >= 0.95 * len(oboxes), "matched %d of %d final boxes" % (matched, len(oboxes))
+    assert tok_same >= 0.97 * matched, "identical token rows %d of %d" % (tok_same, matched)
+    # scores are returned in decreasing order (box_utils.nms contract)
+    assert (np.diff(scores) <= 0).all()
+    return dict(K=len(boxes), K_oracle=len(oboxes), matched=matched, tok_same=tok_same, pick_overlap=same)
+
+
+def test_forward_small_image(model, weights):
+    r = _check_against_oracle(model, weights, 224, 288, 100, seed=3)
+    assert r["K"] > 0
+
+
+def test_forward_720x600_1000_proposals(model, weights):
+    r = _check_against_oracle(model, weights, 600, 720, 1000, seed=0)
+    assert r["K"] > 0
+    t = model.stage_times()
+    assert set(t) >= {"vgg16_trunk", "rpn_nms", "bilinear_roi_pool", "lstm_decode"}
+    assert all(v >= 0 for v in t.values())
+
+
+def test_lm_sample_teacher_forced(model, weights):
+    """LanguageModel:sample on the ORACLE's fc7 codes: tokens identical except where the oracle's
+    own top-2 logit margin is within fp32 noise."""
+    import ctypes as C
+    import torch
+    from densecap_amd._lib import check
+    from oracle import densecap_oracle as O
+    rng = np.random.default_rng(0)
+    n = 300
+    codes = np.maximum(rng.standard_normal((n, 4096)), 0).astype(np.float32)
+    oseq, logits = O.lm_sample(torch.from_numpy(codes), weights, 15, return_logits=True)
+    ctx = model.ctx
+    cd = ctx.to_device(codes); td = ctx.empty((n, 15), np.int32)
+    check(ctx.h, ctx.lib.dc_op_lm_sample(ctx.h, cd.ptr, n, td.ptr), "dc_op_lm_sample")
+    seq = td.numpy()
+    bad_rows = np.nonzero((seq != oseq).any(axis=1))[0]
+    for r in bad_rows:
+        t = int(np.nonzero(seq[r] != oseq[r])[0][0])   # first divergence must be a near-tie
+        top2 = torch.topk(logits[t][r], 2).values
+        margin = float(top2[0] - top2[1]) / max(1.0, float(top2[0].abs()))
+        assert margin < 1e-4, "row %d step %d diverged with margin %g" % (r, t, margin)
+    assert len(bad_rows) <= max(1, n // 50)
+    assert seq.min() >= 1 and seq.max() <= weights["vocab_size"] + 1
+
+
+def test_forward_batch_equals_single(model, weights):
+    from densecap_amd.weights import make_synthetic_image
+    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=100)
+    imgs = np.stack([make_synthetic_image(224, 288, s) for s in range(5)])
+    batch = model.forward_batch(imgs)
+    for i in (0, 3, 4):
+        b, s, t = model.forward_raw(imgs[i])
+        np.testing.assert_array_equal(batch[i][0], b)
+        np.testing.assert_array_equal(batch[i][1], s)
+        np.testing.assert_array_equal(batch[i][2], t)
+
+
+def test_extract_features(model, weights):
+    from densecap_amd.weights import make_synthetic_image
+    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=100)
+    img = make_synthetic_image(224, 288, 3)
+    b, s, _ = model.forward_raw(img)
+    fb, ff = model.extractFeatures(img)
+    np.testing.assert_array_equal(fb, b)
+    assert ff.shape == (len(b), 4096) and (ff >= 0).all() and ff.max() > 0
+
+
+def test_errors_are_reported_not_thrown(model):
+    from densecap_amd._lib import DenseCapError
+    with pytest.raises(DenseCapError):
+        model.setTestArgs(num_proposals=-1)
+    model.setTestArgs(num_proposals=100)
+    with pytest.raises(AssertionError):
+        model.forward_raw(np.zeros((1, 4, 64, 64), np.float32))

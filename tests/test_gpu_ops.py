@@ -1,0 +1,236 @@
+"""Stage-wise (teacher-forced) parity of the HIP kernels against the CPU oracle.
+
+Every test calls the kernels through the C ABI (densecap_amd.ops -> libdensecap_hip.so).
+Integer outputs (NMS picks, valid flags) must be bit-exact; fp32 outputs within the
+north-star tolerance 1e-4 relative (tighter where the arithmetic is order-identical)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4  # BASELINE.json north_star: boxes/scores within 1e-4 relative fp32
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from densecap_amd.ops import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _close(a, b, rel=REL):
+    scale = max(float(np.abs(b).max()), 1e-30)
+    err = float(np.abs(a - b).max())
+    assert err <= rel * scale, "max abs err %g vs scale %g" % (err, scale)
+
+
+# ---- dense contractions --------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 32, 9, 11, 64), (1, 64, 38, 45, 72), (2, 64, 20, 17, 128),
+                                   (1, 128, 75, 90, 256), (1, 512, 38, 45, 256), (1, 64, 150, 180, 64)])
+def test_conv3x3_matches_torch(ctx, shape):
+    import torch
+    from densecap_amd import ops
+    N, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)).float().numpy()
+    out = ops.conv3x3(ctx, x.numpy(), w.numpy(), b.numpy(), relu=True)
+    _close(out, ref)
+    out2 = ops.conv3x3(ctx, x.numpy(), w.numpy(), b.numpy(), relu=False)
+    ref2 = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1).float().numpy()
+    _close(out2, ref2)
+
+
+def test_conv1_1_c3_matches_torch(ctx):
+    import torch
+    from densecap_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(1, 3, 67, 83, generator=g) * 255 - 110
+    w = torch.randn(64, 3, 3, 3, generator=g) * 0.27
+    b = torch.randn(64, generator=g)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)).float().numpy()
+    _close(ops.conv3x3(ctx, x.numpy(), w.numpy(), b.numpy(), relu=True), ref)
+
+
+@pytest.mark.parametrize("hw", [(8, 8), (75, 90), (7, 13), (1, 5)])
+def test_maxpool_ceil(ctx, hw):
+    import torch
+    from densecap_amd import ops
+    x = torch.randn(2, 64, *hw, generator=torch.Generator().manual_seed(1))
+    ref = torch.nn.functional.max_pool2d(x, 2, 2, ceil_mode=True).numpy()
+    np.testing.assert_array_equal(ops.maxpool2x2_ceil(ctx, x.numpy()), ref)
+
+
+@pytest.mark.parametrize("mnk", [(1000, 4096, 512), (1000, 72, 256), (37, 5, 4096), (300, 10498, 512),
+                                 (1710, 64, 64), (129, 257, 96), (1, 1, 32)])
+def test_linear_matches_fp64(ctx, mnk):
+    from densecap_amd import ops
+    M, N, K = mnk
+    rng = np.random.default_rng(M + N + K)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    _close(ops.linear(ctx, x, w, b), ref.astype(np.float32), rel=2e-5)
+    _close(ops.linear(ctx, x, w, b, relu=True), np.maximum(ref, 0).astype(np.float32), rel=2e-5)
+    _close(ops.linear(ctx, x, w, None), (ref - b).astype(np.float32), rel=2e-5)
+
+
+def test_linear_transpose_detecting(ctx):
+    # A = I with an asymmetric W catches a swapped C/D register map
+    from densecap_amd import ops
+    K = 64
+    x = np.eye(K, dtype=np.float32)
+    w = np.arange(96 * K, dtype=np.float32).reshape(96, K)
+    np.testing.assert_array_equal(ops.linear(ctx, x, w, None), w.T)
+
+
+def test_layout_roundtrip(ctx):
+    from densecap_amd import ops
+    x = np.random.default_rng(0).standard_normal((19, 13, 37)).astype(np.float32)
+    h = ops.chw_to_hwc(ctx, x)
+    np.testing.assert_array_equal(h, x.transpose(1, 2, 0))
+    np.testing.assert_array_equal(ops.hwc_to_chw(ctx, h), x)
+
+
+# ---- box algebra: the reference's known-answer tests, on the GPU ---------------------------------
+def test_apply_box_transform_golden(ctx, golden):
+    from densecap_amd import ops
+    g = golden["apply_box_transform"]
+    out = ops.apply_box_transform(ctx, np.array(g["boxes"]), np.array(g["trans"]))
+    np.testing.assert_allclose(out, np.array(g["expected"]), atol=1e-4, rtol=1e-6)
+
+
+def test_make_boxes_golden(ctx, golden):
+    from densecap_amd import ops
+    for case in golden["make_boxes"]:
+        N, k, H, W = case["N"], case["k"], case["H"], case["W"]
+        anchors = np.array(case["anchors"], np.float32)
+        head = np.zeros((N, 4 * k, H, W), np.float32)
+        for (n, a, y, x), v in case["inputs"]:
+            head[n, 4 * a:4 * a + 4, y, x] = v
+        anc = ops.make_anchors(ctx, H, W, case["x0"], case["y0"], case["sx"], case["sy"], anchors)
+        for n in range(N):
+            trans = head[n].reshape(k, 4, H, W).transpose(0, 2, 3, 1).reshape(-1, 4)
+            boxes = ops.apply_box_transform(ctx, anc, trans)
+            for (nn, y, x, a), v in case["expected"]:
+                if nn == n:
+                    np.testing.assert_allclose(boxes[a * H * W + y * W + x], v, atol=1e-4)
+
+
+def test_box_conversions_and_clip_exact(ctx):
+    from densecap_amd import ops
+    from oracle import densecap_oracle as O
+    rng = np.random.default_rng(5)
+    b = np.concatenate([rng.uniform(-100, 900, (5000, 2)), rng.uniform(0.1, 800, (5000, 2))], 1).astype(np.float32)
+    b[:50, 2:] = rng.uniform(0, 1.2, (50, 2))  # degenerate boxes exercise valid=false
+    np.testing.assert_array_equal(ops.xcycwh_to_x1y1x2y2(ctx, b), O.xcycwh_to_x1y1x2y2(b))
+    c, v = ops.clip_boxes(ctx, b, dict(x_min=1, y_min=1, x_max=720, y_max=600))
+    co, vo = O.clip_boxes_xcycwh(b, 1, 1, 720, 600)
+    np.testing.assert_array_equal(c, co)
+    np.testing.assert_array_equal(v, vo)
+    assert 0 < (~vo).sum() < 50
+
+
+def test_box_iou_module(ctx):
+    from densecap_amd import ops
+    from oracle import densecap_oracle as O
+    rng = np.random.default_rng(6)
+    b1 = np.concatenate([rng.uniform(0, 300, (70, 2)), rng.uniform(5, 200, (70, 2))], 1).astype(np.float32)
+    b2 = np.concatenate([rng.uniform(0, 300, (33, 2)), rng.uniform(5, 200, (33, 2))], 1).astype(np.float32)
+    np.testing.assert_array_equal(ops.box_iou(ctx, b1, b2, 0), O.box_iou_module(b1, b2))
+
+
+def test_rpn_decode_matches_oracle(ctx):
+    from densecap_amd import ops
+    from oracle import densecap_oracle as O
+    rng = np.random.default_rng(7)
+    k, h, w = 12, 38, 45
+    box_head = (rng.standard_normal((4 * k, h, w)) * 0.3).astype(np.float32)
+    score_head = (rng.standard_normal((2 * k, h, w)) * 1.5).astype(np.float32)
+    d = ops.rpn_decode(ctx, box_head, score_head, 600, 720, O.DEFAULT_ANCHORS, O.VGG16_FIELD_CENTERS)
+    o = O.rpn_decode(box_head, score_head, 600, 720)
+    np.testing.assert_array_equal(d["valid"], o["valid"])
+    rows = o["rows"]
+    np.testing.assert_array_equal(d["anchors"][rows], o["anchors"])
+    np.testing.assert_array_equal(d["trans"][rows], o["trans"])
+    # exp() on the device is not glibc's expf: a few ulp on w,h and p
+    np.testing.assert_allclose(d["boxes"][rows], o["boxes"], rtol=2e-6, atol=1e-4)
+    np.testing.assert_allclose(d["x1y1x2y2"][rows], o["x1y1x2y2"], rtol=2e-6, atol=2e-4)
+    np.testing.assert_allclose(d["p"][rows], o["p"], rtol=5e-6)
+
+
+# ---- NMS ----------------------------------------------------------------------------------------
+def test_nms_golden(ctx, golden):
+    from densecap_amd import ops
+    for case in golden["nms"]:
+        pick = ops.nms(ctx, np.array(case["boxes"], np.float32), case["thresh"])
+        assert pick.tolist() == case["expected"], case["cite"]
+
+
+def _random_boxes5(rng, n, ties=False):
+    xy = rng.uniform(0, 700, (n, 2)); wh = rng.uniform(8, 400, (n, 2))
+    s = rng.uniform(0, 1, (n, 1))
+    if ties:
+        s = np.round(s, 3)
+    return np.concatenate([xy, xy + wh, s], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,thr,maxb,ties", [(1, 0.7, 10, False), (63, 0.5, None, False), (64, 0.3, None, True),
+                                              (65, 0.7, 7, False), (1000, 0.3, None, True),
+                                              (5000, 0.7, 300, True), (20520, 0.7, 1000, False),
+                                              (20520, 0.7, 1000, True), (36720, 0.7, 2000, False)])
+def test_nms_exact_vs_oracle(ctx, n, thr, maxb, ties):
+    from densecap_amd import ops
+    from oracle import densecap_oracle as O
+    b = _random_boxes5(np.random.default_rng(n + int(thr * 10)), n, ties)
+    assert ops.nms(ctx, b, thr, maxb).tolist() == O.nms(b, thr, maxb).tolist()
+
+
+def test_nms_valid_mask_equals_compaction(ctx):
+    # LocalizationLayer.lua:285-298 compacts by `valid` before NMS; masking is equivalent
+    from densecap_amd import ops
+    from oracle import densecap_oracle as O
+    rng = np.random.default_rng(11)
+    b = _random_boxes5(rng, 3000, True)
+    valid = rng.uniform(size=3000) > 0.2
+    rows = np.nonzero(valid)[0]
+    assert ops.nms(ctx, b, 0.6, 200, valid=valid).tolist() == rows[O.nms(b[rows], 0.6, 200)].tolist()
+
+
+def test_nms_empty(ctx):
+    from densecap_amd import ops
+    assert ops.nms(ctx, np.zeros((0, 5), np.float32), 0.5).size == 0
+
+
+# ---- bilinear RoI pooling ----------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [dict(B=10, C=128, h=32, w=33, HH=7, WW=8, H=512, W=528),   # BatchBilinearSamplerBHWD_test.lua:15-46 shapes
+                                 dict(B=1000, C=512, h=38, w=45, HH=7, WW=7, H=600, W=720),
+                                 dict(B=128, C=512, h=32, w=32, HH=7, WW=7, H=512, W=512)])  # BilinearRoiPooling_test.lua:58-97
+def test_bilinear_roi_pool_vs_oracle(ctx, cfg):
+    from densecap_amd import ops
+    from oracle import densecap_oracle as O
+    rng = np.random.default_rng(cfg["B"])
+    feat = rng.standard_normal((cfg["C"], cfg["h"], cfg["w"])).astype(np.float32)
+    B = cfg["B"]
+    boxes = np.concatenate([rng.uniform(-50, cfg["W"] + 50, (B, 1)), rng.uniform(-50, cfg["H"] + 50, (B, 1)),
+                            rng.uniform(2, cfg["W"], (B, 1)), rng.uniform(2, cfg["H"], (B, 1))], 1).astype(np.float32)
+    ref = O.bilinear_roi_pool(feat, boxes, cfg["H"], cfg["W"], cfg["HH"], cfg["WW"])
+    out = ops.bilinear_roi_pool(ctx, feat, boxes, cfg["H"], cfg["W"], cfg["HH"], cfg["WW"], out_layout=0)
+    np.testing.assert_allclose(out, ref, atol=1e-6, rtol=0)   # the reference's own fast-vs-naive tolerance
+    out1 = ops.bilinear_roi_pool(ctx, feat, boxes, cfg["H"], cfg["W"], cfg["HH"], cfg["WW"], out_layout=1)
+    np.testing.assert_array_equal(out1.transpose(0, 3, 1, 2), out)
+    assert (np.abs(ref).sum(axis=(1, 2, 3)) > 0).all()
+
+
+def test_bilinear_roi_pool_identity_property(ctx):
+    # whole-image box sampled at the map's own resolution returns the map (BoxToAffine_visual_test.ipynb)
+    from densecap_amd import ops
+    feat = np.random.default_rng(2).standard_normal((16, 9, 11)).astype(np.float32)
+    H, W = 144, 176
+    box = np.array([[(W + 1) / 2, (H + 1) / 2, W, H]], np.float32)
+    out = ops.bilinear_roi_pool(ctx, feat, box, H, W, 9, 11)
+    np.testing.assert_allclose(out[0], feat, atol=1e-5)
