@@ -71,6 +71,7 @@ struct dc_ctx {
   std::string err;
   bool have_weights = false;
   float rpn_nms_thresh = 0.7f, final_nms_thresh = 0.3f;
+  int max_lanes = 3;
   int num_proposals = 300;  // LocalizationLayer default (LocalizationLayer.lua:237); run_model sets 1000
   // dims
   int k = 0, R = 0, V = 0, T = 0, E = 0, Hd = 0, D = 0;
@@ -460,6 +461,13 @@ int dc_set_test_args(dc_ctx* ctx, float rpn_nms_thresh, float final_nms_thresh, 
   return DC_OK;
 }
 
+int dc_set_lanes(dc_ctx* ctx, int lanes) {
+  if (!ctx) return DC_E_INVALID;
+  if (lanes < 1 || lanes > 4) return ctx->fail(DC_E_INVALID, "dc_set_lanes: lanes must be in [1,4]");
+  ctx->max_lanes = lanes;
+  return DC_OK;
+}
+
 int dc_load_weights(dc_ctx* ctx, const dc_weights* w) {
   if (!ctx || !w) return DC_E_INVALID;
   HIPCHK(hipSetDevice(ctx->device));
@@ -568,7 +576,7 @@ static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, i
   const int P = ctx->num_proposals;
   for (int i = 0; i < n; ++i)
     if (outs[i].capacity <= 0) return ctx->fail(DC_E_INVALID, "dc_result.capacity must be > 0");
-  const int nl = std::min(n, 3);
+  const int nl = std::min(n, ctx->max_lanes);
   while ((int)ctx->lanes.size() < nl) ctx->lanes.emplace_back(new Lane());
   for (int l = 0; l < nl; ++l) DCCHK(lane_prepare(ctx, *ctx->lanes[l], H, W, P));
   const size_t img_elems = (size_t)3 * H * W;

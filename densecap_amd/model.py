@@ -77,6 +77,11 @@ class DenseCapModel:
                                                     int(self.opt["num_proposals"])), "dc_set_test_args")
         return self
 
+    def setLanes(self, lanes):
+        """Streams dc_forward_batch pipelines images over (1 = serial kernels)."""
+        check(self.ctx.h, self.lib.dc_set_lanes(self.ctx.h, int(lanes)), "dc_set_lanes")
+        return self
+
     def convert(self, dtype=None, use_cudnn=None):
         """model:convert(dtype, use_cudnn): the HIP path is always fp32 on the ctx's device."""
         return self

@@ -121,6 +121,9 @@ int dc_forward_test(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_
  * back to back; images are software-pipelined over the ctx's lanes (streams). */
 int dc_forward_batch(dc_ctx* ctx, const float* imgs, int n, int H, int W, int imgs_on_device,
                      dc_result* outs);
+/* Number of lanes (HIP streams with private workspaces, 1..4, default 3) dc_forward_batch
+ * pipelines images over.  1 = strictly serial kernels (what per-kernel profiles want). */
+int dc_set_lanes(dc_ctx* ctx, int lanes);
 /* DenseCapModel:extractFeatures (DenseCapModel.lua:285-304): boxes (K,4) and fc7
  * codes (K,fc_dim) after the final NMS; the LSTM decode is skipped. Host outputs. */
 int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_device,

