@@ -24,7 +24,14 @@ struct GemmDesc {
   const float* rowterm = nullptr;
   const int32_t* rowidx = nullptr;   // values are 1-based token ids -> row = id-1
   int rowterm_ld = 0;
+  // optional fused row arg-max (vocab projection): instead of storing C, every (row, N-tile) writes its
+  // best (value, column) to amax_val/amax_idx[(m * amax_ld) + tile_n]; C may be null.
+  float* amax_val = nullptr;
+  int32_t* amax_idx = nullptr;
+  int amax_ld = 0;
 };
+// number of N-tiles launch_mfma_gemm will use for this problem (size of the arg-max partial rows)
+int mfma_gemm_ntiles_n(const GemmDesc& d);
 // Launches the fp32 MFMA kernel on `stream`; returns hipSuccess or the launch error.
 hipError_t launch_mfma_gemm(const GemmDesc& d, hipStream_t stream);
 double gemm_flops(const GemmDesc& d);
@@ -45,6 +52,9 @@ hipError_t launch_lstm_pointwise(const float* gates, float* c, float* h, int n, 
 hipError_t launch_row_argmax(const float* logits, int n, int N, int ld, int32_t* tok, int32_t* seq, int T, int t,
                              hipStream_t s);
 hipError_t launch_fill_i32(int32_t* p, int32_t v, int n, hipStream_t s);
+// reduce the per-N-tile arg-max partials of the fused vocab epilogue: tok[m] = seq[m*T+t] = 1 + argmax
+hipError_t launch_argmax_finalize(const float* pval, const int32_t* pidx, int n, int ntiles, int ld, int32_t* tok,
+                                  int32_t* seq, int T, int t, hipStream_t s);
 // objectness + box regression heads + final ApplyBoxTransform (DenseCapModel.lua:134,139-140)
 hipError_t launch_recog_heads(const float* codes, const float* w5 /*(5,D): obj, 4 boxreg*/, const float* b5,
                               const float* roi_boxes, float* obj, float* trans, float* final_boxes, int n, int D,

@@ -283,8 +283,14 @@ int lm_sample(dc_ctx* ctx, Lane& L, const float* codes, int n, int32_t* seq_out)
     d.rowterm = ctx->xg; d.rowidx = L.tok; d.rowterm_ld = 4 * Hd;
     DCCHK(run_gemm(ctx, d, s));
     KCHK(launch_lstm_pointwise(L.gates, L.cstate, L.hstate, n, Hd, 0, s));
-    DCCHK(linear(ctx, s, L.hstate, ctx->out_w, ctx->out_b, L.logits, n, V1, Hd, 0));
-    KCHK(launch_row_argmax(L.logits, n, V1, V1, L.tok, seq_out, T, t, s));
+    {  // vocab projection with the row arg-max fused into the GEMM epilogue: logits never reach HBM
+      GemmDesc v;
+      v.A = L.hstate; v.W = ctx->out_w; v.bias = ctx->out_b; v.C = nullptr; v.M = n; v.N = V1; v.K = Hd; v.ldc = V1;
+      const int ntn = mfma_gemm_ntiles_n(v);
+      v.amax_val = L.logits; v.amax_idx = reinterpret_cast<int32_t*>(L.logits + (size_t)n * ntn); v.amax_ld = ntn;
+      DCCHK(run_gemm(ctx, v, s));
+      KCHK(launch_argmax_finalize(v.amax_val, v.amax_idx, n, ntn, ntn, L.tok, seq_out, T, t, s));
+    }
   }
   return DC_OK;
 }

@@ -179,6 +179,23 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict
   }
 }
 
+// reduce per-N-tile arg-max partials (ascending tile order, strict '>' keeps the first max)
+__global__ void argmax_finalize_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx, int n,
+                                       int ntiles, int ld, int32_t* __restrict__ tok, int32_t* __restrict__ seq,
+                                       int T, int t) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n) return;
+  float best = pval[(size_t)m * ld];
+  int bi = pidx[(size_t)m * ld];
+  for (int j = 1; j < ntiles; ++j) {
+    const float v = pval[(size_t)m * ld + j];
+    const int i = pidx[(size_t)m * ld + j];
+    if (i != 0x7fffffff && (bi == 0x7fffffff || v > best)) { best = v; bi = i; }
+  }
+  tok[m] = bi + 1;
+  seq[(size_t)m * T + t] = bi + 1;
+}
+
 __global__ void fill_i32_kernel(int32_t* p, int32_t v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -269,6 +286,12 @@ hipError_t launch_lstm_pointwise(const float* gates, float* c, float* h, int n, 
 hipError_t launch_row_argmax(const float* logits, int n, int N, int ld, int32_t* tok, int32_t* seq, int T, int t,
                              hipStream_t s) {
   hipLaunchKernelGGL(row_argmax_kernel, dim3((n + 3) / 4), dim3(256), 0, s, logits, n, N, ld, tok, seq, T, t);
+  return hipGetLastError();
+}
+hipError_t launch_argmax_finalize(const float* pval, const int32_t* pidx, int n, int ntiles, int ld, int32_t* tok,
+                                  int32_t* seq, int T, int t, hipStream_t s) {
+  hipLaunchKernelGGL(argmax_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pval, pidx, n, ntiles, ld, tok,
+                     seq, T, t);
   return hipGetLastError();
 }
 hipError_t launch_fill_i32(int32_t* p, int32_t v, int n, hipStream_t s) {

@@ -18,6 +18,8 @@
 // a fixed permutation of the summation order, identical for A and B.
 // Pipeline: register-staged double buffering, one s_barrier per K-tile: global loads of
 // tile t+1 are issued before the MFMAs of tile t and written to the other LDS buffer after.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -178,10 +180,276 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmDesc d, int ntm, int
   }
 }
 
+
+// =========================================================================================
+// v2: LDS-DMA (buffer_load ... lds) 3-stage ring, fragment double-buffering, ONE barrier per
+// K-tile placed in the MIDDLE of the tile's MFMA sequence.
+//
+//  * operands go HBM/L2 -> LDS directly (no staging VGPRs, no ds_write); conv zero padding
+//    comes for free from the buffer descriptor's out-of-range rule (offset >= num_records
+//    returns 0), so the im2col patch is assembled by the memory unit;
+//  * LDS rows are 128 B, unpadded (an LDS-DMA wave instruction writes 1 KiB linearly = 8 rows);
+//    bank conflicts are avoided by XOR-swizzling the 16-byte chunk index with (row>>1)&7 on the
+//    SOURCE address and on the fragment read;
+//  * tile t+2 is requested right after the barrier of tile t, i.e. a full K-tile (64 MFMAs per
+//    wave = 4096 cycles) before it is needed; the barrier sits after MFMA group 1 so the first
+//    fragments of tile t+1 are fetched from LDS while groups 2-3 of tile t execute: the MFMA
+//    pipe never waits for an LDS round trip.
+// =========================================================================================
+template <int TM, int TN, bool CONV>
+__global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int PA = BM / 32, PB = BN / 32;
+  constexpr int STAGE = (BM + BN) * BK;  // floats per ring stage
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int nblk = ntm * ntn;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, o = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+  }
+  int tile_m, tile_n;
+  if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
+  else           { tile_n = bid % ntn; tile_m = bid / ntn; }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int lrow = tid >> 3;                              // 0..31: row within a 32-row pass
+  const int lchunk = (tid & 7) ^ ((lrow >> 1) & 7);        // LOGICAL 16-B chunk this lane fetches
+
+  // ---- buffer descriptors (wave-uniform) + per-lane byte offsets ---------------------------
+  __amdgpu_buffer_rsrc_t rsrcA, rsrcB;
+  unsigned a_off[PA];
+  int a_y[PA], a_x[PA];
+  bool a_ok[PA];
+  if constexpr (CONV) {
+    const size_t bytes = (size_t)d.M * d.Cin * 4;
+    rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : bytes), 0x00020000);
+    const int hw = d.H * d.Wd;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      int m = m0 + lrow + 32 * i;
+      a_ok[i] = m < d.M;
+      if (m >= d.M) m = d.M - 1;
+      const int img = m / hw, rem = m - img * hw;
+      a_y[i] = rem / d.Wd;
+      a_x[i] = rem - a_y[i] * d.Wd;
+      a_off[i] = (unsigned)m * (unsigned)d.Cin * 4u + (unsigned)lchunk * 16u;
+    }
+  } else {
+    const float* baseA = d.A + (size_t)m0 * d.K;
+    const size_t bytes = (size_t)(d.M - m0) * d.K * 4;
+    rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : bytes), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      int rr = lrow + 32 * i;
+      if (m0 + rr >= d.M) rr = d.M - 1 - m0;
+      a_off[i] = (unsigned)rr * (unsigned)d.K * 4u + (unsigned)lchunk * 16u;
+      a_ok[i] = true; a_y[i] = a_x[i] = 0;
+    }
+  }
+  unsigned b_off[PB];
+  {
+    const float* baseB = d.W + (size_t)n0 * d.K;
+    const size_t bytes = (size_t)(d.N - n0) * d.K * 4;
+    rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)baseB, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : bytes), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      int rr = lrow + 32 * i;
+      if (n0 + rr >= d.N) rr = d.N - 1 - n0;
+      b_off[i] = (unsigned)rr * (unsigned)d.K * 4u + (unsigned)lchunk * 16u;
+    }
+  }
+
+  int tap = 0, c0 = 0;  // conv K-walk
+  // request K-tile `kt` into ring stage `st`
+  auto issue = [&](int kt, int st) {
+    float* sa = smem + st * STAGE + (8 * wid) * BK;       // this wave's 8-row slice of pass 0
+    float* sb = sa + BM * BK;
+    if constexpr (CONV) {
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      const int toff = ((dy * d.Wd + dx) * d.Cin + c0) * 4;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const bool ok = a_ok[i] && (unsigned)(a_y[i] + dy) < (unsigned)d.H && (unsigned)(a_x[i] + dx) < (unsigned)d.Wd;
+        const unsigned vo = ok ? a_off[i] + (unsigned)toff : 0xfffffff0u;   // out of range -> zeros
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, sa + i * 32 * BK, 16, (int)vo, 0, 0, 0);
+      }
+      c0 += BK;
+      if (c0 >= d.Cin) { c0 = 0; ++tap; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, sa + i * 32 * BK, 16, (int)a_off[i], kt * (BK * 4), 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, sb + i * 32 * BK, 16, (int)b_off[i], kt * (BK * 4), 0, 0);
+  };
+
+  // ---- fragment addressing --------------------------------------------------------------------
+  const int r = lane & 31, hsel = lane >> 5;
+  int foff[4];  // float offset of logical chunk (2g+hsel) of row r inside a 32-row block
+#pragma unroll
+  for (int g = 0; g < 4; ++g) foff[g] = r * BK + (((2 * g + hsel) ^ ((r >> 1) & 7)) << 2);
+  const int a_base = (wm * 32 * TM) * BK;
+  const int b_base = BM * BK + (wn * 32 * TN) * BK;
+
+  f32x4 fa[2][TM], fb[2][TN];
+  auto read_frag = [&](int st, int g, int set) {
+    const float* base = smem + st * STAGE + foff[g];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(base + a_base + i * 32 * BK);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[set][j] = *reinterpret_cast<const f32x4*>(base + b_base + j * 32 * BK);
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  auto mfma_group = [&](int set) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
+  };
+
+  const int nkt = d.K / BK;
+  issue(0, 0);
+  if (nkt > 1) issue(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  read_frag(0, 0, 0);
+
+  int st = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int st1 = st == 2 ? 0 : st + 1;
+    const int st2 = st1 == 2 ? 0 : st1 + 1;
+    read_frag(st, 1, 1);
+    mfma_group(0);
+    read_frag(st, 2, 0);
+    mfma_group(1);
+    // ---- mid-tile rendezvous: tile kt+1 has landed everywhere; stage st2 (tile kt-1) is free
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 2 < nkt) issue(kt + 2, st2);
+    read_frag(st, 3, 1);
+    mfma_group(0);
+    if (kt + 1 < nkt) read_frag(st1, 0, 0);
+    mfma_group(1);
+    st = st1;
+  }
+
+  if constexpr (!CONV) {
+    if (d.amax_val != nullptr) {
+      // ---- fused row arg-max epilogue (vocab projection + torch.max, LanguageModel.lua:326-329) ----
+      // lane -> best over its TN columns; xor-shuffle over the 32 lanes of a half-wave; the two
+      // waves that share rows (wn = 0,1) meet in LDS.  Ties: lower column wins (first max).
+      __syncthreads();                      // everyone is done reading the operand ring
+      float* lv = smem;                     // [2][BM]
+      int* li = reinterpret_cast<int*>(smem + 2 * BM);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float bv_ = -INFINITY;
+          int bi_ = 0x7fffffff;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 32 * TN + j * 32 + r;
+            if (n < d.N) {
+              const float v = acc[i][j][e] + (d.bias ? d.bias[n] : 0.f);
+              if (v > bv_ || (bi_ == 0x7fffffff)) { bv_ = v; bi_ = n; }
+            }
+          }
+#pragma unroll
+          for (int o = 1; o < 32; o <<= 1) {
+            const float ov = __shfl_xor(bv_, o, 64);
+            const int oi = __shfl_xor(bi_, o, 64);
+            if (oi != 0x7fffffff && (bi_ == 0x7fffffff || ov > bv_ || (ov == bv_ && oi < bi_))) { bv_ = ov; bi_ = oi; }
+          }
+          if (r == e) {
+            const int row = wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hsel;
+            lv[wn * BM + row] = bv_;
+            li[wn * BM + row] = bi_;
+          }
+        }
+      }
+      __syncthreads();
+      if (tid < BM) {
+        const int m = m0 + tid;
+        if (m < d.M) {
+          float v0 = lv[tid], v1 = lv[BM + tid];
+          int i0 = li[tid], i1 = li[BM + tid];
+          if (i1 != 0x7fffffff && (i0 == 0x7fffffff || v1 > v0)) { v0 = v1; i0 = i1; }   // wn=1 has higher columns
+          d.amax_val[(size_t)m * d.amax_ld + tile_n] = v0;
+          d.amax_idx[(size_t)m * d.amax_ld + tile_n] = i0;
+        }
+      }
+      return;
+    }
+  }
+  // ---- epilogue: bias (+ gathered row term) + ReLU, channels-last store -------------------
+  // C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * 32 * TN + j * 32 + r;
+    const bool n_ok = n < d.N;
+    const float bv = (d.bias != nullptr && n_ok) ? d.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mb = m0 + wm * 32 * TM + i * 32 + 4 * hsel;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = mb + (e & 3) + 8 * (e >> 2);
+        if (n_ok && m < d.M) {
+          float v;
+          if (d.rowterm != nullptr) v = d.rowterm[(size_t)(d.rowidx[m] - 1) * d.rowterm_ld + n] + acc[i][j][e];
+          else v = acc[i][j][e] + bv;
+          if (d.relu) v = v > 0.f ? v : 0.f;
+          d.C[(size_t)m * d.ldc + n] = v;
+        }
+      }
+    }
+  }
+}
+
+
 template <int TM, int TN, bool CONV>
 hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+  const int m_fastest = ntm <= ntn ? 1 : 0;
+  static const bool use_v1 = getenv("DENSECAP_GEMM_V1") != nullptr;
+  // v2 addresses operands through 32-bit buffer offsets
+  const bool fits = CONV ? ((size_t)d.M * d.Cin * 4 < 0xfffffff0ull) : ((size_t)BM * d.K * 4 < 0xfffffff0ull);
+  if ((!use_v1 || d.amax_val != nullptr) && fits && (size_t)BN * d.K * 4 < 0xfffffff0ull) {
+    const size_t lds = (size_t)3 * (BM + BN) * BK * sizeof(float);
+    static bool attr2 = false;
+    if (!attr2) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, CONV>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      attr2 = true;
+    }
+    hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, CONV>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn,
+                       m_fastest);
+    return hipGetLastError();
+  }
+  if (d.amax_val != nullptr) return hipErrorInvalidValue;  // fused arg-max lives in the v2 kernel only
   const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -190,7 +458,6 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int m_fastest = ntm <= ntn ? 1 : 0;
   hipLaunchKernelGGL((mfma_gemm_kernel<TM, TN, CONV>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn,
                      m_fastest);
   return hipGetLastError();
@@ -208,6 +475,16 @@ hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
 }
 
 }  // namespace
+
+int mfma_gemm_ntiles_n(const GemmDesc& d) {
+  auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
+  int bn;
+  if (d.N > 64 && blocks(128, 128) >= 384) bn = 128;
+  else if (d.N <= 64 && blocks(128, 64) >= 384) bn = 64;
+  else if (d.N > 64 && blocks(128, 128) >= 200 && blocks(128, 128) <= 256) bn = 128;
+  else bn = 64;
+  return (d.N + bn - 1) / bn;
+}
 
 double gemm_flops(const GemmDesc& d) { return 2.0 * (double)d.M * (double)d.N * (double)d.K; }
 

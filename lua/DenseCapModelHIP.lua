@@ -1,0 +1,154 @@
+--[[
+DenseCapModelHIP: drop-in for the TEST-TIME API of nn.DenseCapModel
+(densecap/DenseCapModel.lua) backed by libdensecap_hip.so on an AMD MI355X.
+
+Same method names / return values as the reference:
+  model:convert(dtype, use_cudnn)            (DenseCapModel.lua:198-208)   no-op, fp32 HIP
+  model:setTestArgs{rpn_nms_thresh=, final_nms_thresh=, num_proposals=}   (:185-191)
+  model:evaluate()
+  boxes, scores, captions = model:forward_test(img)                         (:319-327)
+  boxes, feats = model:extractFeatures(img)                                 (:285-304)
+  model.nets.language_model:decodeSequence(seq)                             (LanguageModel.lua:86-103)
+
+Construction: DenseCapModelHIP.fromCheckpoint(checkpoint.model, gpu) walks the Torch7
+module tree of a loaded reference checkpoint (run_model.lua:146-147) and hands the
+FloatTensor storages to dc_load_weights.  Written against the header; not executable in
+the build container (no LuaJIT / Torch7 there) -- see INTEGRATION.md.
+--]]
+local ffi = require 'ffi'
+local hip = require 'densecap_hip'
+local C = hip.C
+
+local Model = {}
+Model.__index = Model
+
+local function fptr(t)  -- FloatTensor -> const float*
+  assert(t:type() == 'torch.FloatTensor' and t:isContiguous())
+  return ffi.cast('const float*', torch.data(t))
+end
+
+-- ref: nn.DenseCapModel instance deserialised by torch.load; gpu: 0-based HIP device
+function Model.fromCheckpoint(ref, gpu)
+  local self = setmetatable({}, Model)
+  local pctx = ffi.new('dc_ctx*[1]')
+  hip.check(nil, C.dc_create(pctx, gpu or 0), 'dc_create')
+  self.ctx = ffi.gc(pctx[0], C.dc_destroy)
+  ref:float()
+  local w = ffi.new('dc_weights')
+  local keep = {}
+  local function P(t) t = t:contiguous(); keep[#keep + 1] = t; return fptr(t) end
+  -- VGG-16 convs: conv_net1 (layers 1-10) then conv_net2 (11-30), DenseCapModel.lua:61-76
+  local convs = {}
+  for _, net in ipairs{ref.nets.conv_net1, ref.nets.conv_net2} do
+    for i = 1, #net do
+      local m = net:get(i)
+      if torch.isTypeOf(m, 'nn.SpatialConvolution') then convs[#convs + 1] = m end
+    end
+  end
+  assert(#convs == 13, 'expected the 13 VGG-16 convolutions')
+  for i, m in ipairs(convs) do
+    w.conv_w[i - 1] = P(m.weight:view(m.nOutputPlane, m.nInputPlane, 3, 3))
+    w.conv_b[i - 1] = P(m.bias)
+  end
+  -- RPN (LocalizationLayer.lua:609-690): rpn = Sequential{conv, ReLU, ConcatTable{box_branch, rpn_branch}, Flatten}
+  local rpn = ref.nets.localization_layer.nets.rpn
+  local rconv = rpn:get(1)
+  local box_conv = rpn:get(3):get(1):get(1)
+  local score_conv = rpn:get(3):get(2):get(1)
+  w.rpn_conv_w, w.rpn_conv_b = P(rconv.weight), P(rconv.bias)
+  w.rpn_box_w, w.rpn_box_b = P(box_conv.weight), P(box_conv.bias)
+  w.rpn_score_w, w.rpn_score_b = P(score_conv.weight), P(score_conv.bias)
+  local make_anchors = rpn:get(3):get(1):get(3):get(1):get(1)   -- nn.MakeAnchors
+  w.anchors = P(make_anchors.anchors)
+  w.field_centers[0], w.field_centers[1] = make_anchors.x0, make_anchors.y0
+  w.field_centers[2], w.field_centers[3] = make_anchors.sx, make_anchors.sy
+  w.num_anchors = make_anchors.anchors:size(2)
+  w.rpn_hidden = rconv.nOutputPlane
+  -- recog_base = VGG layers 32..38: View, fc6, ReLU, Dropout, fc7, ReLU, Dropout (DenseCapModel.lua:64,90)
+  local fcs = {}
+  for i = 1, #ref.nets.recog_base do
+    local m = ref.nets.recog_base:get(i)
+    if torch.isTypeOf(m, 'nn.Linear') then fcs[#fcs + 1] = m end
+  end
+  w.fc6_w, w.fc6_b, w.fc7_w, w.fc7_b = P(fcs[1].weight), P(fcs[1].bias), P(fcs[2].weight), P(fcs[2].bias)
+  w.obj_w, w.obj_b = P(ref.nets.objectness_branch.weight), P(ref.nets.objectness_branch.bias)
+  w.boxreg_w, w.boxreg_b = P(ref.nets.box_reg_branch.weight), P(ref.nets.box_reg_branch.bias)
+  -- language model (LanguageModel.lua:27-61)
+  local lm = ref.nets.language_model
+  local enc = lm.image_encoder:get(1)
+  w.lm_enc_w, w.lm_enc_b = P(enc.weight), P(enc.bias)
+  w.lm_emb = P(lm.lookup_table.weight)
+  local lstm, out
+  for i = 1, #lm.rnn do
+    local m = lm.rnn:get(i)
+    if torch.isTypeOf(m, 'nn.LSTM') then lstm = m end
+    if torch.isTypeOf(m, 'nn.Linear') then out = m end
+  end
+  w.lstm_w, w.lstm_b = P(lstm.weight), P(lstm.bias)
+  w.lm_out_w, w.lm_out_b = P(out.weight), P(out.bias)
+  w.vocab_size, w.seq_length = lm.vocab_size, lm.seq_length
+  w.enc_size, w.rnn_size, w.fc_dim = lm.input_encoding_size, lm.rnn_size, fcs[2].weight:size(1)
+  hip.check(self.ctx, C.dc_load_weights(self.ctx, w), 'dc_load_weights')
+  keep = nil
+  self.opt = {rpn_nms_thresh = 0.7, final_nms_thresh = 0.3, num_proposals = 300}
+  self.vocab_size, self.seq_length, self.fc_dim = lm.vocab_size, lm.seq_length, fcs[2].weight:size(1)
+  self.idx_to_token = lm.idx_to_token
+  -- keep the reference's field layout for callers that reach into it
+  self.nets = {language_model = {decodeSequence = function(_, seq) return self:decodeSequence(seq) end}}
+  self:setTestArgs{}
+  return self
+end
+
+function Model:setTestArgs(kwargs)
+  for k, v in pairs(kwargs or {}) do self.opt[k] = v end
+  hip.check(self.ctx, C.dc_set_test_args(self.ctx, self.opt.rpn_nms_thresh, self.opt.final_nms_thresh,
+                                         self.opt.num_proposals), 'dc_set_test_args')
+end
+function Model:convert(dtype, use_cudnn) return self end
+function Model:evaluate() return self end
+function Model:type() return self end
+
+function Model:decodeSequence(seq)   -- LanguageModel.lua:86-103
+  local captions = {}
+  local N, T = seq:size(1), seq:size(2)
+  for i = 1, N do
+    local caption = ''
+    for t = 1, T do
+      local idx = seq[{i, t}]
+      if idx == self.vocab_size + 1 or idx == 0 then break end
+      if t > 1 then caption = caption .. ' ' end
+      caption = caption .. self.idx_to_token[idx]
+    end
+    table.insert(captions, caption)
+  end
+  return captions
+end
+
+function Model:forward_test(input)
+  assert(input:dim() == 4 and input:size(1) == 1 and input:size(2) == 3)  -- DenseCapModel.lua:244
+  local img = input:float():contiguous()
+  local H, W, P, T = img:size(3), img:size(4), self.opt.num_proposals, self.seq_length
+  local boxes, scores = torch.FloatTensor(P, 4), torch.FloatTensor(P, 1)
+  local tokens = torch.IntTensor(P, T)
+  local r = ffi.new('dc_result')
+  r.capacity = P
+  r.boxes, r.scores = torch.data(boxes), torch.data(scores)
+  r.tokens = torch.data(tokens)
+  hip.check(self.ctx, C.dc_forward_test(self.ctx, fptr(img), H, W, 0, r), 'dc_forward_test')
+  local K = r.K
+  if K == 0 then return torch.FloatTensor(), torch.FloatTensor(), {} end
+  local seq = tokens[{{1, K}}]:long()
+  return boxes[{{1, K}}]:clone(), scores[{{1, K}}]:clone(), self:decodeSequence(seq)
+end
+
+function Model:extractFeatures(input)
+  local img = input:float():contiguous()
+  local H, W, P = img:size(3), img:size(4), self.opt.num_proposals
+  local boxes, feats = torch.FloatTensor(P, 4), torch.FloatTensor(P, self.fc_dim)
+  local K = ffi.new('int32_t[1]')
+  hip.check(self.ctx, C.dc_extract_features(self.ctx, fptr(img), H, W, 0, P, torch.data(boxes),
+                                            torch.data(feats), K), 'dc_extract_features')
+  return boxes[{{1, K[0]}}]:clone(), feats[{{1, K[0]}}]:clone()
+end
+
+return Model

@@ -1,0 +1,56 @@
+--[[
+LuaJIT FFI binding of libdensecap_hip.so (C ABI: include/densecap.h).
+
+This is the binding a maintainer of jcjohnson/densecap adds next to
+densecap/DenseCapModel.lua.  It needs only LuaJIT (already required by Torch7);
+no cutorch / cunn / cudnn.  NOTE: no Lua runtime exists in the build container,
+so this file is written against the header and reviewed by inspection only; the
+identical ABI is exercised from Python (densecap_amd/_lib.py), which is what
+the parity tests and bench.py execute.
+--]]
+local ffi = require 'ffi'
+
+ffi.cdef[[
+typedef struct dc_ctx dc_ctx;
+typedef struct dc_weights {
+  const float* conv_w[13]; const float* conv_b[13];
+  const float* rpn_conv_w; const float* rpn_conv_b;
+  const float* rpn_box_w;  const float* rpn_box_b;
+  const float* rpn_score_w; const float* rpn_score_b;
+  const float* fc6_w; const float* fc6_b; const float* fc7_w; const float* fc7_b;
+  const float* obj_w; const float* obj_b; const float* boxreg_w; const float* boxreg_b;
+  const float* lm_enc_w; const float* lm_enc_b; const float* lm_emb;
+  const float* lstm_w; const float* lstm_b; const float* lm_out_w; const float* lm_out_b;
+  const float* anchors;
+  float field_centers[4];
+  int32_t num_anchors, rpn_hidden, vocab_size, seq_length, enc_size, rnn_size, fc_dim;
+} dc_weights;
+typedef struct dc_result {
+  int32_t capacity, K, T;
+  float* boxes; float* scores; int32_t* tokens;
+} dc_result;
+int dc_create(dc_ctx** out, int hip_device);
+void dc_destroy(dc_ctx* ctx);
+const char* dc_last_error(const dc_ctx* ctx);
+int dc_load_weights(dc_ctx* ctx, const dc_weights* w);
+int dc_set_test_args(dc_ctx* ctx, float rpn_nms_thresh, float final_nms_thresh, int num_proposals);
+int dc_set_lanes(dc_ctx* ctx, int lanes);
+int dc_forward_test(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_device, dc_result* out);
+int dc_forward_batch(dc_ctx* ctx, const float* imgs, int n, int H, int W, int imgs_on_device, dc_result* outs);
+int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_device,
+                        int capacity, float* boxes, float* feats, int32_t* K);
+int dc_stage_times(dc_ctx* ctx, const char** names, float* ms, int max_stages);
+]]
+
+local M = {}
+M.C = ffi.load(os.getenv('DENSECAP_HIP_LIB') or 'densecap_hip')
+
+function M.check(ctx, rc, what)
+  if rc < 0 then
+    error(string.format('%s failed (%d): %s', what or 'densecap_hip', rc,
+                        ffi.string(M.C.dc_last_error(ctx))))
+  end
+  return rc
+end
+
+return M

@@ -1,0 +1,49 @@
+"""Micro-benchmark of the MFMA contraction kernel on hot-path shapes (run on the GPU box).
+usage: python tools/gemm_bench.py [reps]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
+import numpy as np
+from densecap_amd.ops import Context
+from densecap_amd._lib import check
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+ctx = Context(0)
+lib = ctx.lib
+
+def prof(reset):
+    l = C.c_int64(0); ms = C.c_double(0); fl = C.c_double(0)
+    lib.dc_mfma_profile(ctx.h, reset, C.byref(l), C.byref(ms), C.byref(fl))
+    return l.value, ms.value, fl.value
+
+rng = np.random.default_rng(0)
+def dev_rand(n):
+    return ctx.to_device(rng.standard_normal(n).astype(np.float32))
+
+LIN = [("fc6", 1000, 4096, 25088), ("fc7", 1000, 4096, 4096), ("lm_enc", 1000, 512, 4096),
+       ("gates", 1000, 2048, 512), ("vocab", 1000, 10498, 512), ("rpn_heads", 1710, 72, 256),
+       ("fc6_b32", 9600, 4096, 25088) if len(sys.argv) > 2 else None]
+CONV = [("conv1_2", 600, 720, 64, 64), ("conv2_1", 300, 360, 64, 128), ("conv2_2", 300, 360, 128, 128),
+        ("conv3_1", 150, 180, 128, 256), ("conv3_2", 150, 180, 256, 256), ("conv4_1", 75, 90, 256, 512),
+        ("conv4_2", 75, 90, 512, 512), ("conv5_1", 38, 45, 512, 512), ("rpn_conv", 38, 45, 512, 256)]
+print("%-10s %10s %10s %8s" % ("op", "GFLOP", "us", "TF"))
+for item in LIN:
+    if item is None: continue
+    name, M, N, K = item
+    A = dev_rand(M * K); W = dev_rand(N * K); b = dev_rand(N); Cc = ctx.empty((M, N))
+    check(ctx.h, lib.dc_op_linear(ctx.h, A.ptr, W.ptr, b.ptr, Cc.ptr, M, N, K, 1))
+    prof(1)
+    for _ in range(reps):
+        check(ctx.h, lib.dc_op_linear(ctx.h, A.ptr, W.ptr, b.ptr, Cc.ptr, M, N, K, 1))
+    l, ms, fl = prof(-1)
+    print("%-10s %10.2f %10.1f %8.1f" % (name, fl / l / 1e9, ms / l * 1e3, fl / ms / 1e9))
+    for x in (A, W, b, Cc): x.free()
+for name, H, Wd, Cin, Cout in CONV:
+    A = dev_rand(H * Wd * Cin); W = dev_rand(Cout * 9 * Cin); b = dev_rand(Cout); Cc = ctx.empty((H, Wd, Cout))
+    check(ctx.h, lib.dc_op_conv3x3(ctx.h, A.ptr, W.ptr, b.ptr, Cc.ptr, 1, H, Wd, Cin, Cout, 1))
+    prof(1)
+    for _ in range(reps):
+        check(ctx.h, lib.dc_op_conv3x3(ctx.h, A.ptr, W.ptr, b.ptr, Cc.ptr, 1, H, Wd, Cin, Cout, 1))
+    l, ms, fl = prof(-1)
+    print("%-10s %10.2f %10.1f %8.1f" % (name, fl / l / 1e9, ms / l * 1e3, fl / ms / 1e9))
+    for x in (A, W, b, Cc): x.free()
