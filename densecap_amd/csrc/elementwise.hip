@@ -190,7 +190,7 @@ __global__ void argmax_finalize_kernel(const float* __restrict__ pval, const int
   for (int j = 1; j < ntiles; ++j) {
     const float v = pval[(size_t)m * ld + j];
     const int i = pidx[(size_t)m * ld + j];
-    if (i != 0x7fffffff && (bi == 0x7fffffff || v > best)) { best = v; bi = i; }
+    if (v > best) { best = v; bi = i; }
   }
   tok[m] = bi + 1;
   seq[(size_t)m * T + t] = bi + 1;

@@ -356,47 +356,48 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
   if constexpr (!CONV) {
     if (d.amax_val != nullptr) {
       // ---- fused row arg-max epilogue (vocab projection + torch.max, LanguageModel.lua:326-329) ----
-      // lane -> best over its TN columns; xor-shuffle over the 32 lanes of a half-wave; the two
-      // waves that share rows (wn = 0,1) meet in LDS.  Ties: lower column wins (first max).
+      // The biased tile is transposed through LDS (row stride BN+1: conflict-free column writes),
+      // then two threads scan each row's 2 x BN/2 columns sequentially.  Ties: lower column (first max).
       __syncthreads();                      // everyone is done reading the operand ring
-      float* lv = smem;                     // [2][BM]
-      int* li = reinterpret_cast<int*>(smem + 2 * BM);
+      constexpr int LDT = BN + 1;
+      float* tile = smem;                   // [BM][LDT]
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+      for (int j = 0; j < TN; ++j) {
+        const int cl = wn * 32 * TN + j * 32 + r;
+        const int n = n0 + cl;
+        const float bvv = (d.bias != nullptr && n < d.N) ? d.bias[n] : 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          float bv_ = -INFINITY;
-          int bi_ = 0x7fffffff;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * 32 * TN + j * 32 + r;
-            if (n < d.N) {
-              const float v = acc[i][j][e] + (d.bias ? d.bias[n] : 0.f);
-              if (v > bv_ || (bi_ == 0x7fffffff)) { bv_ = v; bi_ = n; }
-            }
-          }
-#pragma unroll
-          for (int o = 1; o < 32; o <<= 1) {
-            const float ov = __shfl_xor(bv_, o, 64);
-            const int oi = __shfl_xor(bi_, o, 64);
-            if (oi != 0x7fffffff && (bi_ == 0x7fffffff || ov > bv_ || (ov == bv_ && oi < bi_))) { bv_ = ov; bi_ = oi; }
-          }
-          if (r == e) {
+          for (int e = 0; e < 16; ++e) {
             const int row = wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hsel;
-            lv[wn * BM + row] = bv_;
-            li[wn * BM + row] = bi_;
+            tile[row * LDT + cl] = n < d.N ? acc[i][j][e] + bvv : -INFINITY;
           }
-        }
       }
       __syncthreads();
-      if (tid < BM) {
-        const int m = m0 + tid;
-        if (m < d.M) {
-          float v0 = lv[tid], v1 = lv[BM + tid];
-          int i0 = li[tid], i1 = li[BM + tid];
-          if (i1 != 0x7fffffff && (i0 == 0x7fffffff || v1 > v0)) { v0 = v1; i0 = i1; }   // wn=1 has higher columns
-          d.amax_val[(size_t)m * d.amax_ld + tile_n] = v0;
-          d.amax_idx[(size_t)m * d.amax_ld + tile_n] = i0;
+      {
+        constexpr int TPR = 256 / BM;       // threads per row (2 or 4)
+        constexpr int CPT = BN / TPR;       // columns per thread
+        const int row = tid / TPR, part = tid % TPR;
+        const float* p = tile + row * LDT + part * CPT;
+        float best = p[0];
+        int bi = 0;
+#pragma unroll 8
+        for (int c = 1; c < CPT; ++c) {
+          const float v = p[c];
+          if (v > best) { best = v; bi = c; }
+        }
+        bi += n0 + part * CPT;
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) {   // partner threads hold higher columns: strict '>' keeps the first max
+          const float ov = __shfl_xor(best, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        const int m = m0 + row;
+        if (part == 0 && m < d.M) {
+          d.amax_val[(size_t)m * d.amax_ld + tile_n] = best;
+          d.amax_idx[(size_t)m * d.amax_ld + tile_n] = bi;
         }
       }
       return;
