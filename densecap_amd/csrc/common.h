@@ -73,15 +73,24 @@ hipError_t launch_rpn_decode(const float* heads, int h, int w, int k, const floa
                              float sx, float sy, int img_h, int img_w, float* boxes, float* anchors_out,
                              float* trans, float* x1y1x2y2, float* p, uint8_t* valid, hipStream_t s);
 struct NmsWorkspace {
-  // device scratch, sized for n_cap boxes
+  // device scratch, sized for n_cap boxes (see boxes.hip)
   int n_cap = 0;
-  uint32_t* rank = nullptr;       // (n)
+  uint32_t* keys = nullptr;       // (n) order-preserving sort keys
+  int32_t* tmp_idx = nullptr;     // (n) bucketed (unordered inside a bucket) indices
+  uint32_t* tmp_key = nullptr;    // (n) their keys, same order
   int32_t* order = nullptr;       // (n) sorted position -> original index
   float* sboxes = nullptr;        // (n,4) boxes in sorted order
   float* sarea = nullptr;         // (n)
+  int32_t* pick_pos = nullptr;    // (n) sorted positions of the picks so far
+  int32_t* hist = nullptr;        // (NMS_BUCKETS)
+  int32_t* cursor = nullptr;      // (NMS_BUCKETS)
+  int32_t* off = nullptr;         // (NMS_BUCKETS)
+  int32_t* state = nullptr;       // {count, done}
   int32_t* nvalid = nullptr;      // (1)
-  unsigned long long* mask = nullptr;  // (n, nwords)
+  unsigned long long* removed0 = nullptr;  // (1024) bits suppressed by picks of earlier windows
+  unsigned long long* mask = nullptr;      // window bit mask
   size_t mask_words = 0;
+  size_t zero_bytes = 0;          // hist..removed0 are contiguous and zeroed per call
 };
 size_t nms_workspace_bytes(int n);
 hipError_t nms_workspace_bind(NmsWorkspace& ws, void* base, int n);
