@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmDesc d, int ntm, int
 //    fragments of tile t+1 are fetched from LDS while groups 2-3 of tile t execute: the MFMA
 //    pipe never waits for an LDS round trip.
 // =========================================================================================
-template <int TM, int TN, bool CONV>
+template <int TM, int TN, bool CONV, int NS>
 __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int PA = BM / 32, PB = BN / 32;
@@ -266,29 +266,38 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
   }
 
   int tap = 0, c0 = 0;  // conv K-walk
-  // request K-tile `kt` into ring stage `st`
-  auto issue = [&](int kt, int st) {
-    float* sa = smem + st * STAGE + (8 * wid) * BK;       // this wave's 8-row slice of pass 0
-    float* sb = sa + BM * BK;
+  // Request K-tile `kt` into ring stage `st`, one LDS-DMA instruction (1 KiB) per call: piece p in
+  // [0,PA) is an A row-pass, [PA,PA+PB) a B row-pass.  An LDS-DMA instruction occupies the issuing
+  // wave for ~60+ cycles, so the pieces are interleaved 1:1 with MFMAs by the caller.
+  int cv_toff = 0, cv_dy = 0, cv_dx = 0;
+  auto issue_begin = [&]() {
     if constexpr (CONV) {
-      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-      const int toff = ((dy * d.Wd + dx) * d.Cin + c0) * 4;
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        const bool ok = a_ok[i] && (unsigned)(a_y[i] + dy) < (unsigned)d.H && (unsigned)(a_x[i] + dx) < (unsigned)d.Wd;
-        const unsigned vo = ok ? a_off[i] + (unsigned)toff : 0xfffffff0u;   // out of range -> zeros
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, sa + i * 32 * BK, 16, (int)vo, 0, 0, 0);
-      }
+      cv_dy = tap / 3 - 1; cv_dx = tap - (tap / 3) * 3 - 1;
+      cv_toff = ((cv_dy * d.Wd + cv_dx) * d.Cin + c0) * 4;
       c0 += BK;
       if (c0 >= d.Cin) { c0 = 0; ++tap; }
-    } else {
-#pragma unroll
-      for (int i = 0; i < PA; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, sa + i * 32 * BK, 16, (int)a_off[i], kt * (BK * 4), 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < PB; ++i)
+  };
+  auto issue_piece = [&](int kt, int st, int p) {
+    float* sa = smem + st * STAGE + (8 * wid) * BK;       // this wave's 8-row slice of pass 0
+    float* sb = sa + BM * BK;
+    if (p < PA) {
+      if constexpr (CONV) {
+        const bool ok = a_ok[p] && (unsigned)(a_y[p] + cv_dy) < (unsigned)d.H && (unsigned)(a_x[p] + cv_dx) < (unsigned)d.Wd;
+        const unsigned vo = ok ? a_off[p] + (unsigned)cv_toff : 0xfffffff0u;   // out of range -> zeros
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, sa + p * 32 * BK, 16, (int)vo, 0, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, sa + p * 32 * BK, 16, (int)a_off[p], kt * (BK * 4), 0, 0);
+      }
+    } else {
+      const int i = p - PA;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, sb + i * 32 * BK, 16, (int)b_off[i], kt * (BK * 4), 0, 0);
+    }
+  };
+  auto issue = [&](int kt, int st) {
+    issue_begin();
+#pragma unroll
+    for (int p = 0; p < PA + PB; ++p) issue_piece(kt, st, p);
   };
 
   // ---- fragment addressing --------------------------------------------------------------------
@@ -300,12 +309,14 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
   const int b_base = BM * BK + (wn * 32 * TN) * BK;
 
   f32x4 fa[2][TM], fb[2][TN];
-  auto read_frag = [&](int st, int g, int set) {
+  auto read_piece = [&](int st, int g, int set, int p) {   // p in [0,TM): A fragment, [TM,TM+TN): B fragment
     const float* base = smem + st * STAGE + foff[g];
+    if (p < TM) fa[set][p] = *reinterpret_cast<const f32x4*>(base + a_base + p * 32 * BK);
+    else fb[set][p - TM] = *reinterpret_cast<const f32x4*>(base + b_base + (p - TM) * 32 * BK);
+  };
+  auto read_frag = [&](int st, int g, int set) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(base + a_base + i * 32 * BK);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) fb[set][j] = *reinterpret_cast<const f32x4*>(base + b_base + j * 32 * BK);
+    for (int p = 0; p < TM + TN; ++p) read_piece(st, g, set, p);
   };
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -314,19 +325,30 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  auto mfma_group = [&](int set) {
+  constexpr int NM = 4 * TM * TN;        // MFMAs per group
+  auto mfma_slot = [&](int set, int q) {
+    const int e = q / (TM * TN), rem = q % (TM * TN), i = rem / TN, j = rem % TN;
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
+  };
+  // one MFMA group with `nside` side operations spread evenly between its MFMAs (pinned order)
+  auto group_with = [&](int set, int nside, auto&& side) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int q = 0; q < NM; ++q) {
+      mfma_slot(set, q);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
+      for (int k = 0; k < 16; ++k)
+        if (k < nside && (k * NM) / nside == q) {
+          side(k);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
   };
 
   const int nkt = d.K / BK;
-  issue(0, 0);
-  if (nkt > 1) issue(1, 1);
+  // prologue: tiles 0..NS-2 in flight
+#pragma unroll
+  for (int p = 0; p < NS - 1; ++p)
+    if (p < nkt) issue(p, p);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
@@ -334,22 +356,24 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
 
   int st = 0;
   for (int kt = 0; kt < nkt; ++kt) {
-    const int st1 = st == 2 ? 0 : st + 1;
-    const int st2 = st1 == 2 ? 0 : st1 + 1;
-    read_frag(st, 1, 1);
-    mfma_group(0);
-    read_frag(st, 2, 0);
-    mfma_group(1);
-    // ---- mid-tile rendezvous: tile kt+1 has landed everywhere; stage st2 (tile kt-1) is free
+    const int st1 = st == NS - 1 ? 0 : st + 1;
+    const int stn = st == 0 ? NS - 1 : st - 1;     // stage of tile kt-1 == stage of tile kt+NS-1
+    group_with(0, TM + TN, [&](int k) { read_piece(st, 1, 1, k); });
+    group_with(1, TM + TN, [&](int k) { read_piece(st, 2, 0, k); });
+    // ---- mid-tile rendezvous: tile kt+1 has landed everywhere; the stage of tile kt-1 is free
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * (PA + PB)) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 2 < nkt) issue(kt + 2, st2);
-    read_frag(st, 3, 1);
-    mfma_group(0);
-    if (kt + 1 < nkt) read_frag(st1, 0, 0);
-    mfma_group(1);
+    const bool more = kt + NS - 1 < nkt;
+    if (more) issue_begin();
+    // group 2: the PA+PB LDS-DMA pieces of tile kt+NS-1 and the fragment reads of group 3
+    group_with(0, PA + PB + TM + TN, [&](int k) {
+      if (k < PA + PB) { if (more) issue_piece(kt + NS - 1, stn, k); }
+      else read_piece(st, 3, 1, k - (PA + PB));
+    });
+    const bool next = kt + 1 < nkt;
+    group_with(1, TM + TN, [&](int k) { if (next) read_piece(st1, 0, 0, k); });
     st = st1;
   }
 
@@ -438,15 +462,29 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   // v2 addresses operands through 32-bit buffer offsets
   const bool fits = CONV ? ((size_t)d.M * d.Cin * 4 < 0xfffffff0ull) : ((size_t)BM * d.K * 4 < 0xfffffff0ull);
   if ((!use_v1 || d.amax_val != nullptr) && fits && (size_t)BN * d.K * 4 < 0xfffffff0ull) {
-    const size_t lds = (size_t)3 * (BM + BN) * BK * sizeof(float);
+    static const int ns_env = getenv("DENSECAP_GEMM_STAGES") ? atoi(getenv("DENSECAP_GEMM_STAGES")) : 0;
+    const int ns = ns_env == 4 ? 4 : 3;
+    const size_t lds = (size_t)ns * (BM + BN) * BK * sizeof(float);
+    if (ns == 4) {
+      static bool attr4 = false;
+      if (!attr4) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, CONV, 4>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr4 = true;
+      }
+      hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, CONV, 4>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn,
+                         m_fastest);
+      return hipGetLastError();
+    }
     static bool attr2 = false;
     if (!attr2) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, CONV>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, CONV, 3>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       attr2 = true;
     }
-    hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, CONV>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn,
+    hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, CONV, 3>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn,
                        m_fastest);
     return hipGetLastError();
   }
