@@ -179,21 +179,32 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict
   }
 }
 
-// reduce per-N-tile arg-max partials (ascending tile order, strict '>' keeps the first max)
-__global__ void argmax_finalize_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx, int n,
-                                       int ntiles, int ld, int32_t* __restrict__ tok, int32_t* __restrict__ seq,
-                                       int T, int t) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+// reduce per-N-tile arg-max partials: one wave per row, coalesced read of the row's partials; on equal
+// values the lower column wins (first max), which is also the lower tile
+__global__ __launch_bounds__(256) void argmax_finalize_kernel(const float* __restrict__ pval,
+                                                              const int32_t* __restrict__ pidx, int n, int ntiles,
+                                                              int ld, int32_t* __restrict__ tok,
+                                                              int32_t* __restrict__ seq, int T, int t) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (m >= n) return;
-  float best = pval[(size_t)m * ld];
-  int bi = pidx[(size_t)m * ld];
-  for (int j = 1; j < ntiles; ++j) {
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = lane; j < ntiles; j += 64) {
     const float v = pval[(size_t)m * ld + j];
     const int i = pidx[(size_t)m * ld + j];
-    if (v > best) { best = v; bi = i; }
+    if (bi == 0x7fffffff || v > best) { best = v; bi = i; }
   }
-  tok[m] = bi + 1;
-  seq[(size_t)m * T + t] = bi + 1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+  }
+  if (lane == 0) {
+    tok[m] = bi + 1;
+    seq[(size_t)m * T + t] = bi + 1;
+  }
 }
 
 __global__ void fill_i32_kernel(int32_t* p, int32_t v, int n) {
@@ -290,7 +301,7 @@ hipError_t launch_row_argmax(const float* logits, int n, int N, int ld, int32_t*
 }
 hipError_t launch_argmax_finalize(const float* pval, const int32_t* pidx, int n, int ntiles, int ld, int32_t* tok,
                                   int32_t* seq, int T, int t, hipStream_t s) {
-  hipLaunchKernelGGL(argmax_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pval, pidx, n, ntiles, ld, tok,
+  hipLaunchKernelGGL(argmax_finalize_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pval, pidx, n, ntiles, ld, tok,
                      seq, T, t);
   return hipGetLastError();
 }

@@ -15,22 +15,26 @@
 
 namespace {
 
+// One workgroup per box: phase 1 computes the HH*WW sampling positions once (BoxToAffine + grid + floor +
+// weights: ~6 IEEE divisions each) into LDS; phase 2 streams (point, 4-channel) items: four 16-byte taps
+// from the L2-resident map, blend, one 16-byte store.  A point's C channels are 2 KiB contiguous in the
+// output, so every store instruction of a wave writes 1 KiB linearly.
+constexpr int ROI_MAX_PTS = 256;  // phase 1 uses one thread per point
 __global__ __launch_bounds__(256) void bilinear_roi_pool_kernel(const float* __restrict__ feat, int h, int w, int C,
                                                                 const float* __restrict__ boxes, int B,
                                                                 const int32_t* __restrict__ B_dev, float img_h,
                                                                 float img_w, int HH, int WW, float* __restrict__ out,
                                                                 int out_layout) {
+  __shared__ int s_off[ROI_MAX_PTS][4];     // element offset of each tap (or -1 when outside the map)
+  __shared__ float s_w[ROI_MAX_PTS][4];     // w00, w01, w10, w11
   const int C4 = C >> 2;
-  const size_t total = (size_t)B * HH * WW * C4;
+  const int npts = HH * WW;
   const int b_live = B_dev ? min(*B_dev, B) : B;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-    const int c4 = (int)(idx % C4);
-    size_t t = idx / C4;
-    const int j = (int)(t % WW); t /= WW;
-    const int i = (int)(t % HH);
-    const int b = (int)(t / HH);
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (b < b_live) {
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const bool live = b < b_live;
+    __syncthreads();
+    if (live && threadIdx.x < npts) {
+      const int i = threadIdx.x / WW, j = threadIdx.x - i * WW;
       const f32x4 bx = *reinterpret_cast<const f32x4*>(boxes + (size_t)b * 4);
       // BoxToAffine.lua:88-91
       const float th23 = __fdiv_rn(__fadd_rn(__fmul_rn(bx[0], 2.f), -1.f - img_w), img_w - 1.f);
@@ -46,29 +50,48 @@ __global__ __launch_bounds__(256) void bilinear_roi_pool_kernel(const float* __r
       const float xcoord = __fdiv_rn(__fmul_rn(__fadd_rn(gx, 1.f), (float)(w - 1)), 2.f);
       const float ycoord = __fdiv_rn(__fmul_rn(__fadd_rn(gy, 1.f), (float)(h - 1)), 2.f);
       const float xfl = floorf(xcoord), yfl = floorf(ycoord);
-      const int x0 = (int)xfl, y0 = (int)yfl;
+      // clamp before the int cast (far-away boxes): anything outside [-1, dim] is invalid either way
+      const int x0 = (int)fminf(fmaxf(xfl, -2.f), (float)w + 1.f), y0 = (int)fminf(fmaxf(yfl, -2.f), (float)h + 1.f);
       const float wx = __fsub_rn(1.f, __fsub_rn(xcoord, xfl));
       const float wy = __fsub_rn(1.f, __fsub_rn(ycoord, yfl));
       const bool xin0 = x0 >= 0 && x0 <= w - 1, xin1 = x0 + 1 >= 0 && x0 + 1 <= w - 1;
       const bool yin0 = y0 >= 0 && y0 <= h - 1, yin1 = y0 + 1 >= 0 && y0 + 1 <= h - 1;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      const float* fp = feat + (size_t)c4 * 4;
-      const f32x4 tl = (xin0 && yin0) ? *reinterpret_cast<const f32x4*>(fp + ((size_t)y0 * w + x0) * C) : z;
-      const f32x4 tr = (xin1 && yin0) ? *reinterpret_cast<const f32x4*>(fp + ((size_t)y0 * w + x0 + 1) * C) : z;
-      const f32x4 bl = (xin0 && yin1) ? *reinterpret_cast<const f32x4*>(fp + ((size_t)(y0 + 1) * w + x0) * C) : z;
-      const f32x4 br = (xin1 && yin1) ? *reinterpret_cast<const f32x4*>(fp + ((size_t)(y0 + 1) * w + x0 + 1) * C) : z;
-      const float w00 = __fmul_rn(wx, wy), w01 = __fmul_rn(__fsub_rn(1.f, wx), wy);
-      const float w10 = __fmul_rn(wx, __fsub_rn(1.f, wy)), w11 = __fmul_rn(__fsub_rn(1.f, wx), __fsub_rn(1.f, wy));
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        v[e] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w00, tl[e]), __fmul_rn(w01, tr[e])), __fmul_rn(w10, bl[e])),
-                         __fmul_rn(w11, br[e]));
+      const int p = threadIdx.x;
+      s_off[p][0] = (xin0 && yin0) ? (y0 * w + x0) * C : -1;
+      s_off[p][1] = (xin1 && yin0) ? (y0 * w + x0 + 1) * C : -1;
+      s_off[p][2] = (xin0 && yin1) ? ((y0 + 1) * w + x0) * C : -1;
+      s_off[p][3] = (xin1 && yin1) ? ((y0 + 1) * w + x0 + 1) * C : -1;
+      s_w[p][0] = __fmul_rn(wx, wy);
+      s_w[p][1] = __fmul_rn(__fsub_rn(1.f, wx), wy);
+      s_w[p][2] = __fmul_rn(wx, __fsub_rn(1.f, wy));
+      s_w[p][3] = __fmul_rn(__fsub_rn(1.f, wx), __fsub_rn(1.f, wy));
     }
-    if (out_layout == 1) {
-      *reinterpret_cast<f32x4*>(out + idx * 4) = v;
-    } else {
+    __syncthreads();
+    const int items = npts * C4;
+    for (int it = threadIdx.x; it < items; it += 256) {
+      const int p = it / C4, c4 = it - p * C4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (live) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const float* fp = feat + (size_t)c4 * 4;
+        const int o0 = s_off[p][0], o1 = s_off[p][1], o2 = s_off[p][2], o3 = s_off[p][3];
+        const f32x4 tl = o0 >= 0 ? *reinterpret_cast<const f32x4*>(fp + o0) : z;
+        const f32x4 tr = o1 >= 0 ? *reinterpret_cast<const f32x4*>(fp + o1) : z;
+        const f32x4 bl = o2 >= 0 ? *reinterpret_cast<const f32x4*>(fp + o2) : z;
+        const f32x4 br = o3 >= 0 ? *reinterpret_cast<const f32x4*>(fp + o3) : z;
+        const float w00 = s_w[p][0], w01 = s_w[p][1], w10 = s_w[p][2], w11 = s_w[p][3];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) out[(((size_t)b * C + c4 * 4 + e) * HH + i) * WW + j] = v[e];
+        for (int e = 0; e < 4; ++e)
+          v[e] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w00, tl[e]), __fmul_rn(w01, tr[e])), __fmul_rn(w10, bl[e])),
+                           __fmul_rn(w11, br[e]));
+      }
+      if (out_layout == 1) {
+        *reinterpret_cast<f32x4*>(out + ((size_t)b * npts + p) * C + (size_t)c4 * 4) = v;
+      } else {
+        const int i = p / WW, j = p - i * WW;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[(((size_t)b * C + c4 * 4 + e) * HH + i) * WW + j] = v[e];
+      }
     }
   }
 }
@@ -78,10 +101,8 @@ __global__ __launch_bounds__(256) void bilinear_roi_pool_kernel(const float* __r
 hipError_t launch_bilinear_roi_pool(const float* feat_hwc, int h, int w, int C, const float* boxes, int B,
                                     const int32_t* B_dev, int img_h, int img_w, int HH, int WW, float* out,
                                     int out_layout, hipStream_t s) {
-  if (C % 4 || B <= 0) return hipErrorInvalidValue;
-  const size_t total = (size_t)B * HH * WW * (C / 4);
-  size_t grid = (total + 255) / 256;
-  if (grid > 256 * 32) grid = 256 * 32;
+  if (C % 4 || B <= 0 || HH * WW > ROI_MAX_PTS) return hipErrorInvalidValue;
+  const int grid = B < 256 * 16 ? B : 256 * 16;
   hipLaunchKernelGGL(bilinear_roi_pool_kernel, dim3((unsigned)grid), dim3(256), 0, s, feat_hwc, h, w, C, boxes, B,
                      B_dev, (float)img_h, (float)img_w, HH, WW, out, out_layout);
   return hipGetLastError();
