@@ -29,6 +29,8 @@ struct GemmDesc {
   float* amax_val = nullptr;
   int32_t* amax_idx = nullptr;
   int amax_ld = 0;
+  // optional device-side row count: effective M = min(M, *m_dev); workgroups past it exit at once
+  const int32_t* m_dev = nullptr;
 };
 // number of N-tiles launch_mfma_gemm will use for this problem (size of the arg-max partial rows)
 int mfma_gemm_ntiles_n(const GemmDesc& d);
@@ -47,14 +49,15 @@ hipError_t launch_transpose2d(const float* in, float* out, int rows, int cols, h
 // fc6 weight (N, C*HH*WW) with k = c*HW + p  ->  k' = p*C + c
 hipError_t launch_permute_fc6(const float* in, float* out, int N, int C, int HW, hipStream_t s);
 // LSTM pointwise: gates (n,4Hd) [i f o g], c (n,Hd) in/out, h (n,Hd) out
-hipError_t launch_lstm_pointwise(const float* gates, float* c, float* h, int n, int Hd, int zero_c, hipStream_t s);
+hipError_t launch_lstm_pointwise(const float* gates, float* c, float* h, int n, const int32_t* n_dev, int Hd,
+                                  int zero_c, hipStream_t s);
 // row argmax (first max on ties) -> tok (n) 1-based, also seq[m*T + t]
 hipError_t launch_row_argmax(const float* logits, int n, int N, int ld, int32_t* tok, int32_t* seq, int T, int t,
                              hipStream_t s);
 hipError_t launch_fill_i32(int32_t* p, int32_t v, int n, hipStream_t s);
 // reduce the per-N-tile arg-max partials of the fused vocab epilogue: tok[m] = seq[m*T+t] = 1 + argmax
-hipError_t launch_argmax_finalize(const float* pval, const int32_t* pidx, int n, int ntiles, int ld, int32_t* tok,
-                                  int32_t* seq, int T, int t, hipStream_t s);
+hipError_t launch_argmax_finalize(const float* pval, const int32_t* pidx, int n, const int32_t* n_dev, int ntiles,
+                                  int ld, int32_t* tok, int32_t* seq, int T, int t, hipStream_t s);
 // objectness + box regression heads + final ApplyBoxTransform (DenseCapModel.lua:134,139-140)
 hipError_t launch_recog_heads(const float* codes, const float* w5 /*(5,D): obj, 4 boxreg*/, const float* b5,
                               const float* roi_boxes, float* obj, float* trans, float* final_boxes, int n, int D,

@@ -72,6 +72,7 @@ struct dc_ctx {
   bool have_weights = false;
   float rpn_nms_thresh = 0.7f, final_nms_thresh = 0.3f;
   int max_lanes = 3;
+  bool captions_after_final_nms = false;
   int num_proposals = 300;  // LocalizationLayer default (LocalizationLayer.lua:237); run_model sets 1000
   // dims
   int k = 0, R = 0, V = 0, T = 0, E = 0, Hd = 0, D = 0;
@@ -266,30 +267,42 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P) {
     if (_e != hipSuccess) return ctx->fail(DC_E_HIP, "%s: %s", #expr, hipGetErrorString(_e));           \
   } while (0)
 
-// LanguageModel:sample greedy decode (LanguageModel.lua:293-348) for n rows of `codes`.
-int lm_sample(dc_ctx* ctx, Lane& L, const float* codes, int n, int32_t* seq_out) {
+// LanguageModel:sample greedy decode (LanguageModel.lua:293-348) for n rows of `codes` (n_dev: optional
+// device-side row count <= n; rows past it are not computed).
+int lm_sample(dc_ctx* ctx, Lane& L, const float* codes, int n, const int32_t* n_dev, int32_t* seq_out) {
   hipStream_t s = L.stream;
   const int E = ctx->E, Hd = ctx->Hd, V1 = ctx->V + 1, T = ctx->T;
   // image_encoder: Linear(4096,E)+ReLU (:27-30)
-  DCCHK(linear(ctx, s, codes, ctx->enc_w, ctx->enc_b, L.enc, n, E, ctx->D, 1));
+  {
+    GemmDesc g;
+    g.A = codes; g.W = ctx->enc_w; g.bias = ctx->enc_b; g.C = L.enc; g.M = n; g.N = E; g.K = ctx->D; g.ldc = E;
+    g.relu = 1; g.m_dev = n_dev;
+    DCCHK(run_gemm(ctx, g, s));
+  }
   // step 0: gates = (b + enc.Wx) + 0.Wh ; c0 = 0 (output ignored, no vocab projection needed)
-  DCCHK(linear(ctx, s, L.enc, ctx->wxT, ctx->lstm_b, L.gates, n, 4 * Hd, E, 0));
-  KCHK(launch_lstm_pointwise(L.gates, L.cstate, L.hstate, n, Hd, 1, s));
+  {
+    GemmDesc g;
+    g.A = L.enc; g.W = ctx->wxT; g.bias = ctx->lstm_b; g.C = L.gates; g.M = n; g.N = 4 * Hd; g.K = E; g.ldc = 4 * Hd;
+    g.m_dev = n_dev;
+    DCCHK(run_gemm(ctx, g, s));
+  }
+  KCHK(launch_lstm_pointwise(L.gates, L.cstate, L.hstate, n, n_dev, Hd, 1, s));
   KCHK(launch_fill_i32(L.tok, V1, n, s));  // START token = V+1 (:32,320)
   for (int t = 0; t < T; ++t) {
     // gates = (b + Emb[tok].Wx) + h.Wh ; the first term is the precomputed table xg[tok]
     GemmDesc d;
     d.A = L.hstate; d.W = ctx->whT; d.C = L.gates; d.M = n; d.N = 4 * Hd; d.K = Hd; d.ldc = 4 * Hd;
-    d.rowterm = ctx->xg; d.rowidx = L.tok; d.rowterm_ld = 4 * Hd;
+    d.rowterm = ctx->xg; d.rowidx = L.tok; d.rowterm_ld = 4 * Hd; d.m_dev = n_dev;
     DCCHK(run_gemm(ctx, d, s));
-    KCHK(launch_lstm_pointwise(L.gates, L.cstate, L.hstate, n, Hd, 0, s));
+    KCHK(launch_lstm_pointwise(L.gates, L.cstate, L.hstate, n, n_dev, Hd, 0, s));
     {  // vocab projection with the row arg-max fused into the GEMM epilogue: logits never reach HBM
       GemmDesc v;
       v.A = L.hstate; v.W = ctx->out_w; v.bias = ctx->out_b; v.C = nullptr; v.M = n; v.N = V1; v.K = Hd; v.ldc = V1;
+      v.m_dev = n_dev;
       const int ntn = mfma_gemm_ntiles_n(v);
       v.amax_val = L.logits; v.amax_idx = reinterpret_cast<int32_t*>(L.logits + (size_t)n * ntn); v.amax_ld = ntn;
       DCCHK(run_gemm(ctx, v, s));
-      KCHK(launch_argmax_finalize(v.amax_val, v.amax_idx, n, ntn, ntn, L.tok, seq_out, T, t, s));
+      KCHK(launch_argmax_finalize(v.amax_val, v.amax_idx, n, n_dev, ntn, ntn, L.tok, seq_out, T, t, s));
     }
   }
   return DC_OK;
@@ -338,8 +351,9 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int img_on_device, b
   KCHK(launch_recog_heads(L.codes, ctx->head5_w, ctx->head5_b, L.roi_boxes, L.obj, L.final_trans, L.final_boxes, P,
                           ctx->D, s));
   HIPCHK(hipEventRecord(L.ev[6], s));
-  // ---- language model ---------------------------------------------------------------------------
-  if (!features_only) DCCHK(lm_sample(ctx, L, L.codes, P, L.seq));
+  const bool survivors_only = ctx->captions_after_final_nms && !features_only;
+  // ---- language model (reference order: all P proposals, DenseCapModel.lua:127-162) -----------------
+  if (!features_only && !survivors_only) DCCHK(lm_sample(ctx, L, L.codes, P, nullptr, L.seq));
   HIPCHK(hipEventRecord(L.ev[7], s));
   // ---- final NMS + gather (DenseCapModel.lua:261-275) ----------------------------------------------
   KCHK(launch_xcycwh_to_x1y1x2y2(L.final_boxes, L.final_xyxy, P, s));
@@ -351,8 +365,15 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int img_on_device, b
   }
   KCHK(launch_gather_rows(L.final_boxes, L.picks2, L.count2, P, 4, L.out_boxes, s));
   KCHK(launch_gather_rows(L.obj, L.picks2, L.count2, P, 1, L.out_scores, s));
-  if (features_only) KCHK(launch_gather_rows(L.codes, L.picks2, L.count2, P, ctx->D, L.out_feats, s));
-  else KCHK(launch_gather_rows_i32(L.seq, L.picks2, L.count2, P, ctx->T, L.out_tokens, s));
+  if (features_only) {
+    KCHK(launch_gather_rows(L.codes, L.picks2, L.count2, P, ctx->D, L.out_feats, s));
+  } else if (survivors_only) {
+    // identical outputs, less work: LSTM rows are independent, so decode only the rows the final NMS kept
+    KCHK(launch_gather_rows(L.codes, L.picks2, L.count2, P, ctx->D, L.out_feats, s));
+    DCCHK(lm_sample(ctx, L, L.out_feats, P, L.count2, L.out_tokens));
+  } else {
+    KCHK(launch_gather_rows_i32(L.seq, L.picks2, L.count2, P, ctx->T, L.out_tokens, s));
+  }
   HIPCHK(hipEventRecord(L.ev[8], s));
   // ---- results -> pinned host staging ----------------------------------------------------------------
   char* hs = static_cast<char*>(L.host_stage);
@@ -471,6 +492,12 @@ int dc_set_lanes(dc_ctx* ctx, int lanes) {
   if (!ctx) return DC_E_INVALID;
   if (lanes < 1 || lanes > 4) return ctx->fail(DC_E_INVALID, "dc_set_lanes: lanes must be in [1,4]");
   ctx->max_lanes = lanes;
+  return DC_OK;
+}
+
+int dc_set_caption_order(dc_ctx* ctx, int after_final_nms) {
+  if (!ctx) return DC_E_INVALID;
+  ctx->captions_after_final_nms = after_final_nms != 0;
   return DC_OK;
 }
 
@@ -823,7 +850,7 @@ int dc_op_lm_sample(dc_ctx* ctx, const float* codes, int n, int32_t* tokens) {
   L.cstate = (float*)p; p += al((size_t)n * Hd * 4);
   L.logits = (float*)p; p += al((size_t)n * V1 * 4);
   L.tok = (int32_t*)p;
-  int rc = lm_sample(ctx, L, codes, n, tokens);
+  int rc = lm_sample(ctx, L, codes, n, nullptr, tokens);
   hipError_t e2 = hipStreamSynchronize(s);
   L.enc = sv.enc; L.gates = sv.gates; L.hstate = sv.h; L.cstate = sv.c; L.logits = sv.logits; L.tok = sv.tok;
   hipFree(base);

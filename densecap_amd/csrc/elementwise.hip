@@ -138,7 +138,8 @@ __global__ void maxpool2x2_ceil_kernel(const float* __restrict__ in, float* __re
 // ---- LSTM point-wise (torch-rnn nn.LSTM step; gate order i,f,o,g) ----------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 __global__ void lstm_pointwise_kernel(const float* __restrict__ gates, float* __restrict__ c, float* __restrict__ h,
-                                      int n, int Hd, int zero_c) {
+                                      int n, const int32_t* __restrict__ n_dev, int Hd, int zero_c) {
+  if (n_dev) n = min(n, *n_dev);
   const size_t total = (size_t)n * Hd;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t m = i / Hd;
@@ -182,9 +183,11 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict
 // reduce per-N-tile arg-max partials: one wave per row, coalesced read of the row's partials; on equal
 // values the lower column wins (first max), which is also the lower tile
 __global__ __launch_bounds__(256) void argmax_finalize_kernel(const float* __restrict__ pval,
-                                                              const int32_t* __restrict__ pidx, int n, int ntiles,
+                                                              const int32_t* __restrict__ pidx, int n,
+                                                              const int32_t* __restrict__ n_dev, int ntiles,
                                                               int ld, int32_t* __restrict__ tok,
                                                               int32_t* __restrict__ seq, int T, int t) {
+  if (n_dev) n = min(n, *n_dev);
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (m >= n) return;
@@ -289,8 +292,9 @@ hipError_t launch_maxpool2x2_ceil(const float* in, float* out, int nimg, int H, 
                      W, C);
   return hipGetLastError();
 }
-hipError_t launch_lstm_pointwise(const float* gates, float* c, float* h, int n, int Hd, int zero_c, hipStream_t s) {
-  hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(grid_for((size_t)n * Hd)), dim3(256), 0, s, gates, c, h, n, Hd,
+hipError_t launch_lstm_pointwise(const float* gates, float* c, float* h, int n, const int32_t* n_dev, int Hd,
+                                  int zero_c, hipStream_t s) {
+  hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(grid_for((size_t)n * Hd)), dim3(256), 0, s, gates, c, h, n, n_dev, Hd,
                      zero_c);
   return hipGetLastError();
 }
@@ -299,9 +303,9 @@ hipError_t launch_row_argmax(const float* logits, int n, int N, int ld, int32_t*
   hipLaunchKernelGGL(row_argmax_kernel, dim3((n + 3) / 4), dim3(256), 0, s, logits, n, N, ld, tok, seq, T, t);
   return hipGetLastError();
 }
-hipError_t launch_argmax_finalize(const float* pval, const int32_t* pidx, int n, int ntiles, int ld, int32_t* tok,
-                                  int32_t* seq, int T, int t, hipStream_t s) {
-  hipLaunchKernelGGL(argmax_finalize_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pval, pidx, n, ntiles, ld, tok,
+hipError_t launch_argmax_finalize(const float* pval, const int32_t* pidx, int n, const int32_t* n_dev, int ntiles,
+                                  int ld, int32_t* tok, int32_t* seq, int T, int t, hipStream_t s) {
+  hipLaunchKernelGGL(argmax_finalize_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pval, pidx, n, n_dev, ntiles, ld, tok,
                      seq, T, t);
   return hipGetLastError();
 }

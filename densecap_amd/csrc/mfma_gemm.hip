@@ -213,6 +213,11 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
   if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
   else           { tile_n = bid % ntn; tile_m = bid / ntn; }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (d.m_dev != nullptr) {             // device-side row count (e.g. boxes surviving the final NMS)
+    const int me = *d.m_dev;
+    if (me < d.M) d.M = me;
+    if (m0 >= d.M) return;
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -461,7 +466,7 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   static const bool use_v1 = getenv("DENSECAP_GEMM_V1") != nullptr;
   // v2 addresses operands through 32-bit buffer offsets
   const bool fits = CONV ? ((size_t)d.M * d.Cin * 4 < 0xfffffff0ull) : ((size_t)BM * d.K * 4 < 0xfffffff0ull);
-  if ((!use_v1 || d.amax_val != nullptr) && fits && (size_t)BN * d.K * 4 < 0xfffffff0ull) {
+  if ((!use_v1 || d.amax_val != nullptr || d.m_dev != nullptr) && fits && (size_t)BN * d.K * 4 < 0xfffffff0ull) {
     static const int ns_env = getenv("DENSECAP_GEMM_STAGES") ? atoi(getenv("DENSECAP_GEMM_STAGES")) : 0;
     const int ns = ns_env == 4 ? 4 : 3;
     const size_t lds = (size_t)ns * (BM + BN) * BK * sizeof(float);
@@ -488,7 +493,7 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
                        m_fastest);
     return hipGetLastError();
   }
-  if (d.amax_val != nullptr) return hipErrorInvalidValue;  // fused arg-max lives in the v2 kernel only
+  if (d.amax_val != nullptr || d.m_dev != nullptr) return hipErrorInvalidValue;  // v2-only features
   const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -504,6 +509,9 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
 
 template <bool CONV>
 hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
+  static const int tile_env = getenv("DENSECAP_GEMM_TILE") ? atoi(getenv("DENSECAP_GEMM_TILE")) : 0;
+  if (tile_env == 22 && d.N > 64 && d.amax_val == nullptr) return launch_cfg<2, 2, CONV>(d, stream);
+  if (tile_env == 21 && d.amax_val == nullptr) return launch_cfg<2, 1, CONV>(d, stream);
   // Tile choice: largest tile that still yields >= ~1.5 workgroups per CU (256 CUs).
   auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
   if (d.N > 64 && blocks(128, 128) >= 384) return launch_cfg<2, 2, CONV>(d, stream);

@@ -82,6 +82,12 @@ class DenseCapModel:
         check(self.ctx.h, self.lib.dc_set_lanes(self.ctx.h, int(lanes)), "dc_set_lanes")
         return self
 
+    def setCaptionOrder(self, after_final_nms):
+        """False (default): decode all proposals then NMS, as the reference does.  True: final NMS first,
+        decode only the survivors (bit-identical outputs, less LSTM work)."""
+        check(self.ctx.h, self.lib.dc_set_caption_order(self.ctx.h, int(bool(after_final_nms))), "dc_set_caption_order")
+        return self
+
     def convert(self, dtype=None, use_cudnn=None):
         """model:convert(dtype, use_cudnn): the HIP path is always fp32 on the ctx's device."""
         return self

@@ -124,6 +124,11 @@ int dc_forward_batch(dc_ctx* ctx, const float* imgs, int n, int H, int W, int im
 /* Number of lanes (HIP streams with private workspaces, 1..4, default 3) dc_forward_batch
  * pipelines images over.  1 = strictly serial kernels (what per-kernel profiles want). */
 int dc_set_lanes(dc_ctx* ctx, int lanes);
+/* Caption order. 0 (default) = the reference's order: LanguageModel:sample runs on all num_proposals
+ * RoIs and the final NMS then keeps K rows (DenseCapModel.lua:127-162,261-275).  1 = run the final NMS
+ * first and decode only the K surviving rows: LSTM rows are independent, so boxes, scores and tokens
+ * are bit-identical, with ~K/num_proposals of the decode work. */
+int dc_set_caption_order(dc_ctx* ctx, int after_final_nms);
 /* DenseCapModel:extractFeatures (DenseCapModel.lua:285-304): boxes (K,4) and fc7
  * codes (K,fc_dim) after the final NMS; the LSTM decode is skipped. Host outputs. */
 int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_device,

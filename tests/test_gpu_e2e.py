@@ -148,3 +148,46 @@ def test_errors_are_reported_not_thrown(model):
     model.setTestArgs(num_proposals=100)
     with pytest.raises(AssertionError):
         model.forward_raw(np.zeros((1, 4, 64, 64), np.float32))
+
+
+def test_config5_1080x720_2000_proposals(model, weights):
+    """BASELINE.json configs[4]: 1080x720, 2000 proposals (NMS over 36,720 anchors + decode stress)."""
+    r = _check_against_oracle(model, weights, 720, 1080, 2000, seed=5)
+    assert r["K"] > 0
+
+
+def test_config3_batch32_300_proposals(model, weights):
+    """BASELINE.json configs[2]: batch of 32 720x600 images, 300 proposals each, through the lane pipeline.
+    Size-independent properties: every image of the batch equals its single-image run; duplicate images
+    give duplicate results; scores are sorted; token ids are in range."""
+    from densecap_amd.weights import make_synthetic_image
+    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=300)
+    base = [make_synthetic_image(600, 720, s) for s in range(4)]
+    imgs = np.stack([base[i % 4] for i in range(32)])
+    batch = model.forward_batch(imgs)
+    assert len(batch) == 32
+    for i in range(4):
+        b, s, t = model.forward_raw(base[i])
+        for rep in range(i, 32, 4):
+            np.testing.assert_array_equal(batch[rep][0], b)
+            np.testing.assert_array_equal(batch[rep][1], s)
+            np.testing.assert_array_equal(batch[rep][2], t)
+        assert len(b) > 0 and (np.diff(s) <= 0).all()
+        assert t.min() >= 1 and t.max() <= weights["vocab_size"] + 1
+
+
+def test_caption_order_is_output_invariant(model, weights):
+    """dc_set_caption_order(1): final NMS first, decode only the survivors -> bit-identical outputs."""
+    from densecap_amd.weights import make_synthetic_image
+    for (H, W, P, seed) in [(224, 288, 100, 3), (600, 720, 1000, 0)]:
+        model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
+        img = make_synthetic_image(H, W, seed)
+        model.setCaptionOrder(False)
+        b0, s0, t0 = model.forward_raw(img)
+        model.setCaptionOrder(True)
+        b1, s1, t1 = model.forward_raw(img)
+        model.setCaptionOrder(False)
+        np.testing.assert_array_equal(b0, b1)
+        np.testing.assert_array_equal(s0, s1)
+        np.testing.assert_array_equal(t0, t1)
+        assert 0 < len(b0) < P
