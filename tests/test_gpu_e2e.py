@@ -191,3 +191,26 @@ def test_caption_order_is_output_invariant(model, weights):
         np.testing.assert_array_equal(s0, s1)
         np.testing.assert_array_equal(t0, t1)
         assert 0 < len(b0) < P
+
+
+def test_run_model_cli_writes_results_json(tmp_path):
+    """run_model.lua equivalent end to end (BASELINE configs[0] plumbing; synthetic weights: no .t7 offline):
+    image file -> preprocess -> forward_test -> vis/data/results.json schema of run_model.lua:89-95,182-188."""
+    import json
+    from PIL import Image
+    from densecap_amd import run_model as R
+    rng = np.random.default_rng(4)
+    img = rng.uniform(0, 255, (240, 360, 3)).astype(np.uint8)
+    src = tmp_path / "elephant.png"
+    Image.fromarray(img).save(src)
+    out_dir = tmp_path / "vis"
+    rc = R.main(["-input_image", str(src), "-synthetic_weights", "1", "-num_proposals", "50", "-image_size", "360",
+                 "-output_vis_dir", str(out_dir), "-gpu", "0"])
+    assert rc == 0
+    d = json.load(open(out_dir / "results.json"))
+    assert set(d) == {"results", "opt"} and len(d["results"]) == 1
+    r = d["results"][0]
+    assert r["img_name"] == "elephant.png" and set(r) == {"boxes", "scores", "captions", "img_name"}
+    assert len(r["boxes"]) == len(r["scores"]) == len(r["captions"]) > 0 and len(r["boxes"][0]) == 4
+    assert all(a >= b for a, b in zip(r["scores"], r["scores"][1:]))
+    assert d["opt"]["num_proposals"] == 50 and (out_dir / "elephant.png").exists()
