@@ -213,10 +213,11 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
   if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
   else           { tile_n = bid % ntn; tile_m = bid / ntn; }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  int Meff = d.M;
   if (d.m_dev != nullptr) {             // device-side row count (e.g. boxes surviving the final NMS)
     const int me = *d.m_dev;
-    if (me < d.M) d.M = me;
-    if (m0 >= d.M) return;
+    if (me < Meff) Meff = me;
+    if (m0 >= Meff) return;
   }
 
   const int tid = threadIdx.x;
@@ -232,14 +233,14 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
   int a_y[PA], a_x[PA];
   bool a_ok[PA];
   if constexpr (CONV) {
-    const size_t bytes = (size_t)d.M * d.Cin * 4;
+    const size_t bytes = (size_t)Meff * d.Cin * 4;
     rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : bytes), 0x00020000);
     const int hw = d.H * d.Wd;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       int m = m0 + lrow + 32 * i;
-      a_ok[i] = m < d.M;
-      if (m >= d.M) m = d.M - 1;
+      a_ok[i] = m < Meff;
+      if (m >= Meff) m = Meff - 1;
       const int img = m / hw, rem = m - img * hw;
       a_y[i] = rem / d.Wd;
       a_x[i] = rem - a_y[i] * d.Wd;
@@ -247,12 +248,12 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
     }
   } else {
     const float* baseA = d.A + (size_t)m0 * d.K;
-    const size_t bytes = (size_t)(d.M - m0) * d.K * 4;
+    const size_t bytes = (size_t)(Meff - m0) * d.K * 4;
     rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : bytes), 0x00020000);
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       int rr = lrow + 32 * i;
-      if (m0 + rr >= d.M) rr = d.M - 1 - m0;
+      if (m0 + rr >= Meff) rr = Meff - 1 - m0;
       a_off[i] = (unsigned)rr * (unsigned)d.K * 4u + (unsigned)lchunk * 16u;
       a_ok[i] = true; a_y[i] = a_x[i] = 0;
     }
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
           if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
         }
         const int m = m0 + row;
-        if (part == 0 && m < d.M) {
+        if (part == 0 && m < Meff) {
           d.amax_val[(size_t)m * d.amax_ld + tile_n] = best;
           d.amax_idx[(size_t)m * d.amax_ld + tile_n] = bi;
         }
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = mb + (e & 3) + 8 * (e >> 2);
-        if (n_ok && m < d.M) {
+        if (n_ok && m < Meff) {
           float v;
           if (d.rowterm != nullptr) v = d.rowterm[(size_t)(d.rowidx[m] - 1) * d.rowterm_ld + n] + acc[i][j][e];
           else v = acc[i][j][e] + bv;
@@ -458,6 +459,270 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
 }
 
 
+// =========================================================================================
+// K-split variant of the 128x128 tile ("ks"): the four waves do not partition the tile, they partition K.
+//
+// Measured on v2 (profiles/r01_mfma_ablation.md): the fragment ds_read_b128s cost ~11 % of the loop.
+// With 2x2 waves of 64x64 every wave reads (2 A + 2 B) fragments per 16 MFMAs.  Here every wave owns the
+// WHOLE 128x128 tile (16 accumulator tiles = 256 registers; one wave per SIMD may use 512) for one quarter
+// of each K-tile (k = 8w .. 8w+7): (4 A + 4 B) fragments per 64 MFMAs -- half the LDS->VGPR traffic for
+// the same MFMA count.  The four partial tiles are summed once, after the K loop, through LDS
+// (fixed order ((w0+w1)+w2)+w3), one 64x64 quadrant per wave, and leave through the usual epilogue.
+// Because a tile's fragments are read during the previous tile's second half, a 2-stage ring is enough.
+// =========================================================================================
+template <bool CONV>
+__global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
+  constexpr int TM = 2, TN = 2;            // epilogue view: 2x2 waves of 64x64
+  constexpr int BM = 128, BN = 128;
+  constexpr int PA = BM / 32, PB = BN / 32;
+  constexpr int NS = 2;
+  constexpr int STAGE = (BM + BN) * BK;    // floats per ring stage
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int nblk = ntm * ntn;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, rr = nblk & 7, x = bid & 7, o = bid >> 3;
+    bid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + o;
+  }
+  int tile_m, tile_n;
+  if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
+  else           { tile_n = bid % ntn; tile_m = bid / ntn; }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  int Meff = d.M;
+  if (d.m_dev != nullptr) {
+    const int me = *d.m_dev;
+    if (me < Meff) Meff = me;
+    if (m0 >= Meff) return;
+  }
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = tid >> 3;
+  const int lchunk = (tid & 7) ^ ((lrow >> 1) & 7);
+
+  // ---- LDS-DMA descriptors / offsets: identical to v2 (8 pieces per wave per K-tile) ------------------
+  __amdgpu_buffer_rsrc_t rsrcA, rsrcB;
+  unsigned a_off[PA];
+  int a_y[PA], a_x[PA];
+  bool a_ok[PA];
+  if constexpr (CONV) {
+    const size_t bytes = (size_t)Meff * d.Cin * 4;
+    rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : bytes), 0x00020000);
+    const int hw = d.H * d.Wd;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      int m = m0 + lrow + 32 * i;
+      a_ok[i] = m < Meff;
+      if (m >= Meff) m = Meff - 1;
+      const int img = m / hw, rem = m - img * hw;
+      a_y[i] = rem / d.Wd;
+      a_x[i] = rem - a_y[i] * d.Wd;
+      a_off[i] = (unsigned)m * (unsigned)d.Cin * 4u + (unsigned)lchunk * 16u;
+    }
+  } else {
+    const float* baseA = d.A + (size_t)m0 * d.K;
+    const size_t bytes = (size_t)(Meff - m0) * d.K * 4;
+    rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : bytes), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      int rr = lrow + 32 * i;
+      if (m0 + rr >= Meff) rr = Meff - 1 - m0;
+      a_off[i] = (unsigned)rr * (unsigned)d.K * 4u + (unsigned)lchunk * 16u;
+      a_ok[i] = true; a_y[i] = a_x[i] = 0;
+    }
+  }
+  unsigned b_off[PB];
+  {
+    const float* baseB = d.W + (size_t)n0 * d.K;
+    const size_t bytes = (size_t)(d.N - n0) * d.K * 4;
+    rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)baseB, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : bytes), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      int rr = lrow + 32 * i;
+      if (n0 + rr >= d.N) rr = d.N - 1 - n0;
+      b_off[i] = (unsigned)rr * (unsigned)d.K * 4u + (unsigned)lchunk * 16u;
+    }
+  }
+  int tap = 0, c0 = 0;
+  int cv_toff = 0, cv_dy = 0, cv_dx = 0;
+  auto issue_begin = [&]() {
+    if constexpr (CONV) {
+      cv_dy = tap / 3 - 1; cv_dx = tap - (tap / 3) * 3 - 1;
+      cv_toff = ((cv_dy * d.Wd + cv_dx) * d.Cin + c0) * 4;
+      c0 += BK;
+      if (c0 >= d.Cin) { c0 = 0; ++tap; }
+    }
+  };
+  auto issue_piece = [&](int kt, int st, int p) {
+    float* sa = smem + st * STAGE + (8 * wid) * BK;
+    float* sb = sa + BM * BK;
+    if (p < PA) {
+      if constexpr (CONV) {
+        const bool ok = a_ok[p] && (unsigned)(a_y[p] + cv_dy) < (unsigned)d.H && (unsigned)(a_x[p] + cv_dx) < (unsigned)d.Wd;
+        const unsigned vo = ok ? a_off[p] + (unsigned)cv_toff : 0xfffffff0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, sa + p * 32 * BK, 16, (int)vo, 0, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, sa + p * 32 * BK, 16, (int)a_off[p], kt * (BK * 4), 0, 0);
+      }
+    } else {
+      const int i = p - PA;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, sb + i * 32 * BK, 16, (int)b_off[i], kt * (BK * 4), 0, 0);
+    }
+  };
+
+  // ---- fragments: this wave's k-slice (logical chunks 2*wid, 2*wid+1) of all 4+4 row blocks -----------
+  const int r = lane & 31, hsel = lane >> 5;
+  const int foff = r * BK + (((2 * wid + hsel) ^ ((r >> 1) & 7)) << 2);
+  f32x4 fa[2][4], fb[2][4];
+  auto read_piece = [&](int st, int set, int p) {     // p in [0,4): A row block, [4,8): B row block
+    const float* base = smem + st * STAGE + foff;
+    if (p < 4) fa[set][p] = *reinterpret_cast<const f32x4*>(base + p * 32 * BK);
+    else fb[set][p - 4] = *reinterpret_cast<const f32x4*>(base + BM * BK + (p - 4) * 32 * BK);
+  };
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  auto mfma_slot = [&](int set, int q) {               // q in [0,64): e = q/16, (i,j) = q%16
+    const int e = q >> 4, i = (q >> 2) & 3, j = q & 3;
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
+  };
+
+  const int nkt = d.K / BK;
+  issue_begin();
+#pragma unroll
+  for (int p = 0; p < PA + PB; ++p) issue_piece(0, 0, p);
+  if (nkt > 1) {
+    issue_begin();
+#pragma unroll
+    for (int p = 0; p < PA + PB; ++p) issue_piece(1, 1, p);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) read_piece(0, 0, p);
+
+  // one K-tile: 32 MFMAs, rendezvous, 32 MFMAs interleaved with the 8 LDS-DMA pieces of tile kt+2 and the
+  // 8 fragment reads of tile kt+1
+  auto tile_body = [&](int kt, int set) {
+    const int st = kt & 1;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) mfma_slot(set, q);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt+1 landed (issued one tile ago)
+    __builtin_amdgcn_s_barrier();                        // ... everywhere; tile kt's stage is free (already in registers)
+    __builtin_amdgcn_sched_barrier(0);
+    const bool more = kt + 2 < nkt, next = kt + 1 < nkt;
+    if (more) issue_begin();
+#pragma unroll
+    for (int q = 32; q < 64; ++q) {
+      mfma_slot(set, q);
+      const int k = q - 32;
+      if (k < 16 && (k & 1) == 0) {
+        if (more) issue_piece(kt + 2, st, k >> 1);
+        __builtin_amdgcn_sched_barrier(0);
+      } else if (k >= 16 && (k & 1) == 0) {
+        if (next) read_piece(st ^ 1, set ^ 1, (k - 16) >> 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  for (int kt = 0; kt < nkt; kt += 2) {   // nkt is even (launcher guarantees K % 64 == 0): no phi over the 256 accumulators
+    tile_body(kt, 0);
+    tile_body(kt + 1, 1);
+  }
+
+  // ---- cross-wave reduction of the four K-partials + epilogue, one 64x64 quadrant per phase -------------
+  // phase q: every wave stores its partial of quadrant q in MFMA register order (wave w -> slot w, 16 KiB);
+  // then ALL waves sum the four slots (fixed order ((w0+w1)+w2)+w3): wave w' takes register group e4 = w' of
+  // the quadrant's four 32x32 tiles and either stores bias/row-term/ReLU results (128-byte row segments) or,
+  // for the fused arg-max, drops biased logits into an LDS tile that is scanned afterwards.
+  const bool amax = !CONV && d.amax_val != nullptr;
+  constexpr int LDT = BN + 1;
+  float* const slots = smem;                         // [4 waves][4 tiles][4 e4][64 lanes][4]
+  float* const tile = smem + 4 * 4096;               // [BM][LDT] (arg-max only)
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int qi = (q >> 1) * 2, qj = (q & 1) * 2;   // quadrant q = accumulator tiles [qi..qi+1][qj..qj+1]
+    float* slot = slots + wid * 4096;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          f32x4 v = {acc[qi + i][qj + j][e4 * 4 + 0], acc[qi + i][qj + j][e4 * 4 + 1], acc[qi + i][qj + j][e4 * 4 + 2],
+                     acc[qi + i][qj + j][e4 * 4 + 3]};
+          *reinterpret_cast<f32x4*>(slot + ((i * 2 + j) * 4 + e4) * 256 + lane * 4) = v;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int off = ((i * 2 + j) * 4 + wid) * 256 + lane * 4;
+        f32x4 s0 = *reinterpret_cast<const f32x4*>(slots + off);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+          const f32x4 sw = *reinterpret_cast<const f32x4*>(slots + w * 4096 + off);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) s0[c] = s0[c] + sw[c];
+        }
+        // registers e = 4*wid + c of tile (qi+i, qj+j): row = (e&3) + 8*(e>>2) + 4*hsel, col = lane&31
+        const int col_l = (qj + j) * 32 + r;
+        const int n = n0 + col_l;
+        const bool n_ok = n < d.N;
+        const float bv = (d.bias != nullptr && n_ok) ? d.bias[n] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int row_l = (qi + i) * 32 + c + 8 * wid + 4 * hsel;
+          const int m = m0 + row_l;
+          if (amax) {
+            tile[row_l * LDT + col_l] = n_ok ? s0[c] + bv : -INFINITY;
+          } else if (n_ok && m < Meff) {
+            float v;
+            if (d.rowterm != nullptr) v = d.rowterm[(size_t)(d.rowidx[m] - 1) * d.rowterm_ld + n] + s0[c];
+            else v = s0[c] + bv;
+            if (d.relu) v = v > 0.f ? v : 0.f;
+            d.C[(size_t)m * d.ldc + n] = v;
+          }
+        }
+      }
+    __syncthreads();
+  }
+  if (amax) {
+    // fused row arg-max (vocab projection + torch.max, LanguageModel.lua:326-329): two threads per row
+    constexpr int TPR = 256 / BM, CPT = BN / TPR;
+    const int row = tid / TPR, part = tid % TPR;
+    const float* p = tile + row * LDT + part * CPT;
+    float best = p[0];
+    int bi = 0;
+#pragma unroll 8
+    for (int c = 1; c < CPT; ++c) {
+      const float v = p[c];
+      if (v > best) { best = v; bi = c; }
+    }
+    bi += n0 + part * CPT;
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    const int m = m0 + row;
+    if (part == 0 && m < Meff) {
+      d.amax_val[(size_t)m * d.amax_ld + tile_n] = best;
+      d.amax_idx[(size_t)m * d.amax_ld + tile_n] = bi;
+    }
+  }
+}
+
 template <int TM, int TN, bool CONV>
 hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -467,6 +732,23 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   // v2 addresses operands through 32-bit buffer offsets
   const bool fits = CONV ? ((size_t)d.M * d.Cin * 4 < 0xfffffff0ull) : ((size_t)BM * d.K * 4 < 0xfffffff0ull);
   if ((!use_v1 || d.amax_val != nullptr || d.m_dev != nullptr) && fits && (size_t)BN * d.K * 4 < 0xfffffff0ull) {
+    if constexpr (TM == 2 && TN == 2) {
+      static const bool no_ks = getenv("DENSECAP_GEMM_NOKS") != nullptr;
+      if (!no_ks && (d.K % (2 * BK)) == 0 && d.K >= 32 * BK) {   // short K loops do not amortise the 4-phase reduction
+        // 64 KiB operand ring, reused as the 4 x 16 KiB reduction slots; + a 128 x 129 tile for the fused arg-max
+        const size_t lds_ks = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)BM * (BN + 1) * sizeof(float);
+        static bool attrk = false;
+        if (!attrk) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_ks_kernel<CONV>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ks);
+          if (e != hipSuccess) return e;
+          attrk = true;
+        }
+        hipLaunchKernelGGL((mfma_gemm_ks_kernel<CONV>), dim3(ntm * ntn), dim3(256), lds_ks, stream, d, ntm, ntn,
+                           m_fastest);
+        return hipGetLastError();
+      }
+    }
     static const int ns_env = getenv("DENSECAP_GEMM_STAGES") ? atoi(getenv("DENSECAP_GEMM_STAGES")) : 0;
     const int ns = ns_env == 4 ? 4 : 3;
     const size_t lds = (size_t)ns * (BM + BN) * BK * sizeof(float);
