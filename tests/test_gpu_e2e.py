@@ -62,7 +62,7 @@ def _check_against_oracle(model, weights, H, W, P, seed):
     cnt, _ = model.debug_fetch("rpn_nms_count", (1,), np.int32)
     assert cnt[0] == len(st["rpn_nms_idx"])
     same = np.intersect1d(idx[:cnt[0]], st["rpn_nms_idx"]).size / float(cnt[0])
-    assert same >= 0.98, "RPN NMS pick overlap %.4f" % same
+    assert same >= 0.99, "RPN NMS pick overlap %.4f" % same
     # -- final outputs, matched by box identity
     assert abs(len(boxes) - len(oboxes)) <= max(2, len(oboxes) // 50)
     matched = 0
@@ -74,8 +74,8 @@ def _check_against_oracle(model, weights, H, W, P, seed):
             matched += 1
             assert abs(scores[j] - oscores[i]) <= REL * max(1.0, abs(oscores[i])) * 10
             tok_same += int((tokens[j] == oseq[i]).all())
-    assert matched >= 0.95 * len(oboxes), "matched %d of %d final boxes" % (matched, len(oboxes))
-    assert tok_same >= 0.97 * matched, "identical token rows %d of %d" % (tok_same, matched)
+    assert matched >= 0.98 * len(oboxes), "matched %d of %d final boxes" % (matched, len(oboxes))
+    assert tok_same >= 0.98 * matched, "identical token rows %d of %d" % (tok_same, matched)
     # scores are returned in decreasing order (box_utils.nms contract)
     assert (np.diff(scores) <= 0).all()
     return dict(K=len(boxes), K_oracle=len(oboxes), matched=matched, tok_same=tok_same, pick_overlap=same)
