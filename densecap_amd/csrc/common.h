@@ -31,7 +31,16 @@ struct GemmDesc {
   int amax_ld = 0;
   // optional device-side row count: effective M = min(M, *m_dev); workgroups past it exit at once
   const int32_t* m_dev = nullptr;
+  // split-K (K-split 128x128 kernel only): `splitk` workgroups share one tile, each sums a contiguous K range
+  // and writes its raw partial tile to splitk_ws[(slice*M + m)*N + n]; launch_splitk_reduce finishes the job
+  int splitk = 1;
+  float* splitk_ws = nullptr;
 };
+// C = act(sum_s ws[s] + bias): fixed summation order s = 0..S-1
+hipError_t launch_splitk_reduce(const float* ws, int S, const float* bias, float* C, int M, int N, int ldc, int relu,
+                                hipStream_t s);
+// split factor launch_mfma_gemm would like for this problem (1 = none) and the workspace floats it needs
+int mfma_gemm_splitk(const GemmDesc& d);
 // number of N-tiles launch_mfma_gemm will use for this problem (size of the arg-max partial rows)
 int mfma_gemm_ntiles_n(const GemmDesc& d);
 // Launches the fp32 MFMA kernel on `stream`; returns hipSuccess or the launch error.

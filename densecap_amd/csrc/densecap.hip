@@ -49,6 +49,7 @@ struct Lane {
   float *enc = nullptr, *gates = nullptr, *hstate = nullptr, *cstate = nullptr, *logits = nullptr;
   int32_t *tok = nullptr, *seq = nullptr;
   float *out_boxes = nullptr, *out_scores = nullptr, *out_feats = nullptr;
+  float* splitk_ws = nullptr;   // split-K partial tiles (<= 256 tiles of 128x128)
   int32_t* out_tokens = nullptr;
   // pinned host staging
   void* host_stage = nullptr;
@@ -142,18 +143,25 @@ hipEvent_t prof_event(dc_ctx* ctx) {
   return e;
 }
 
-// every MFMA contraction goes through here (optionally bracketed by HIP events)
-int run_gemm(dc_ctx* ctx, const GemmDesc& d, hipStream_t s) {
+// every MFMA contraction goes through here (optionally bracketed by HIP events).  `ws` (optional) is a
+// scratch buffer of ws_floats floats on the same stream: problems with few tiles and a long K are split
+// along K over several workgroups per tile and finished by a small reduce kernel.
+int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, float* ws = nullptr, size_t ws_floats = 0) {
+  GemmDesc d = d_in;
+  const int sp = ws ? mfma_gemm_splitk(d) : 1;
+  const bool split = sp > 1 && (size_t)sp * d.M * d.N <= ws_floats && d.ldc % 4 == 0 && d.N % 4 == 0;
+  if (split) { d.splitk = sp; d.splitk_ws = ws; }
+  ProfEvt pe{nullptr, nullptr, gemm_flops(d)};
   if (ctx->prof) {
-    ProfEvt pe{prof_event(ctx), prof_event(ctx), gemm_flops(d)};
-    hipEventRecord(pe.a, s);
-    hipError_t e = launch_mfma_gemm(d, s);
-    hipEventRecord(pe.b, s);
-    ctx->prof_pending.push_back(pe);
-    if (e != hipSuccess) return ctx->fail(DC_E_HIP, "mfma gemm launch failed: %s", hipGetErrorString(e));
-    return DC_OK;
+    pe.a = prof_event(ctx); pe.b = prof_event(ctx);
+    (void)hipEventRecord(pe.a, s);
   }
   hipError_t e = launch_mfma_gemm(d, s);
+  if (e == hipSuccess && split) e = launch_splitk_reduce(ws, sp, d.bias, d.C, d.M, d.N, d.ldc, d.relu, s);
+  if (ctx->prof) {
+    (void)hipEventRecord(pe.b, s);
+    ctx->prof_pending.push_back(pe);
+  }
   if (e != hipSuccess)
     return ctx->fail(DC_E_HIP, "mfma gemm launch failed: %s (M=%d N=%d K=%d conv=%d)", hipGetErrorString(e), d.M,
                      d.N, d.K, d.conv);
@@ -174,20 +182,21 @@ void prof_collect(dc_ctx* ctx) {
 }
 
 int linear(dc_ctx* ctx, hipStream_t s, const float* A, const float* W, const float* bias, float* C, int M, int N,
-           int K, int relu) {
+           int K, int relu, float* ws = nullptr, size_t ws_floats = 0) {
   GemmDesc d;
   d.A = A; d.W = W; d.bias = bias; d.C = C; d.M = M; d.N = N; d.K = K; d.ldc = N; d.relu = relu;
-  return run_gemm(ctx, d, s);
+  return run_gemm(ctx, d, s, ws, ws_floats);
 }
 int conv3x3(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, const float* b, float* out, int nimg, int H,
-            int W, int Cin, int Cout, int relu) {
+            int W, int Cin, int Cout, int relu, float* ws = nullptr, size_t ws_floats = 0) {
   GemmDesc d;
   d.A = in; d.W = w; d.bias = b; d.C = out; d.M = nimg * H * W; d.N = Cout; d.K = 9 * Cin; d.ldc = Cout;
   d.relu = relu; d.conv = 1; d.H = H; d.Wd = W; d.Cin = Cin;
-  return run_gemm(ctx, d, s);
+  return run_gemm(ctx, d, s, ws, ws_floats);
 }
 
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+constexpr size_t kSplitkWsFloats = (size_t)256 * 128 * 128;   // mfma_gemm_splitk never asks for more
 
 // (Re)build a lane's workspace for image size (H,W) and proposal capacity P.
 int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P) {
@@ -243,6 +252,7 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P) {
       {(void**)&L.out_scores, (size_t)P * 4},
       {(void**)&L.out_tokens, (size_t)P * Tn * 4},
       {(void**)&L.out_feats, (size_t)P * Dm * 4},
+      {(void**)&L.splitk_ws, kSplitkWsFloats * 4},
   };
   size_t total = 0;
   for (auto& c : cv) total += al(c.bytes);
@@ -277,7 +287,7 @@ int lm_sample(dc_ctx* ctx, Lane& L, const float* codes, int n, const int32_t* n_
     GemmDesc g;
     g.A = codes; g.W = ctx->enc_w; g.bias = ctx->enc_b; g.C = L.enc; g.M = n; g.N = E; g.K = ctx->D; g.ldc = E;
     g.relu = 1; g.m_dev = n_dev;
-    DCCHK(run_gemm(ctx, g, s));
+    DCCHK(run_gemm(ctx, g, s, L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0));
   }
   // step 0: gates = (b + enc.Wx) + 0.Wh ; c0 = 0 (output ignored, no vocab projection needed)
   {
@@ -324,13 +334,14 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int img_on_device, b
       h = (h + 1) / 2; w = (w + 1) / 2; cur ^= 1;
     }
     DCCHK(conv3x3(ctx, s, L.act[cur], ctx->conv_w[i], ctx->conv_b[i], L.act[cur ^ 1], 1, h, w, kVgg[i].cin,
-                  kVgg[i].cout, 1));
+                  kVgg[i].cout, 1, L.splitk_ws, kSplitkWsFloats));
     cur ^= 1;
   }
   L.feat = L.act[cur];
   HIPCHK(hipEventRecord(L.ev[1], s));
   // ---- RPN (LocalizationLayer.lua:265, build_rpn :609-690) ----------------------------------
-  DCCHK(conv3x3(ctx, s, L.feat, ctx->rpn_w, ctx->rpn_b, L.rpn_hidden, 1, h, w, 512, ctx->R, 1));
+  DCCHK(conv3x3(ctx, s, L.feat, ctx->rpn_w, ctx->rpn_b, L.rpn_hidden, 1, h, w, 512, ctx->R, 1, L.splitk_ws,
+                kSplitkWsFloats));
   DCCHK(linear(ctx, s, L.rpn_hidden, ctx->heads_w, ctx->heads_b, L.heads, h * w, 6 * ctx->k, ctx->R, 0));
   KCHK(launch_rpn_decode(L.heads, h, w, ctx->k, ctx->anchors, ctx->fc[0], ctx->fc[1], ctx->fc[2], ctx->fc[3], H, W,
                          L.rpn_boxes, nullptr, nullptr, L.rpn_xyxy, L.rpn_p, L.rpn_valid, s));
@@ -344,8 +355,9 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int img_on_device, b
   KCHK(launch_bilinear_roi_pool(L.feat, h, w, 512, L.roi_boxes, P, L.count1, H, W, 7, 7, L.roi_feats, 1, s));
   HIPCHK(hipEventRecord(L.ev[4], s));
   // ---- recog_base fc6/fc7 (DenseCapModel.lua:133) ------------------------------------------------
-  DCCHK(linear(ctx, s, L.roi_feats, ctx->fc6_w, ctx->fc6_b, L.fc6_out, P, ctx->D, 49 * 512, 1));
-  DCCHK(linear(ctx, s, L.fc6_out, ctx->fc7_w, ctx->fc7_b, L.codes, P, ctx->D, ctx->D, 1));
+  DCCHK(linear(ctx, s, L.roi_feats, ctx->fc6_w, ctx->fc6_b, L.fc6_out, P, ctx->D, 49 * 512, 1, L.splitk_ws,
+               kSplitkWsFloats));
+  DCCHK(linear(ctx, s, L.fc6_out, ctx->fc7_w, ctx->fc7_b, L.codes, P, ctx->D, ctx->D, 1, L.splitk_ws, kSplitkWsFloats));
   HIPCHK(hipEventRecord(L.ev[5], s));
   // ---- objectness / box regression / final boxes (DenseCapModel.lua:134,139-140) -----------------
   KCHK(launch_recog_heads(L.codes, ctx->head5_w, ctx->head5_b, L.roi_boxes, L.obj, L.final_trans, L.final_boxes, P,
@@ -763,8 +775,15 @@ int dc_op_conv3x3(dc_ctx* ctx, const float* in, const float* w, const float* b, 
   OP_PROLOGUE();
   if (Cin % 32 || n_img <= 0 || H <= 0 || W <= 0 || Cout <= 0)
     return ctx->fail(DC_E_INVALID, "dc_op_conv3x3: need Cin %% 32 == 0 and positive sizes");
-  DCCHK(conv3x3(ctx, s, in, w, b, out, n_img, H, W, Cin, Cout, relu));
-  OP_EPILOGUE();
+  float* ws = nullptr;
+  HIPCHK(hipMalloc((void**)&ws, kSplitkWsFloats * 4));
+  int rc = conv3x3(ctx, s, in, w, b, out, n_img, H, W, Cin, Cout, relu, ws, kSplitkWsFloats);
+  hipError_t e2 = hipStreamSynchronize(s);
+  (void)hipFree(ws);
+  prof_collect(ctx);
+  if (rc != DC_OK) return rc;
+  if (e2 != hipSuccess) return ctx->fail(DC_E_HIP, "dc_op_conv3x3 sync: %s", hipGetErrorString(e2));
+  return DC_OK;
 }
 int dc_op_conv3x3_c3(dc_ctx* ctx, const float* in, const float* w, const float* b, float* out, int H, int W, int Cout,
                      int relu) {
@@ -780,8 +799,15 @@ int dc_op_linear(dc_ctx* ctx, const float* A, const float* W, const float* bias,
                  int relu) {
   OP_PROLOGUE();
   if (K % 32 || M <= 0 || N <= 0) return ctx->fail(DC_E_INVALID, "dc_op_linear: need K %% 32 == 0");
-  DCCHK(linear(ctx, s, A, W, bias, C, M, N, K, relu));
-  OP_EPILOGUE();
+  float* ws = nullptr;
+  HIPCHK(hipMalloc((void**)&ws, kSplitkWsFloats * 4));
+  int rc = linear(ctx, s, A, W, bias, C, M, N, K, relu, ws, kSplitkWsFloats);
+  hipError_t e2 = hipStreamSynchronize(s);
+  (void)hipFree(ws);
+  prof_collect(ctx);
+  if (rc != DC_OK) return rc;
+  if (e2 != hipSuccess) return ctx->fail(DC_E_HIP, "dc_op_linear sync: %s", hipGetErrorString(e2));
+  return DC_OK;
 }
 int dc_op_make_anchors(dc_ctx* ctx, float* out, int h, int w, float x0, float y0, float sx, float sy,
                        const float* anchors_dev, int k) {

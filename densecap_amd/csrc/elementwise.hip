@@ -210,6 +210,33 @@ __global__ __launch_bounds__(256) void argmax_finalize_kernel(const float* __res
   }
 }
 
+// split-K finish: C = act(sum_s ws[s] + bias), fixed order
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, const float* __restrict__ bias,
+                                     float* __restrict__ C, int M, int N, int ldc, int relu) {
+  const int N4 = N >> 2;
+  const size_t total = (size_t)M * N4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = i / N4;
+    const int n = (int)(i - m * N4) * 4;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(ws + m * N + n);
+    for (int s = 1; s < S; ++s) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ws + ((size_t)s * M + m) * N + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = acc[e] + v[e];
+    }
+    if (bias) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = acc[e] + b[e];
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = acc[e] > 0.f ? acc[e] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(C + m * ldc + n) = acc;
+  }
+}
+
 __global__ void fill_i32_kernel(int32_t* p, int32_t v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -307,6 +334,13 @@ hipError_t launch_argmax_finalize(const float* pval, const int32_t* pidx, int n,
                                   int ld, int32_t* tok, int32_t* seq, int T, int t, hipStream_t s) {
   hipLaunchKernelGGL(argmax_finalize_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pval, pidx, n, n_dev, ntiles, ld, tok,
                      seq, T, t);
+  return hipGetLastError();
+}
+hipError_t launch_splitk_reduce(const float* ws, int S, const float* bias, float* C, int M, int N, int ldc, int relu,
+                                hipStream_t s) {
+  if (N % 4 || ldc % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)M * (N / 4))), dim3(256), 0, s, ws, S, bias, C, M, N, ldc,
+                     relu);
   return hipGetLastError();
 }
 hipError_t launch_fill_i32(int32_t* p, int32_t v, int n, hipStream_t s) {

@@ -479,12 +479,14 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
   constexpr int STAGE = (BM + BN) * BK;    // floats per ring stage
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
-  const int nblk = ntm * ntn;
+  const int nblk = ntm * ntn * d.splitk;
   int bid = blockIdx.x;
   {
     const int q = nblk >> 3, rr = nblk & 7, x = bid & 7, o = bid >> 3;
     bid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + o;
   }
+  const int slice = bid % d.splitk;                  // K slice of this workgroup (split-K), fastest index
+  bid /= d.splitk;
   int tile_m, tile_n;
   if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
   else           { tile_n = bid % ntn; tile_m = bid / ntn; }
@@ -592,14 +594,21 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
   };
 
-  const int nkt = d.K / BK;
+  // this workgroup's K range [kt0, kt0 + nkt) (the whole K unless split-K)
+  const int nkt = d.K / BK / d.splitk;
+  const int kt0 = slice * nkt;
+  if constexpr (CONV) {
+    const int cpt = d.Cin / BK;
+    tap = kt0 / cpt;
+    c0 = (kt0 - tap * cpt) * BK;
+  }
   issue_begin();
 #pragma unroll
-  for (int p = 0; p < PA + PB; ++p) issue_piece(0, 0, p);
+  for (int p = 0; p < PA + PB; ++p) issue_piece(kt0, 0, p);
   if (nkt > 1) {
     issue_begin();
 #pragma unroll
-    for (int p = 0; p < PA + PB; ++p) issue_piece(1, 1, p);
+    for (int p = 0; p < PA + PB; ++p) issue_piece(kt0 + 1, 1, p);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
       mfma_slot(set, q);
       const int k = q - 32;
       if (k < 16 && (k & 1) == 0) {
-        if (more) issue_piece(kt + 2, st, k >> 1);
+        if (more) issue_piece(kt0 + kt + 2, st, k >> 1);
         __builtin_amdgcn_sched_barrier(0);
       } else if (k >= 16 && (k & 1) == 0) {
         if (next) read_piece(st ^ 1, set ^ 1, (k - 16) >> 1);
@@ -685,6 +694,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
           const int m = m0 + row_l;
           if (amax) {
             tile[row_l * LDT + col_l] = n_ok ? s0[c] + bv : -INFINITY;
+          } else if (d.splitk > 1) {
+            if (n_ok && m < Meff) d.splitk_ws[((size_t)slice * d.M + m) * d.N + n] = s0[c];
           } else if (n_ok && m < Meff) {
             float v;
             if (d.rowterm != nullptr) v = d.rowterm[(size_t)(d.rowidx[m] - 1) * d.rowterm_ld + n] + s0[c];
@@ -734,7 +745,7 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   if ((!use_v1 || d.amax_val != nullptr || d.m_dev != nullptr) && fits && (size_t)BN * d.K * 4 < 0xfffffff0ull) {
     if constexpr (TM == 2 && TN == 2) {
       static const bool no_ks = getenv("DENSECAP_GEMM_NOKS") != nullptr;
-      if (!no_ks && (d.K % (2 * BK)) == 0 && d.K >= 32 * BK) {   // short K loops do not amortise the 4-phase reduction
+      if (!no_ks && (d.K % (2 * BK * d.splitk)) == 0 && d.K >= 32 * BK * d.splitk / (d.splitk > 1 ? 2 : 1)) {   // short K loops do not amortise the 4-phase reduction
         // 64 KiB operand ring, reused as the 4 x 16 KiB reduction slots; + a 128 x 129 tile for the fused arg-max
         const size_t lds_ks = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)BM * (BN + 1) * sizeof(float);
         static bool attrk = false;
@@ -744,11 +755,12 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
           if (e != hipSuccess) return e;
           attrk = true;
         }
-        hipLaunchKernelGGL((mfma_gemm_ks_kernel<CONV>), dim3(ntm * ntn), dim3(256), lds_ks, stream, d, ntm, ntn,
+        hipLaunchKernelGGL((mfma_gemm_ks_kernel<CONV>), dim3(ntm * ntn * d.splitk), dim3(256), lds_ks, stream, d, ntm, ntn,
                            m_fastest);
         return hipGetLastError();
       }
     }
+    if (d.splitk > 1) return hipErrorInvalidValue;   // split-K exists only in the K-split kernel
     static const int ns_env = getenv("DENSECAP_GEMM_STAGES") ? atoi(getenv("DENSECAP_GEMM_STAGES")) : 0;
     const int ns = ns_env == 4 ? 4 : 3;
     const size_t lds = (size_t)ns * (BM + BN) * BK * sizeof(float);
@@ -775,7 +787,7 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
                        m_fastest);
     return hipGetLastError();
   }
-  if (d.amax_val != nullptr || d.m_dev != nullptr) return hipErrorInvalidValue;  // v2-only features
+  if (d.amax_val != nullptr || d.m_dev != nullptr || d.splitk > 1) return hipErrorInvalidValue;  // v2/ks-only features
   const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -791,6 +803,7 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
 
 template <bool CONV>
 hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
+  if (d.splitk > 1) return launch_cfg<2, 2, CONV>(d, stream);
   static const int tile_env = getenv("DENSECAP_GEMM_TILE") ? atoi(getenv("DENSECAP_GEMM_TILE")) : 0;
   if (tile_env == 22 && d.N > 64 && d.amax_val == nullptr) return launch_cfg<2, 2, CONV>(d, stream);
   if (tile_env == 21 && d.amax_val == nullptr) return launch_cfg<2, 1, CONV>(d, stream);
@@ -813,6 +826,27 @@ int mfma_gemm_ntiles_n(const GemmDesc& d) {
   else if (d.N > 64 && blocks(128, 128) >= 200 && blocks(128, 128) <= 256) bn = 128;
   else bn = 64;
   return (d.N + bn - 1) / bn;
+}
+
+// Few 128x128 tiles and a long K: split K so that ~224-256 workgroups exist (one round on 256 CUs).  Every slice
+// keeps an even number (>= 16) of K-tiles for the K-split kernel.
+int mfma_gemm_splitk(const GemmDesc& d) {
+  static const bool off = getenv("DENSECAP_GEMM_NOSPLITK") != nullptr || getenv("DENSECAP_GEMM_NOKS") != nullptr ||
+                          getenv("DENSECAP_GEMM_V1") != nullptr || getenv("DENSECAP_GEMM_TILE") != nullptr;
+  if ((size_t)128 * d.K * 4 >= 0xfffffff0ull || (d.conv && (size_t)d.M * d.Cin * 4 >= 0xfffffff0ull)) return 1;
+  if (off || d.amax_val != nullptr || d.rowterm != nullptr || d.m_dev != nullptr) return 1;
+  const long tiles = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
+  if (tiles >= 128 || d.N < 128) return 1;
+  const int nkt = d.K / BK;
+  int best = 1;
+  for (int sp = 2; sp <= 16; ++sp) {
+    if (tiles * sp > 256) break;
+    if (nkt % sp) continue;
+    const int per = nkt / sp;
+    if ((per & 1) || per < 16) continue;
+    best = sp;
+  }
+  return best;
 }
 
 double gemm_flops(const GemmDesc& d) { return 2.0 * (double)d.M * (double)d.N * (double)d.K; }
