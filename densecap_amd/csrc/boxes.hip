@@ -445,8 +445,7 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const u64* __restrict__ m
       }
       if ((al >> lane) & 1ull) {
         const int pos = __builtin_popcountll(al & ((1ull << lane) - 1ull));
-        picks[cnt + pos] = order[row];
-        pick_pos[cnt + pos] = row;
+        pick_pos[cnt + pos] = row;           // original indices are written once, after the loop
         s_rows[pos] = row - r0;
       }
       if (lane == 0) {
@@ -469,6 +468,11 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const u64* __restrict__ m
     }
     __syncthreads();
   }
+  // picks of this window: sorted position -> original index, off the per-chunk critical path
+  __syncthreads();
+  const int c_begin = st->count, c_end = s_cnt;
+  for (int i = c_begin + tid; i < c_end; i += 256) picks[i] = order[pick_pos[i]];
+  __syncthreads();
   if (tid == 0) {
     st->count = s_cnt;
     if (full || n >= ntot) { st->done = 1; *count_out = s_cnt; }
