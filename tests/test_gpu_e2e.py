@@ -214,3 +214,17 @@ def test_run_model_cli_writes_results_json(tmp_path):
     assert len(r["boxes"]) == len(r["scores"]) == len(r["captions"]) > 0 and len(r["boxes"][0]) == 4
     assert all(a >= b for a, b in zip(r["scores"], r["scores"][1:]))
     assert d["opt"]["num_proposals"] == 50 and (out_dir / "elephant.png").exists()
+
+
+def test_edge_shapes_do_not_break(model, weights):
+    """Tiny images (2x2 feature map), more proposals requested than anchors exist, non-multiple-of-16 sizes."""
+    from densecap_amd.weights import make_synthetic_image
+    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=50)
+    b, s, t = model.forward_raw(make_synthetic_image(48, 64, 1))
+    assert 0 < len(b) <= 50 and t.shape == (len(b), 15) and np.isfinite(b).all() and np.isfinite(s).all()
+    model.setTestArgs(num_proposals=5000)                     # 96x128 -> 6x8 map -> 576 anchors < 5000
+    b, s, t = model.forward_raw(make_synthetic_image(96, 128, 2))
+    assert 0 < len(b) <= 576 and (np.diff(s) <= 0).all()
+    model.setTestArgs(num_proposals=64)
+    b, s, t = model.forward_raw(make_synthetic_image(203, 301, 3))   # odd sizes: ceil-mode pooling everywhere
+    assert 0 < len(b) <= 64 and t.min() >= 1
