@@ -35,12 +35,22 @@ struct GemmDesc {
   // and writes its raw partial tile to splitk_ws[(slice*M + m)*N + n]; launch_splitk_reduce finishes the job
   int splitk = 1;
   float* splitk_ws = nullptr;
+  // row window (K-split kernel only): tiles cover rows [m_begin, M); a_rows = rows of the whole A operand
+  // (extent of the conv input for the buffer descriptor) when M is only a prefix, 0 = M
+  int m_begin = 0;
+  int a_rows = 0;
 };
 // C = act(sum_s ws[s] + bias): fixed summation order s = 0..S-1
 hipError_t launch_splitk_reduce(const float* ws, int S, const float* bias, float* C, int M, int N, int ldc, int relu,
                                 hipStream_t s);
-// split factor launch_mfma_gemm would like for this problem (1 = none) and the workspace floats it needs
+// split factor launch_mfma_gemm would like for this problem (1 = none)
 int mfma_gemm_splitk(const GemmDesc& d);
+// Tail plan for problems whose 128x128 tile count is not a multiple of the 256 CUs: rows [0, m_split) run as
+// whole tiles (full rounds), rows [m_split, M) are split `tail_splitk` ways along K so the last partial round
+// fills the chip.  Returns false when it does not pay.
+bool mfma_gemm_tail_plan(const GemmDesc& d, int* m_split, int* tail_splitk);
+// force the K-split 128x128 kernel (honours m_begin / a_rows / splitk)
+hipError_t launch_mfma_gemm_ks(const GemmDesc& d, hipStream_t stream);
 // number of N-tiles launch_mfma_gemm will use for this problem (size of the arg-max partial rows)
 int mfma_gemm_ntiles_n(const GemmDesc& d);
 // Launches the fp32 MFMA kernel on `stream`; returns hipSuccess or the launch error.

@@ -74,6 +74,7 @@ struct dc_ctx {
   float rpn_nms_thresh = 0.7f, final_nms_thresh = 0.3f;
   int max_lanes = 3;
   bool captions_after_final_nms = false;
+  bool serial_mode = true;   // one image in flight: idle CUs in a layer's last round are worth a tail split-K
   int num_proposals = 300;  // LocalizationLayer default (LocalizationLayer.lua:237); run_model sets 1000
   // dims
   int k = 0, R = 0, V = 0, T = 0, E = 0, Hd = 0, D = 0;
@@ -148,16 +149,38 @@ hipEvent_t prof_event(dc_ctx* ctx) {
 // along K over several workgroups per tile and finished by a small reduce kernel.
 int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, float* ws = nullptr, size_t ws_floats = 0) {
   GemmDesc d = d_in;
-  const int sp = ws ? mfma_gemm_splitk(d) : 1;
-  const bool split = sp > 1 && (size_t)sp * d.M * d.N <= ws_floats && d.ldc % 4 == 0 && d.N % 4 == 0;
-  if (split) { d.splitk = sp; d.splitk_ws = ws; }
   ProfEvt pe{nullptr, nullptr, gemm_flops(d)};
   if (ctx->prof) {
     pe.a = prof_event(ctx); pe.b = prof_event(ctx);
     (void)hipEventRecord(pe.a, s);
   }
-  hipError_t e = launch_mfma_gemm(d, s);
-  if (e == hipSuccess && split) e = launch_splitk_reduce(ws, sp, d.bias, d.C, d.M, d.N, d.ldc, d.relu, s);
+  hipError_t e = hipSuccess;
+  const bool ws_ok = ws != nullptr && d.ldc % 4 == 0 && d.N % 4 == 0;
+  int m_split = 0, tail_sp = 1;
+  const int sp = ws_ok ? mfma_gemm_splitk(d) : 1;
+  if (sp > 1 && (size_t)sp * d.M * d.N <= ws_floats) {
+    // few tiles, long K: every tile is shared by `sp` workgroups
+    d.splitk = sp; d.splitk_ws = ws;
+    e = launch_mfma_gemm(d, s);
+    if (e == hipSuccess) e = launch_splitk_reduce(ws, sp, d.bias, d.C, d.M, d.N, d.ldc, d.relu, s);
+  } else if (ws_ok && ctx->serial_mode && mfma_gemm_tail_plan(d, &m_split, &tail_sp) &&
+             (size_t)tail_sp * (d.M - m_split) * d.N <= ws_floats) {
+    // tile count not a multiple of the CU count: whole tiles for the full rounds, K-split for the last one
+    if (m_split > 0) {
+      GemmDesc a = d;
+      a.M = m_split; a.a_rows = d.M;
+      e = launch_mfma_gemm_ks(a, s);
+    }
+    if (e == hipSuccess) {
+      GemmDesc b = d;
+      b.m_begin = m_split; b.a_rows = d.M; b.splitk = tail_sp; b.splitk_ws = ws;
+      e = launch_mfma_gemm_ks(b, s);
+      if (e == hipSuccess)
+        e = launch_splitk_reduce(ws, tail_sp, d.bias, d.C + (size_t)m_split * d.ldc, d.M - m_split, d.N, d.ldc, d.relu, s);
+    }
+  } else {
+    e = launch_mfma_gemm(d, s);
+  }
   if (ctx->prof) {
     (void)hipEventRecord(pe.b, s);
     ctx->prof_pending.push_back(pe);
@@ -196,7 +219,7 @@ int conv3x3(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, const f
 }
 
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
-constexpr size_t kSplitkWsFloats = (size_t)256 * 128 * 128;   // mfma_gemm_splitk never asks for more
+constexpr size_t kSplitkWsFloats = (size_t)640 * 128 * 128;   // 40 MiB: split-K (<= 256 tiles) and tail plans (<= 3 x ~200 tiles)
 
 // (Re)build a lane's workspace for image size (H,W) and proposal capacity P.
 int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P) {
@@ -622,6 +645,7 @@ static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, i
   for (int i = 0; i < n; ++i)
     if (outs[i].capacity <= 0) return ctx->fail(DC_E_INVALID, "dc_result.capacity must be > 0");
   const int nl = std::min(n, ctx->max_lanes);
+  ctx->serial_mode = nl == 1;   // with several images in flight the other lanes fill a layer's last round
   while ((int)ctx->lanes.size() < nl) ctx->lanes.emplace_back(new Lane());
   for (int l = 0; l < nl; ++l) DCCHK(lane_prepare(ctx, *ctx->lanes[l], H, W, P));
   const size_t img_elems = (size_t)3 * H * W;

@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
   int tile_m, tile_n;
   if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
   else           { tile_n = bid % ntn; tile_m = bid / ntn; }
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = d.m_begin + tile_m * BM, n0 = tile_n * BN;
   int Meff = d.M;
   if (d.m_dev != nullptr) {
     const int me = *d.m_dev;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
   int a_y[PA], a_x[PA];
   bool a_ok[PA];
   if constexpr (CONV) {
-    const size_t bytes = (size_t)Meff * d.Cin * 4;
+    const size_t bytes = (size_t)(d.a_rows ? d.a_rows : d.M) * d.Cin * 4;
     rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : bytes), 0x00020000);
     const int hw = d.H * d.Wd;
 #pragma unroll
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
           if (amax) {
             tile[row_l * LDT + col_l] = n_ok ? s0[c] + bv : -INFINITY;
           } else if (d.splitk > 1) {
-            if (n_ok && m < Meff) d.splitk_ws[((size_t)slice * d.M + m) * d.N + n] = s0[c];
+            if (n_ok && m < Meff) d.splitk_ws[((size_t)slice * (d.M - d.m_begin) + (m - d.m_begin)) * d.N + n] = s0[c];
           } else if (n_ok && m < Meff) {
             float v;
             if (d.rowterm != nullptr) v = d.rowterm[(size_t)(d.rowidx[m] - 1) * d.rowterm_ld + n] + s0[c];
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
 template <int TM, int TN, bool CONV>
 hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
-  const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+  const int ntm = (d.M - d.m_begin + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
   const int m_fastest = ntm <= ntn ? 1 : 0;
   static const bool use_v1 = getenv("DENSECAP_GEMM_V1") != nullptr;
   // v2 addresses operands through 32-bit buffer offsets
@@ -745,7 +745,8 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   if ((!use_v1 || d.amax_val != nullptr || d.m_dev != nullptr) && fits && (size_t)BN * d.K * 4 < 0xfffffff0ull) {
     if constexpr (TM == 2 && TN == 2) {
       static const bool no_ks = getenv("DENSECAP_GEMM_NOKS") != nullptr;
-      if (!no_ks && (d.K % (2 * BK * d.splitk)) == 0 && d.K >= 32 * BK * d.splitk / (d.splitk > 1 ? 2 : 1)) {   // short K loops do not amortise the 4-phase reduction
+      const bool forced = d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0;
+      if (!no_ks && (d.K % (2 * BK * d.splitk)) == 0 && (forced || d.K >= 32 * BK)) {   // short K loops do not amortise the 4-phase reduction
         // 64 KiB operand ring, reused as the 4 x 16 KiB reduction slots; + a 128 x 129 tile for the fused arg-max
         const size_t lds_ks = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)BM * (BN + 1) * sizeof(float);
         static bool attrk = false;
@@ -760,7 +761,7 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
         return hipGetLastError();
       }
     }
-    if (d.splitk > 1) return hipErrorInvalidValue;   // split-K exists only in the K-split kernel
+    if (d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0) return hipErrorInvalidValue;   // K-split kernel features
     static const int ns_env = getenv("DENSECAP_GEMM_STAGES") ? atoi(getenv("DENSECAP_GEMM_STAGES")) : 0;
     const int ns = ns_env == 4 ? 4 : 3;
     const size_t lds = (size_t)ns * (BM + BN) * BK * sizeof(float);
@@ -847,6 +848,49 @@ int mfma_gemm_splitk(const GemmDesc& d) {
     best = sp;
   }
   return best;
+}
+
+// 4096 cycles per K-tile at ~2.1 GHz: the unit of the tail cost model below
+static const double kUsPerKtile = 1.95;
+bool mfma_gemm_tail_plan(const GemmDesc& d, int* m_split, int* tail_splitk) {
+  static const bool off = getenv("DENSECAP_GEMM_NOTAIL") != nullptr || getenv("DENSECAP_GEMM_NOSPLITK") != nullptr ||
+                          getenv("DENSECAP_GEMM_NOKS") != nullptr || getenv("DENSECAP_GEMM_V1") != nullptr ||
+                          getenv("DENSECAP_GEMM_TILE") != nullptr || getenv("DENSECAP_GEMM_V2") != nullptr;
+  if (off || d.amax_val != nullptr || d.rowterm != nullptr || d.m_dev != nullptr || d.N < 128 || d.N % 4) return false;
+  if ((size_t)128 * d.K * 4 >= 0xfffffff0ull || (d.conv && (size_t)d.M * d.Cin * 4 >= 0xfffffff0ull)) return false;
+  const int ntm = (d.M + 127) / 128, ntn = (d.N + 127) / 128, nkt = d.K / BK;
+  if ((nkt & 1) || nkt < 16 || 256 % ntn) return false;
+  const long T = (long)ntm * ntn;
+  if (T < 128) return false;                        // few tiles: plain split-K (mfma_gemm_splitk) handles it
+  const long rounds = T / 256, r = T % 256;
+  if (r == 0) return false;
+  const double t_tile = nkt * kUsPerKtile;
+  const double base = t_tile;                       // the partial round as whole tiles
+  double best = base;
+  int best_s = 1;
+  for (int sp = 2; sp <= 8; ++sp) {
+    if (nkt % sp) continue;
+    const int per = nkt / sp;
+    if ((per & 1) || per < 6) continue;
+    const long units = r * sp;
+    const double t = (double)((units + 255) / 256) * per * kUsPerKtile          // K loops
+                     + (double)((units + 255) / 256) * 4.0                       // per-round prologue + 4-phase reduction
+                     + (double)(sp + 1) * r * 65536.0 / 4.0e6 + 6.0;             // partial tiles through HBM + reduce launch
+    if (t < best) { best = t; best_s = sp; }
+  }
+  if (best_s == 1 || best > 0.93 * base) return false;
+  *m_split = (int)(rounds * 256 / ntn) * 128;       // rows covered by the full rounds (whole row-tiles: ntn | 256)
+  *tail_splitk = best_s;
+  return true;
+}
+
+hipError_t launch_mfma_gemm_ks(const GemmDesc& d, hipStream_t stream) {
+  if (d.M - d.m_begin <= 0 || d.N <= 0 || d.K <= 0 || (d.K % (2 * BK * d.splitk)) != 0) return hipErrorInvalidValue;
+  if (d.conv) {
+    if (d.Cin % BK != 0 || d.K != 9 * d.Cin) return hipErrorInvalidValue;
+    return launch_cfg<2, 2, true>(d, stream);
+  }
+  return launch_cfg<2, 2, false>(d, stream);
 }
 
 double gemm_flops(const GemmDesc& d) { return 2.0 * (double)d.M * (double)d.N * (double)d.K; }

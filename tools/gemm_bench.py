@@ -22,6 +22,7 @@ def dev_rand(n):
 
 LIN = [("fc6", 1000, 4096, 25088), ("fc7", 1000, 4096, 4096), ("lm_enc", 1000, 512, 4096),
        ("gates", 1000, 2048, 512), ("vocab", 1000, 10498, 512), ("rpn_heads", 1710, 72, 256),
+       ("dense_c3_2", 27000, 256, 2304), ("dense_c4_2", 6750, 512, 4608), ("dense_c2_2", 108000, 128, 1152),
        ("fc6_b32", 9600, 4096, 25088) if len(sys.argv) > 2 else None]
 CONV = [("conv1_2", 600, 720, 64, 64), ("conv2_1", 300, 360, 64, 128), ("conv2_2", 300, 360, 128, 128),
         ("conv3_1", 150, 180, 128, 256), ("conv3_2", 150, 180, 256, 256), ("conv4_1", 75, 90, 256, 512),
