@@ -1,0 +1,103 @@
+"""webcam/daemon.lua on the MI355X path (the second caller of the boundary).
+
+File-drop protocol of the reference (webcam/daemon.lua:55-102): poll `-input_dir` for `*.jpg`, run
+forward_test, rescale boxes to the ORIGINAL image size (`box_utils.scale_boxes_xywh`, box_utils.lua:459-467),
+write `<id>.json` {boxes, captions, height, width} to `-output_dir`, delete the input; sleep 50 ms.
+
+    python -m densecap_amd.daemon -input_dir webcam/inputs -output_dir webcam/outputs -synthetic_weights 1
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+from .run_model import load_image_caffe, xcycwh_to_xywh
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prefix_chars="-", description=__doc__,
+                                formatter_class=argparse.RawDescriptionHelpFormatter)
+    a = p.add_argument
+    a("-checkpoint", default="data/models/densecap/densecap-pretrained-vgg16.t7")
+    a("-max_image_size", type=int, default=720)
+    a("-input_dir", default="webcam/inputs")
+    a("-input_ext", default=".jpg")
+    a("-output_dir", default="webcam/outputs")
+    a("-rpn_nms_thresh", type=float, default=0.7)
+    a("-final_nms_thresh", type=float, default=0.3)
+    a("-num_proposals", type=int, default=1000)
+    a("-gpu", type=int, default=0)
+    a("-synthetic_weights", type=int, default=0)
+    a("-max_polls", type=int, default=-1, help="stop after this many directory polls (-1 = forever)")
+    return p
+
+
+def scale_boxes_xywh(boxes, frac):
+    """box_utils.scale_boxes_xywh (box_utils.lua:459-467): 1-based -> 0-based, scale, back to 1-based."""
+    b = np.array(boxes, dtype=np.float32, copy=True).reshape(-1, 4)
+    b[:, :2] -= np.float32(1)
+    b *= np.float32(frac)
+    b[:, :2] += np.float32(1)
+    return b
+
+
+def process_file(model, in_path, out_path, max_image_size):
+    """One iteration of daemon.lua:57-100.  Returns True if an output was written."""
+    from PIL import Image
+    try:
+        with Image.open(in_path) as im:
+            ori_w, ori_h = im.size
+        img_caffe, _ = load_image_caffe(in_path, max_image_size)
+    except Exception:                                 # pcall(image.load) failed: leave the file, try again later
+        return False
+    H = img_caffe.shape[2]
+    boxes, _scores, captions = model.forward_test(img_caffe)
+    boxes_xywh = scale_boxes_xywh(xcycwh_to_xywh(boxes), float(ori_h) / H)
+    out = dict(boxes=[[float(v) for v in r] for r in boxes_xywh], captions=list(captions), height=ori_h, width=ori_w)
+    os.remove(in_path)
+    tmp = out_path + ".tmp"
+    with open(tmp, "w") as f:
+        json.dump(out, f)
+    os.replace(tmp, out_path)
+    return True
+
+
+def serve(model, opt):
+    polls = 0
+    os.makedirs(opt.output_dir, exist_ok=True)
+    while opt.max_polls < 0 or polls < opt.max_polls:
+        for fn in sorted(os.listdir(opt.input_dir)):
+            if not fn.endswith(opt.input_ext):
+                continue
+            in_path = os.path.join(opt.input_dir, fn)
+            out_path = os.path.join(opt.output_dir, fn[:-len(opt.input_ext)] + ".json")
+            print("Running model on image " + in_path)
+            process_file(model, in_path, out_path, opt.max_image_size)
+        polls += 1
+        time.sleep(0.05)
+
+
+def main(argv=None):
+    opt = build_parser().parse_args(argv)
+    from . import DenseCapModel
+    if opt.synthetic_weights:
+        from .weights import make_synthetic_weights
+        weights = make_synthetic_weights()
+    else:
+        from . import t7
+        weights = t7.weights_from_checkpoint(t7.load(opt.checkpoint))
+    model = DenseCapModel(weights, device=opt.gpu)
+    model.evaluate()
+    model.setTestArgs(num_proposals=opt.num_proposals, rpn_nms_thresh=opt.rpn_nms_thresh,
+                      final_nms_thresh=opt.final_nms_thresh)
+    serve(model, opt)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

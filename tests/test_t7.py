@@ -62,3 +62,28 @@ def test_run_model_preprocessing_and_json(tmp_path):
     assert j == {"boxes": [[8.0, 17.0, 5.0, 7.0]], "scores": [0.5], "captions": ["a cat"]}
     opt = R.build_parser().parse_args(["-input_image", "x.jpg", "-num_proposals", "300"])
     assert opt.rpn_nms_thresh == 0.7 and opt.final_nms_thresh == 0.3 and opt.num_proposals == 300
+
+
+def test_daemon_protocol_with_fake_model(tmp_path):
+    """webcam/daemon.lua:55-102 host protocol: input consumed, <id>.json with boxes rescaled to the original size."""
+    import json
+    from PIL import Image
+    from densecap_amd import daemon as D
+
+    class FakeModel:
+        def forward_test(self, img):
+            assert img.shape == (1, 3, 360, 720)          # 1440x720 image scaled to max side 720
+            return np.array([[10.5, 20.5, 4.0, 6.0]], np.float32), np.array([[1.0]], np.float32), ["a dog"]
+
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    Image.fromarray(np.zeros((720, 1440, 3), np.uint8)).save(ind / "frame7.jpg")
+    (ind / "broken.jpg").write_bytes(b"not a jpeg")
+    opt = D.build_parser().parse_args(["-input_dir", str(ind), "-output_dir", str(outd), "-max_polls", "1"])
+    D.serve(FakeModel(), opt)
+    out = json.load(open(outd / "frame7.json"))
+    assert out["height"] == 720 and out["width"] == 1440 and out["captions"] == ["a dog"]
+    # xywh = (9, 18, 4, 6) in the 360-high frame -> x2 back to the original: ((9-1)*2+1, (18-1)*2+1, 8, 12)
+    np.testing.assert_allclose(out["boxes"], [[17.0, 35.0, 8.0, 12.0]])
+    assert not (ind / "frame7.jpg").exists() and (ind / "broken.jpg").exists()
+    np.testing.assert_allclose(D.scale_boxes_xywh([[1, 1, 10, 10]], 1.5), [[1, 1, 15, 15]])
