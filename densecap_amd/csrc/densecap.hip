@@ -74,7 +74,7 @@ struct dc_ctx {
   float rpn_nms_thresh = 0.7f, final_nms_thresh = 0.3f;
   int max_lanes = 3;
   bool captions_after_final_nms = false;
-  bool serial_mode = true;   // one image in flight: idle CUs in a layer's last round are worth a tail split-K
+  bool serial_mode = false;  // lanes == 1: idle CUs in a layer's last round are worth a tail split-K (dc_set_lanes)
   int num_proposals = 300;  // LocalizationLayer default (LocalizationLayer.lua:237); run_model sets 1000
   // dims
   int k = 0, R = 0, V = 0, T = 0, E = 0, Hd = 0, D = 0;
@@ -527,6 +527,9 @@ int dc_set_lanes(dc_ctx* ctx, int lanes) {
   if (!ctx) return DC_E_INVALID;
   if (lanes < 1 || lanes > 4) return ctx->fail(DC_E_INVALID, "dc_set_lanes: lanes must be in [1,4]");
   ctx->max_lanes = lanes;
+  // numerics depend only on this setting, never on how many images a call happens to carry: with one lane the
+  // last partial round of a layer is K-split (different fp32 summation order for those rows)
+  ctx->serial_mode = lanes == 1;
   return DC_OK;
 }
 
@@ -645,7 +648,6 @@ static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, i
   for (int i = 0; i < n; ++i)
     if (outs[i].capacity <= 0) return ctx->fail(DC_E_INVALID, "dc_result.capacity must be > 0");
   const int nl = std::min(n, ctx->max_lanes);
-  ctx->serial_mode = nl == 1;   // with several images in flight the other lanes fill a layer's last round
   while ((int)ctx->lanes.size() < nl) ctx->lanes.emplace_back(new Lane());
   for (int l = 0; l < nl; ++l) DCCHK(lane_prepare(ctx, *ctx->lanes[l], H, W, P));
   const size_t img_elems = (size_t)3 * H * W;

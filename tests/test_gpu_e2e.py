@@ -228,3 +228,20 @@ def test_edge_shapes_do_not_break(model, weights):
     model.setTestArgs(num_proposals=64)
     b, s, t = model.forward_raw(make_synthetic_image(203, 301, 3))   # odd sizes: ceil-mode pooling everywhere
     assert 0 < len(b) <= 64 and t.min() >= 1
+
+
+def test_single_lane_mode_parity(model, weights):
+    """dc_set_lanes(1) switches on the tail K-split of each conv layer's last partial round (other fp32
+    summation order for those rows): same parity bar against the oracle, and still deterministic."""
+    from densecap_amd.weights import make_synthetic_image
+    model.setLanes(1)
+    try:
+        r = _check_against_oracle(model, weights, 600, 720, 1000, seed=0)
+        assert r["K"] > 0
+        img = make_synthetic_image(600, 720, 0)
+        a = model.forward_raw(img)
+        b = model.forward_batch(np.stack([img, img]))[1]
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    finally:
+        model.setLanes(3)
