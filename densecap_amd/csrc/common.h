@@ -74,6 +74,8 @@ hipError_t launch_lstm_pointwise(const float* gates, float* c, float* h, int n, 
 hipError_t launch_row_argmax(const float* logits, int n, int N, int ld, int32_t* tok, int32_t* seq, int T, int t,
                              hipStream_t s);
 hipError_t launch_fill_i32(int32_t* p, int32_t v, int n, hipStream_t s);
+// idx[i] = i for i < cap, *count_out = *count_in
+hipError_t launch_iota_count(int32_t* idx, int32_t* count_out, const int32_t* count_in, int cap, hipStream_t s);
 // reduce the per-N-tile arg-max partials of the fused vocab epilogue: tok[m] = seq[m*T+t] = 1 + argmax
 hipError_t launch_argmax_finalize(const float* pval, const int32_t* pidx, int n, const int32_t* n_dev, int ntiles,
                                   int ld, int32_t* tok, int32_t* seq, int T, int t, hipStream_t s);

@@ -219,7 +219,17 @@ int conv3x3(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, const f
 }
 
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+// num_proposals = -1 (LocalizationLayer.lua:322-324: uncapped RPN NMS): capacity = every anchor of this image size
+int effective_proposals(const dc_ctx* ctx, int H, int W);
 constexpr size_t kSplitkWsFloats = (size_t)640 * 128 * 128;   // 40 MiB: split-K (<= 256 tiles) and tail plans (<= 3 x ~200 tiles)
+
+int effective_proposals(const dc_ctx* ctx, int H, int W) {
+  if (ctx->num_proposals != -1) return ctx->num_proposals;
+  int fh = H, fw = W;
+  for (int i = 0; i < DC_NUM_VGG_CONVS; ++i)
+    if (kVgg[i].pool_after) { fh = (fh + 1) / 2; fw = (fw + 1) / 2; }
+  return std::min(ctx->k * fh * fw, 65536);
+}
 
 // (Re)build a lane's workspace for image size (H,W) and proposal capacity P.
 int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P) {
@@ -396,7 +406,8 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int img_on_device, b
     KCHK(launch_nms(L.nms, L.final_xyxy, L.obj, nullptr, P, L.count1, ctx->final_nms_thresh, -1, L.picks2, L.count2,
                     s));
   } else {
-    return ctx->fail(DC_E_UNSUPPORTED, "final_nms_thresh <= 0 is not supported");
+    // DenseCapModel.lua:261: no final NMS when final_nms_thresh <= 0 -> all RoIs, in RPN order
+    KCHK(launch_iota_count(L.picks2, L.count2, L.count1, P, s));
   }
   KCHK(launch_gather_rows(L.final_boxes, L.picks2, L.count2, P, 4, L.out_boxes, s));
   KCHK(launch_gather_rows(L.obj, L.picks2, L.count2, P, 1, L.out_scores, s));
@@ -515,8 +526,8 @@ const char* dc_last_error(const dc_ctx* ctx) { return ctx ? ctx->err.c_str() : g
 
 int dc_set_test_args(dc_ctx* ctx, float rpn_nms_thresh, float final_nms_thresh, int num_proposals) {
   if (!ctx) return DC_E_INVALID;
-  if (num_proposals <= 0 || num_proposals > 65536)
-    return ctx->fail(DC_E_UNSUPPORTED, "num_proposals must be in [1,65536] (got %d)", num_proposals);
+  if (num_proposals != -1 && (num_proposals <= 0 || num_proposals > 65536))
+    return ctx->fail(DC_E_UNSUPPORTED, "num_proposals must be -1 (uncapped) or in [1,65536] (got %d)", num_proposals);
   ctx->rpn_nms_thresh = rpn_nms_thresh;
   ctx->final_nms_thresh = final_nms_thresh;
   ctx->num_proposals = num_proposals;
@@ -644,7 +655,7 @@ static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, i
   if (!ctx->have_weights) return ctx->fail(DC_E_STATE, "dc_forward_*: weights not loaded");
   if (!imgs || !outs || n <= 0 || H < 32 || W < 32) return ctx->fail(DC_E_INVALID, "dc_forward_*: bad arguments");
   HIPCHK(hipSetDevice(ctx->device));
-  const int P = ctx->num_proposals;
+  const int P = effective_proposals(ctx, H, W);
   for (int i = 0; i < n; ++i)
     if (outs[i].capacity <= 0) return ctx->fail(DC_E_INVALID, "dc_result.capacity must be > 0");
   const int nl = std::min(n, ctx->max_lanes);
@@ -677,7 +688,7 @@ int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img
   HIPCHK(hipSetDevice(ctx->device));
   Lane& L = lane0(ctx);
   DCCHK(harvest(ctx, L));
-  DCCHK(lane_prepare(ctx, L, H, W, ctx->num_proposals));
+  DCCHK(lane_prepare(ctx, L, H, W, effective_proposals(ctx, H, W)));
   L.pending = nullptr;
   L.pending_capacity = capacity; L.pending_box_dst = boxes; L.pending_feat_dst = feats; L.pending_k_dst = K;
   DCCHK(enqueue_forward(ctx, L, img_chw, img_on_device, true));

@@ -237,6 +237,11 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, const 
   }
 }
 
+__global__ void iota_count_kernel(int32_t* idx, int32_t* count_out, const int32_t* count_in, int cap) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap) idx[i] = i;
+  if (i == 0) *count_out = *count_in;
+}
 __global__ void fill_i32_kernel(int32_t* p, int32_t v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -341,6 +346,10 @@ hipError_t launch_splitk_reduce(const float* ws, int S, const float* bias, float
   if (N % 4 || ldc % 4) return hipErrorInvalidValue;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)M * (N / 4))), dim3(256), 0, s, ws, S, bias, C, M, N, ldc,
                      relu);
+  return hipGetLastError();
+}
+hipError_t launch_iota_count(int32_t* idx, int32_t* count_out, const int32_t* count_in, int cap, hipStream_t s) {
+  hipLaunchKernelGGL(iota_count_kernel, dim3((cap + 255) / 256), dim3(256), 0, s, idx, count_out, count_in, cap);
   return hipGetLastError();
 }
 hipError_t launch_fill_i32(int32_t* p, int32_t v, int n, hipStream_t s) {

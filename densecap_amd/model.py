@@ -53,6 +53,7 @@ class DenseCapModel:
         for i, v in enumerate(weights["field_centers"]):
             w.field_centers[i] = float(v)
         w.num_anchors = int(_np32(weights["anchors"]).shape[1])
+        self.num_anchors = int(w.num_anchors)
         w.rpn_hidden = int(_np32(weights["rpn_conv_w"]).shape[0])
         w.vocab_size = self.vocab_size
         w.seq_length = self.seq_length
@@ -114,10 +115,18 @@ class DenseCapModel:
         r.tokens = tokens.ctypes.data_as(_lib.c_int32_p)
         return r, boxes, scores, tokens
 
+    def _capacity(self, H, W):
+        P = int(self.opt["num_proposals"])
+        if P != -1:
+            return P
+        for _ in range(4):                       # four ceil-mode 2x2 pools (conv5_3 map)
+            H, W = (H + 1) // 2, (W + 1) // 2
+        return min(self.num_anchors * H * W, 65536)
+
     def forward_raw(self, img):
         """forward_test without string decoding: (boxes (K,4) xcycwh, scores (K,), tokens (K,T))."""
         img = self._check_input(img)
-        P = int(self.opt["num_proposals"])
+        P = self._capacity(img.shape[1], img.shape[2])
         r, boxes, scores, tokens = self._new_result(P)
         check(self.ctx.h, self.lib.dc_forward_test(self.ctx.h, img.ctypes.data, img.shape[1], img.shape[2], 0,
                                                    C.byref(r)), "dc_forward_test")

@@ -109,7 +109,8 @@ const char* dc_last_error(const dc_ctx* ctx);
  * DenseCapModel.lua:198-208): upload + repack weights for the kernels. */
 int dc_load_weights(dc_ctx* ctx, const dc_weights* w);
 /* DenseCapModel:setTestArgs{rpn_nms_thresh,final_nms_thresh,num_proposals}
- * (DenseCapModel.lua:185-191). num_proposals = -1 is not supported (cap needed). */
+ * (DenseCapModel.lua:185-191). num_proposals = -1 = uncapped RPN NMS (capacity = all anchors of the image,
+ * LocalizationLayer.lua:322-324); final_nms_thresh <= 0 = no final NMS (DenseCapModel.lua:261). */
 int dc_set_test_args(dc_ctx* ctx, float rpn_nms_thresh, float final_nms_thresh, int num_proposals);
 
 /* ---- the hot path ------------------------------------------------------- */

@@ -144,7 +144,9 @@ def test_extract_features(model, weights):
 def test_errors_are_reported_not_thrown(model):
     from densecap_amd._lib import DenseCapError
     with pytest.raises(DenseCapError):
-        model.setTestArgs(num_proposals=-1)
+        model.setTestArgs(num_proposals=0)
+    with pytest.raises(DenseCapError):
+        model.setTestArgs(num_proposals=100000)
     model.setTestArgs(num_proposals=100)
     with pytest.raises(AssertionError):
         model.forward_raw(np.zeros((1, 4, 64, 64), np.float32))
@@ -245,3 +247,24 @@ def test_single_lane_mode_parity(model, weights):
             np.testing.assert_array_equal(x, y)
     finally:
         model.setLanes(3)
+
+
+def test_uncapped_proposals_and_no_final_nms(model, weights):
+    """num_proposals = -1 (LocalizationLayer.lua:322-324) and final_nms_thresh <= 0 (DenseCapModel.lua:261),
+    against the oracle on a small image."""
+    from densecap_amd.weights import make_synthetic_image
+    from oracle import densecap_oracle as O
+    img = make_synthetic_image(128, 160, 9)            # 8x10 map -> 960 anchors
+    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=-1)
+    b, s, t = model.forward_raw(img)
+    ob, os_, oseq = O.forward_test(img, weights, 0.7, 0.3, -1, 15)
+    assert len(b) == len(ob) > 0
+    np.testing.assert_allclose(b, ob, rtol=1e-4, atol=1e-3)
+    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.0, num_proposals=40)
+    b, s, t = model.forward_raw(img)
+    ob, os_, oseq = O.forward_test(img, weights, 0.7, 0.0, 40, 15)
+    assert len(b) == len(ob) == 40
+    np.testing.assert_allclose(b, ob, rtol=1e-4, atol=1e-3)       # RPN order, no sorting by objectness
+    np.testing.assert_allclose(s, os_, rtol=1e-4, atol=1e-4)
+    assert (t == oseq).all(axis=1).mean() > 0.9
+    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=100)
