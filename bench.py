@@ -72,7 +72,14 @@ def main():
     # setup (not a step): one image per lane so that every lane's workspace exists before anything is timed
     model.forward_batch_device(dev.ptr, min(args.lanes, n_img), H, W)
     if Wm > 0:
-        model.forward_batch_device(dev.ptr, Wm, H, W)
+        wres = model.forward_batch_device(dev.ptr, Wm, H, W)
+    else:
+        wres = model.forward_batch_device(dev.ptr, 1, H, W)
+    if dist is not None:
+        # warm the collective too (communicator setup of the first RCCL call is not part of a step)
+        from densecap_amd import dist as D
+        wrec = D.pack_records([wres[0]] * K, P, model.seq_length)
+        D.gather_records(dist, wrec[0], wrec[1], rank, world, device=torch.device("cuda", local_rank))
     sync()
     if args.lanes == 1:
         model.mfma_profile(reset=1)  # HIP events around every MFMA launch during the timed region
