@@ -748,11 +748,13 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
       const bool forced = d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0;
       if (!no_ks && (d.K % (2 * BK * d.splitk)) == 0 && (forced || d.K >= 32 * BK)) {   // short K loops do not amortise the 4-phase reduction
         // 64 KiB operand ring, reused as the 4 x 16 KiB reduction slots; + a 128 x 129 tile for the fused arg-max
-        const size_t lds_ks = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)BM * (BN + 1) * sizeof(float);
+        const size_t lds_ks_max = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)BM * (BN + 1) * sizeof(float);
+        // without the arg-max tile a K-split workgroup leaves 96 KiB of the CU's LDS to co-resident workgroups
+        const size_t lds_ks = d.amax_val != nullptr ? lds_ks_max : (size_t)2 * (BM + BN) * BK * sizeof(float);
         static bool attrk = false;
         if (!attrk) {
           hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_ks_kernel<CONV>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ks);
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ks_max);
           if (e != hipSuccess) return e;
           attrk = true;
         }
