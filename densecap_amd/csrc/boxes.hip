@@ -165,7 +165,7 @@ __global__ void rpn_decode_kernel(const float* __restrict__ heads, int h, int w,
 // order-preserving key (histogram -> exclusive scan -> scatter) followed by an exact in-bucket rank
 // (compare against the few members of the same bucket).  Deterministic regardless of atomic order, and
 // exactly the oracle's tie rule.
-// Stage 2/3 -- window by window over the sorted list (4096, 8192, 16384, 32768 boxes): the whole GPU
+// Stage 2/3 -- window by window over the sorted list (4096 boxes, then 32768 at a time): the whole GPU
 // computes (a) which window candidates are already suppressed by earlier picks and (b) the window's
 // upper-triangular suppression bit-mask; one workgroup then scans the window 64 candidates per step.
 // Kernels of later windows exit at once when the pick budget is met (`done` flag), so the common case
@@ -535,7 +535,9 @@ hipError_t launch_rpn_decode(const float* heads, int h, int w, int k, const floa
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // window k covers sorted rows [win_start(k), win_start(k+1))
-static int win_start(int k) { return NMS_WIN0 * ((1 << k) - 1); }
+// windows: 4096 boxes, then 32768 at a time (the scan kernel's LDS bit set holds 32768).  The pick budget is
+// normally met inside the first window; every further window costs three (empty) launches.
+static int win_start(int k) { return k == 0 ? 0 : NMS_WIN0 + (k - 1) * 32768; }
 static size_t nms_mask_words(int n) {
   size_t best = 0;
   for (int k = 0; win_start(k) < n; ++k) {
