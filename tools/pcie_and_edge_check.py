@@ -1,5 +1,5 @@
-import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+import os, sys, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from densecap_amd import DenseCapModel
 from densecap_amd.weights import make_synthetic_weights, make_synthetic_image
 W = make_synthetic_weights(); m = DenseCapModel(W, 0); m.setTestArgs(num_proposals=1000)
