@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--proposals", type=int, default=1000)
     ap.add_argument("--lanes", type=int, default=3, help="streams images are pipelined over (1 = serial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-pass", action="store_true",
+                    help="skip the secondary caption-order measurement (keeps rocprof kernel statistics to one workload)")
     args = ap.parse_args()
 
     import numpy as np
@@ -107,7 +109,7 @@ def main():
     # Secondary figure (not `value`): final NMS first, captions only for the surviving boxes -- bit-identical
     # outputs (tests/test_gpu_e2e.py::test_caption_order_is_output_invariant), less LSTM work.
     alt = None
-    if dist is None:
+    if dist is None and not args.no_alt_pass:
         model.setCaptionOrder(True)
         model.forward_batch_device(dev.ptr, min(2, K), H, W)
         sync()
