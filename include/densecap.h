@@ -142,14 +142,15 @@ int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img
  * LocalizationLayer.lua:219-230).  names[i] are static strings.  Returns the
  * number of stages written (<= max_stages). */
 int dc_stage_times(dc_ctx* ctx, const char** names, float* ms, int max_stages);
-/* Accumulated [launch count, total ms, total algorithmic FLOPs] of the MFMA
- * contraction kernel family since the last reset (HIP events around every launch).
- * Used by bench.py for the live roofline figure. */
+/* Accumulated [contraction count, total ms, total algorithmic FLOPs] of the MFMA contraction kernel family
+ * (HIP events around every contraction, including its split-K finish).  reset = 1 (re)starts the
+ * measurement, reset = -1 stops it, 0 just reads.  Used by bench.py for the live roofline figure. */
 int dc_mfma_profile(dc_ctx* ctx, int reset, int64_t* launches, double* total_ms, double* total_flops);
 /* Copy an intermediate of the most recent forward to the host for stage-wise parity:
  * name in {"feat_hwc","rpn_heads","rpn_boxes","rpn_x1y1x2y2","rpn_p","rpn_valid",
- * "rpn_nms_idx","roi_boxes","roi_feats","codes","obj","final_trans","final_boxes",
- * "seq","final_nms_idx"}.  Returns the number of elements copied (or <0). */
+ * "rpn_nms_idx","rpn_nms_count","roi_boxes","roi_feats","codes","obj","final_trans","final_boxes",
+ * "seq","final_nms_idx","final_nms_count"} (lane 0; "seq" is only filled in the reference caption order).
+ * Returns the number of elements copied (or <0). */
 int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t capacity_bytes);
 
 /* ---- device memory helpers (for hosts without a GPU allocator, e.g. LuaJIT) -- */
