@@ -342,8 +342,9 @@ int lm_sample(dc_ctx* ctx, Lane& L, const float* codes, int n, const int32_t* n_
       GemmDesc v;
       v.A = L.hstate; v.W = ctx->out_w; v.bias = ctx->out_b; v.C = nullptr; v.M = n; v.N = V1; v.K = Hd; v.ldc = V1;
       v.m_dev = n_dev;
+      v.amax_val = L.logits;
       const int ntn = mfma_gemm_ntiles_n(v);
-      v.amax_val = L.logits; v.amax_idx = reinterpret_cast<int32_t*>(L.logits + (size_t)n * ntn); v.amax_ld = ntn;
+      v.amax_idx = reinterpret_cast<int32_t*>(L.logits + (size_t)n * ntn); v.amax_ld = ntn;
       DCCHK(run_gemm(ctx, v, s));
       KCHK(launch_argmax_finalize(v.amax_val, v.amax_idx, n, n_dev, ntn, ntn, L.tok, seq_out, T, t, s));
     }
