@@ -178,7 +178,7 @@ constexpr int NMS_WIN0 = 4096;
 
 __device__ __forceinline__ uint32_t sort_key(float s, bool valid) {
   if (!valid) return 0xffffffffu;
-  if (s != s) s = -INFINITY;             // NaN scores sort last among valid boxes
+  if (s != s) return 0u;                 // NaN ranks above every number, as in TH's sort (GT_OR_NAN): picked first
   if (s == 0.f) s = 0.f;                 // -0 == +0 (ties broken by index, as a float compare would)
   uint32_t u = __float_as_uint(s);
   u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // larger float -> larger u

@@ -118,7 +118,9 @@ def nms_py(boxes5, overlap, max_boxes=None):
     x1, y1, x2, y2, s = b[:, 0], b[:, 1], b[:, 2], b[:, 3], b[:, 4]
     area = (x2 - x1 + F32(1)) * (y2 - y1 + F32(1))
     # ascending sort, take from the tail; stable on (-s) => lower index first
-    order = np.argsort(-s.astype(np.float64), kind="stable")  # descending
+    # TH's sort ranks NaN above every number (end of the ascending list = picked first)
+    s64 = s.astype(np.float64)
+    order = np.lexsort((np.arange(len(s64)), -np.where(np.isnan(s64), 0.0, s64), ~np.isnan(s64)))  # descending
     I = order[::-1].copy()  # ascending list, best at the tail
     thr = F32(overlap)
     pick = []

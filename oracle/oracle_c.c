@@ -20,13 +20,16 @@
 typedef struct { float s; int i; } si_t;
 static int cmp_desc(const void* a, const void* b) {
     const si_t* x = (const si_t*)a; const si_t* y = (const si_t*)b;
+    const int xn = x->s != x->s, yn = y->s != y->s;   /* TH sort (GT_OR_NAN): NaN ranks above every number */
+    if (xn != yn) return xn ? -1 : 1;
     if (x->s > y->s) return -1;
     if (x->s < y->s) return 1;
     return (x->i > y->i) - (x->i < y->i);  /* tie rule: lower original index first */
 }
 
 /* boxes5: (n,5) x1 y1 x2 y2 score.  Writes 0-based picks, returns their count.
- * max_boxes < 0 means uncapped.  NaN scores sort last (never beat a number). */
+ * max_boxes < 0 means uncapped.  NaN scores rank above every number (TH's sort puts NaN at the end of
+ * the ascending list, box_utils.lua:185 takes from the tail), ties by index. */
 int oracle_nms(const float* boxes5, int n, float overlap, int max_boxes, int* pick) {
     if (n <= 0) return 0;
     si_t* ord = (si_t*)malloc(sizeof(si_t) * (size_t)n);

@@ -268,3 +268,38 @@ def test_uncapped_proposals_and_no_final_nms(model, weights):
     np.testing.assert_allclose(s, os_, rtol=1e-4, atol=1e-4)
     assert (t == oseq).all(axis=1).mean() > 0.9
     model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=100)
+
+
+def test_argmax_takes_first_index_on_exact_ties():
+    """torch.max on ties (LanguageModel.lua:329): first maximum.  Every odd row of the vocabulary matrix duplicates
+    the even row before it, so each step's maximum is an exact two-way tie inside one tile or across two tiles."""
+    import ctypes as C
+    from densecap_amd import DenseCapModel
+    from densecap_amd._lib import check
+    from densecap_amd.weights import make_synthetic_weights
+    for V, far in ((300, False), (2047, False), (2047, True)):
+        w = make_synthetic_weights(seed=7, vocab_size=V, seq_length=6)
+        ow, ob = w["lm_out_w"], w["lm_out_b"]
+        n2 = (V + 1) // 2
+        if far:                              # row j + n2 duplicates row j: the tie spans two column tiles
+            ow[n2:2 * n2] = ow[:n2]
+            ob[n2:2 * n2] = ob[:n2]
+        else:                                # odd rows duplicate the even row before them: tie inside one tile
+            ow[1:2 * n2:2] = ow[0:2 * n2:2]
+            ob[1:2 * n2:2] = ob[0:2 * n2:2]
+        m = DenseCapModel(w, device=0)
+        try:
+            ctx = m.ctx
+            n = 333
+            codes = np.maximum(np.random.default_rng(V).standard_normal((n, 4096)), 0).astype(np.float32)
+            cd = ctx.to_device(codes); td = ctx.empty((n, 6), np.int32)
+            check(ctx.h, ctx.lib.dc_op_lm_sample(ctx.h, cd.ptr, n, td.ptr), "dc_op_lm_sample")
+            seq = td.numpy()
+            assert seq.min() >= 1 and seq.max() <= V + 1
+            if far:
+                assert (seq <= n2).all()
+            else:
+                assert (seq % 2 == 1).all()  # 1-based ids of the even (first) rows are odd
+            assert len(np.unique(seq)) > 10
+        finally:
+            m.ctx.close()

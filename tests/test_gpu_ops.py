@@ -234,3 +234,16 @@ def test_bilinear_roi_pool_identity_property(ctx):
     box = np.array([[(W + 1) / 2, (H + 1) / 2, W, H]], np.float32)
     out = ops.bilinear_roi_pool(ctx, feat, box, H, W, 9, 11)
     np.testing.assert_allclose(out[0], feat, atol=1e-5)
+
+
+def test_nms_nan_and_inf_scores(ctx):
+    # docs/SEMANTICS.md: NaN scores sort last (never beat a number); +-inf order like numbers
+    from densecap_amd import ops
+    from oracle import densecap_oracle as O
+    rng = np.random.default_rng(5)
+    b = _random_boxes5(rng, 2000, True)
+    b[rng.choice(2000, 100, replace=False), 4] = np.nan
+    b[rng.choice(2000, 20, replace=False), 4] = np.inf
+    b[rng.choice(2000, 20, replace=False), 4] = -np.inf
+    for maxb in (None, 150):
+        assert ops.nms(ctx, b, 0.5, maxb).tolist() == O.nms(b, 0.5, maxb).tolist()

@@ -31,6 +31,20 @@ def test_nms_c_equals_py_random():
             assert O.nms(b, thr, 50).tolist() == O.nms_py(b, thr, 50).tolist()
 
 
+def test_nms_nan_scores_rank_first_like_th_sort():
+    # docs/SEMANTICS.md: TH's sort puts NaN at the end of the ascending list, box_utils.lua:185-204 picks from the tail
+    rng = np.random.default_rng(3)
+    xy = rng.uniform(0, 2000, (200, 2)); wh = rng.uniform(5, 30, (200, 2))
+    b = np.concatenate([xy, xy + wh, rng.uniform(0, 1, (200, 1))], 1).astype(np.float32)
+    b[[150, 7], 4] = np.nan
+    b[33, 4] = np.inf
+    b[90, 4] = -np.inf
+    for f in (O.nms, O.nms_py):
+        p = f(b, 0.99, None).tolist()
+        assert p[:3] == [7, 150, 33] and p[-1] == 90 and len(p) == 200
+    assert O.nms(b, 0.5, 40).tolist() == O.nms_py(b, 0.5, 40).tolist()
+
+
 def test_apply_box_transform_golden(golden):
     g = golden["apply_box_transform"]
     out = O.apply_box_transform(np.array(g["boxes"], np.float32), np.array(g["trans"], np.float32))
