@@ -4,6 +4,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -71,3 +72,35 @@ def test_oracle_forward_tiny_runs():
     assert seq.min() >= 1 and seq.max() <= 41
     caps = O.decode_sequence(seq, W["idx_to_token"], 40)
     assert len(caps) == len(boxes)
+
+
+def _build_c_harness(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "dc_harness")
+    lib = os.path.join(ROOT, "densecap_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "dc_harness.c"), "-o", exe, "-L" + lib, "-ldensecap_hip",
+                           "-Wl,-rpath," + lib, "-lm"])
+    return exe
+
+
+def test_c_harness_links_against_the_header_and_fails_loudly_without_gpu(tmp_path):
+    """A plain-C program (no Python, no torch types) builds against include/densecap.h and the .so; on a box
+    without a HIP device dc_create reports the error through the return code (no abort, no CPU fallback)."""
+    import subprocess
+    import torch
+    exe = _build_c_harness(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by test_c_harness_runs_on_gpu")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 1
+    assert "no CPU fallback" in p.stderr
+
+
+@pytest.mark.gpu
+def test_c_harness_runs_on_gpu(tmp_path):
+    import subprocess
+    exe = _build_c_harness(tmp_path)
+    p = subprocess.run([exe, "224", "288", "100", "3"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "HARNESS OK" in p.stdout and "expected error before load_weights" in p.stdout
