@@ -1,0 +1,101 @@
+"""extract_features.lua on the MI355X path.
+
+Same flags and output datasets as the reference's `extract_features.lua` (flags :11-27, `run_image`
+:30-44, main :47-99): for each image of `-input_txt`, `DenseCapModel:extractFeatures` (boxes + fc7 codes
+after the final NMS, no LSTM decode), boxes converted to xywh, the first `-boxes_per_image` rows kept.
+
+    python -m densecap_amd.extract_features -input_txt paths.txt -output_h5 feats.h5 -checkpoint model.t7
+
+Output: datasets `/feats` (N, M, 4096) and `/boxes` (N, M, 4), fp32.  The reference writes them with
+torch-hdf5; this image has no HDF5 library, so when `h5py` cannot be imported the same two arrays go to
+`<output_h5>.npz` (keys `feats`, `boxes`) and a note is printed.
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+
+import numpy as np
+
+from .run_model import load_image_caffe, xcycwh_to_xywh
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prefix_chars="-", description=__doc__,
+                                formatter_class=argparse.RawDescriptionHelpFormatter)
+    a = p.add_argument
+    a("-checkpoint", default="data/models/densecap/densecap-pretrained-vgg16.t7")
+    a("-image_size", type=int, default=720)
+    a("-rpn_nms_thresh", type=float, default=0.7)
+    a("-final_nms_thresh", type=float, default=0.4)
+    a("-num_proposals", type=int, default=1000)
+    a("-boxes_per_image", type=int, default=100)
+    a("-input_txt", default="")
+    a("-max_images", type=int, default=0)
+    a("-output_h5", default="")
+    a("-gpu", type=int, default=0)
+    a("-synthetic_weights", type=int, default=0,
+      help="1: random weights in checkpoint shapes (no pretrained .t7 is available offline)")
+    return p
+
+
+def write_datasets(path, feats, boxes):
+    try:
+        import h5py
+    except ImportError:
+        out = path + ".npz"
+        np.savez(out, feats=feats, boxes=boxes)
+        print("h5py is not installed: wrote datasets feats%s, boxes%s to %s" % (feats.shape, boxes.shape, out))
+        return out
+    with h5py.File(path, "w") as f:
+        f.create_dataset("feats", data=feats)
+        f.create_dataset("boxes", data=boxes)
+    return path
+
+
+def main(argv=None):
+    opt = build_parser().parse_args(argv)
+    if not opt.input_txt:
+        raise SystemExit("Must provide -input_txt")
+    if not opt.output_h5:
+        raise SystemExit("Must provide -output_h5")
+    with open(opt.input_txt) as f:
+        paths = [ln.strip() for ln in f if ln.strip()]
+    if opt.max_images > 0:
+        paths = paths[:opt.max_images]
+    from . import DenseCapModel
+    if opt.synthetic_weights:
+        from .weights import make_synthetic_weights
+        weights = make_synthetic_weights()
+    else:
+        import os
+        from . import t7
+        if not os.path.exists(opt.checkpoint):
+            raise SystemExit("checkpoint %s not found (use -synthetic_weights 1 for random weights)" % opt.checkpoint)
+        weights = t7.weights_from_checkpoint(t7.load(opt.checkpoint))
+    model = DenseCapModel(weights, device=opt.gpu)
+    model.setTestArgs(rpn_nms_thresh=opt.rpn_nms_thresh, final_nms_thresh=opt.final_nms_thresh,
+                      num_proposals=opt.num_proposals)
+    model.evaluate()
+    N, M = len(paths), opt.boxes_per_image
+    all_boxes = np.zeros((N, M, 4), np.float32)
+    all_feats = None
+    for i, path in enumerate(paths):
+        print("Processing image %d / %d" % (i + 1, N))
+        img_caffe, _ = load_image_caffe(path, opt.image_size)
+        boxes_xcycwh, feats = model.extractFeatures(img_caffe)
+        if len(boxes_xcycwh) < M:     # the reference's boxes[{{1, M}}] raises on a short result as well
+            raise SystemExit("image %s: only %d boxes survive the final NMS, -boxes_per_image is %d"
+                             % (path, len(boxes_xcycwh), M))
+        if all_feats is None:
+            all_feats = np.zeros((N, M, feats.shape[1]), np.float32)
+        all_boxes[i] = xcycwh_to_xywh(boxes_xcycwh)[:M]
+        all_feats[i] = feats[:M]
+    if all_feats is None:
+        all_feats = np.zeros((0, M, 4096), np.float32)
+    write_datasets(opt.output_h5, all_feats, all_boxes)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -218,6 +218,35 @@ def test_run_model_cli_writes_results_json(tmp_path):
     assert d["opt"]["num_proposals"] == 50 and (out_dir / "elephant.png").exists()
 
 
+def test_extract_features_cli_writes_feats_and_boxes(tmp_path):
+    """extract_features.lua equivalent: -input_txt list -> /feats (N,M,4096), /boxes (N,M,4) xywh (npz without h5py)."""
+    from PIL import Image
+    from densecap_amd import extract_features as X
+    rng = np.random.default_rng(6)
+    lines = []
+    for i in range(2):
+        src = tmp_path / ("im%d.png" % i)
+        Image.fromarray(rng.uniform(0, 255, (240, 360, 3)).astype(np.uint8)).save(src)
+        lines.append(str(src))
+    (tmp_path / "list.txt").write_text("\n".join(lines + ["/nonexistent/ignored_by_max_images.png"]) + "\n")
+    out = tmp_path / "feats.h5"
+    rc = X.main(["-input_txt", str(tmp_path / "list.txt"), "-output_h5", str(out), "-synthetic_weights", "1",
+                 "-num_proposals", "60", "-boxes_per_image", "3", "-image_size", "360", "-max_images", "2",
+                 "-final_nms_thresh", "0.4"])
+    assert rc == 0
+    try:
+        import h5py
+        f = h5py.File(out, "r"); feats, boxes = f["feats"][:], f["boxes"][:]
+    except ImportError:
+        d = np.load(str(out) + ".npz"); feats, boxes = d["feats"], d["boxes"]
+    assert feats.shape == (2, 3, 4096) and boxes.shape == (2, 3, 4)
+    assert feats.dtype == np.float32 and (feats >= 0).all() and feats.max() > 0      # fc7 codes are post-ReLU
+    assert (boxes[:, :, 2:] > 0).all()
+    with pytest.raises(SystemExit):                                                 # fewer survivors than requested
+        X.main(["-input_txt", str(tmp_path / "list.txt"), "-output_h5", str(out), "-synthetic_weights", "1",
+                "-num_proposals", "5", "-boxes_per_image", "50", "-image_size", "360", "-max_images", "1"])
+
+
 def test_edge_shapes_do_not_break(model, weights):
     """Tiny images (2x2 feature map), more proposals requested than anchors exist, non-multiple-of-16 sizes."""
     from densecap_amd.weights import make_synthetic_image
