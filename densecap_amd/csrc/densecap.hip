@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <memory>
 
 #include "common.h"
@@ -663,13 +664,18 @@ static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, i
   while ((int)ctx->lanes.size() < nl) ctx->lanes.emplace_back(new Lane());
   for (int l = 0; l < nl; ++l) DCCHK(lane_prepare(ctx, *ctx->lanes[l], H, W, P));
   const size_t img_elems = (size_t)3 * H * W;
+  static const bool host_timing = getenv("DENSECAP_HOST_TIMING") != nullptr;   // stderr: host ms spent enqueueing
+  double enq_ms = 0;
   for (int i = 0; i < n; ++i) {
     Lane& L = *ctx->lanes[i % nl];
     DCCHK(harvest(ctx, L));
     L.pending = &outs[i];
+    const auto t0 = std::chrono::steady_clock::now();
     DCCHK(enqueue_forward(ctx, L, imgs + img_elems * i, on_dev, false));
+    enq_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
   for (int l = 0; l < nl; ++l) DCCHK(harvest(ctx, *ctx->lanes[l]));
+  if (host_timing) fprintf(stderr, "[densecap] %d images: host enqueue %.3f ms/image\n", n, enq_ms / n);
   prof_collect(ctx);
   return DC_OK;
 }

@@ -814,7 +814,8 @@ hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
   auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
   // fused arg-max: 128x64 tiles (72 KiB LDS, two workgroups per CU) overlap one tile's LDS-transpose epilogue
   // with the other's K loop -- measured 2.43 vs 2.51 ms for the 15 decode steps at 1000 x 10498
-  if (d.amax_val != nullptr && d.N > 64 && blocks(128, 128) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
+  // and the same holds for every K loop too short for the K-split kernel (conv2_1: 214 -> 178 us)
+  if ((d.amax_val != nullptr || d.K < 32 * BK) && d.N > 64 && blocks(128, 128) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
   if (d.N > 64 && blocks(128, 128) >= 384) return launch_cfg<2, 2, CONV>(d, stream);
   if (d.N <= 64 && blocks(128, 64) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
   if (d.N > 64 && blocks(128, 128) >= 200 && blocks(128, 128) <= 256) return launch_cfg<2, 2, CONV>(d, stream);
@@ -827,7 +828,7 @@ hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
 int mfma_gemm_ntiles_n(const GemmDesc& d) {
   auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
   int bn;
-  if (d.N > 64 && blocks(128, 128) >= 384) bn = d.amax_val != nullptr ? 64 : 128;   // mirrors launch_pick
+  if (d.N > 64 && blocks(128, 128) >= 384) bn = (d.amax_val != nullptr || d.K < 32 * BK) ? 64 : 128;   // mirrors launch_pick
   else if (d.N <= 64 && blocks(128, 64) >= 384) bn = 64;
   else if (d.N > 64 && blocks(128, 128) >= 200 && blocks(128, 128) <= 256) bn = 128;
   else bn = 64;
