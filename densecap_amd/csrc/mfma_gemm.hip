@@ -472,10 +472,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
 // =========================================================================================
 template <bool CONV>
 __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
-  constexpr int TM = 2, TN = 2;            // epilogue view: 2x2 waves of 64x64
   constexpr int BM = 128, BN = 128;
   constexpr int PA = BM / 32, PB = BN / 32;
-  constexpr int NS = 2;
   constexpr int STAGE = (BM + BN) * BK;    // floats per ring stage
   extern __shared__ __attribute__((aligned(16))) float smem[];
 

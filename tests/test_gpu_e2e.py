@@ -332,3 +332,15 @@ def test_argmax_takes_first_index_on_exact_ties():
             assert len(np.unique(seq)) > 10
         finally:
             m.ctx.close()
+
+
+def test_randomised_shapes_and_thresholds_match_oracle():
+    """tools/fuzz_e2e.py: random H, W, num_proposals (incl. -1, 1), thresholds (incl. 0, 1, disabled), lanes and
+    caption order; every oracle box must be reproduced with identical tokens."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_e2e.py"), "10", "1"], capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "FUZZ OK: 10/10" in p.stdout
