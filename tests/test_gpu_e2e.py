@@ -5,6 +5,8 @@ Greedy NMS and arg-max are discontinuous: an fp32 rounding difference upstream (
 vs glibc, MFMA summation order vs BLAS) can flip a near-tie.  Exact integer parity is asserted
 under teacher forcing in test_gpu_ops.py; here the comparison is flip-aware: rows are matched
 by box identity and every mismatch must be explained by a near-tie margin in the oracle."""
+import os
+
 import numpy as np
 import pytest
 
