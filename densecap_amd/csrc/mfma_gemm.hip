@@ -25,6 +25,7 @@
 namespace {
 
 constexpr int BK = 32;
+constexpr unsigned CV_PAD = 0xffffe000u;   // conv padding marker: voffset (+ up to 8 KiB of channel offset) past any descriptor range
 constexpr int LDS_LD = BK + 4;  // floats per LDS row
 
 template <int TM, int TN, bool CONV>
@@ -275,13 +276,28 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
   // Request K-tile `kt` into ring stage `st`, one LDS-DMA instruction (1 KiB) per call: piece p in
   // [0,PA) is an A row-pass, [PA,PA+PB) a B row-pass.  An LDS-DMA instruction occupies the issuing
   // wave for ~60+ cycles, so the pieces are interleaved 1:1 with MFMAs by the caller.
-  int cv_toff = 0, cv_dy = 0, cv_dx = 0;
+  // im2col addressing: the per-lane byte offsets (tap displacement and the padding test folded in; CV_PAD = beyond the
+  // descriptor's range -> the memory unit returns zeros) are recomputed only when the K walk enters a new tap, i.e. every
+  // Cin/32 K-tiles; within a tap a K-tile only moves the scalar channel offset.  The per-piece issue is then a bare
+  // buffer_load (the earlier per-piece compare/select chain cost ~3 % of the loop).
+  unsigned cv_vo[PA];
+  int cv_soff = 0;
+  bool cv_new_tap = true;
   auto issue_begin = [&]() {
     if constexpr (CONV) {
-      cv_dy = tap / 3 - 1; cv_dx = tap - (tap / 3) * 3 - 1;
-      cv_toff = ((cv_dy * d.Wd + cv_dx) * d.Cin + c0) * 4;
+      if (cv_new_tap) {
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const unsigned toff = (unsigned)((dy * d.Wd + dx) * d.Cin * 4);
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          const bool ok = a_ok[i] && (unsigned)(a_y[i] + dy) < (unsigned)d.H && (unsigned)(a_x[i] + dx) < (unsigned)d.Wd;
+          cv_vo[i] = ok ? a_off[i] + toff : CV_PAD;
+        }
+      }
+      cv_soff = c0 * 4;
       c0 += BK;
-      if (c0 >= d.Cin) { c0 = 0; ++tap; }
+      cv_new_tap = c0 >= d.Cin;
+      if (cv_new_tap) { c0 = 0; ++tap; }
     }
   };
   auto issue_piece = [&](int kt, int st, int p) {
@@ -289,9 +305,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
     float* sb = sa + BM * BK;
     if (p < PA) {
       if constexpr (CONV) {
-        const bool ok = a_ok[p] && (unsigned)(a_y[p] + cv_dy) < (unsigned)d.H && (unsigned)(a_x[p] + cv_dx) < (unsigned)d.Wd;
-        const unsigned vo = ok ? a_off[p] + (unsigned)cv_toff : 0xfffffff0u;   // out of range -> zeros
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, sa + p * 32 * BK, 16, (int)vo, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, sa + p * 32 * BK, 16, (int)cv_vo[p], cv_soff, 0, 0);
       } else {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, sa + p * 32 * BK, 16, (int)a_off[p], kt * (BK * 4), 0, 0);
       }
@@ -545,13 +559,28 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
     }
   }
   int tap = 0, c0 = 0;
-  int cv_toff = 0, cv_dy = 0, cv_dx = 0;
+  // im2col addressing: the per-lane byte offsets (tap displacement and the padding test folded in; CV_PAD = beyond the
+  // descriptor's range -> the memory unit returns zeros) are recomputed only when the K walk enters a new tap, i.e. every
+  // Cin/32 K-tiles; within a tap a K-tile only moves the scalar channel offset.  The per-piece issue is then a bare
+  // buffer_load (the earlier per-piece compare/select chain cost ~3 % of the loop).
+  unsigned cv_vo[PA];
+  int cv_soff = 0;
+  bool cv_new_tap = true;
   auto issue_begin = [&]() {
     if constexpr (CONV) {
-      cv_dy = tap / 3 - 1; cv_dx = tap - (tap / 3) * 3 - 1;
-      cv_toff = ((cv_dy * d.Wd + cv_dx) * d.Cin + c0) * 4;
+      if (cv_new_tap) {
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const unsigned toff = (unsigned)((dy * d.Wd + dx) * d.Cin * 4);
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          const bool ok = a_ok[i] && (unsigned)(a_y[i] + dy) < (unsigned)d.H && (unsigned)(a_x[i] + dx) < (unsigned)d.Wd;
+          cv_vo[i] = ok ? a_off[i] + toff : CV_PAD;
+        }
+      }
+      cv_soff = c0 * 4;
       c0 += BK;
-      if (c0 >= d.Cin) { c0 = 0; ++tap; }
+      cv_new_tap = c0 >= d.Cin;
+      if (cv_new_tap) { c0 = 0; ++tap; }
     }
   };
   auto issue_piece = [&](int kt, int st, int p) {
@@ -559,9 +588,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
     float* sb = sa + BM * BK;
     if (p < PA) {
       if constexpr (CONV) {
-        const bool ok = a_ok[p] && (unsigned)(a_y[p] + cv_dy) < (unsigned)d.H && (unsigned)(a_x[p] + cv_dx) < (unsigned)d.Wd;
-        const unsigned vo = ok ? a_off[p] + (unsigned)cv_toff : 0xfffffff0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, sa + p * 32 * BK, 16, (int)vo, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, sa + p * 32 * BK, 16, (int)cv_vo[p], cv_soff, 0, 0);
       } else {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, sa + p * 32 * BK, 16, (int)a_off[p], kt * (BK * 4), 0, 0);
       }
@@ -739,7 +766,7 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   const int m_fastest = ntm <= ntn ? 1 : 0;
   static const bool use_v1 = getenv("DENSECAP_GEMM_V1") != nullptr;
   // v2 addresses operands through 32-bit buffer offsets
-  const bool fits = CONV ? ((size_t)d.M * d.Cin * 4 < 0xfffffff0ull) : ((size_t)BM * d.K * 4 < 0xfffffff0ull);
+  const bool fits = CONV ? ((size_t)(d.a_rows > d.M ? d.a_rows : d.M) * d.Cin * 4 < CV_PAD && d.Cin <= 2048) : ((size_t)BM * d.K * 4 < 0xfffffff0ull);
   if ((!use_v1 || d.amax_val != nullptr || d.m_dev != nullptr) && fits && (size_t)BN * d.K * 4 < 0xfffffff0ull) {
     if constexpr (TM == 2 && TN == 2) {
       static const bool no_ks = getenv("DENSECAP_GEMM_NOKS") != nullptr;
@@ -838,7 +865,7 @@ int mfma_gemm_ntiles_n(const GemmDesc& d) {
 int mfma_gemm_splitk(const GemmDesc& d) {
   static const bool off = getenv("DENSECAP_GEMM_NOSPLITK") != nullptr || getenv("DENSECAP_GEMM_NOKS") != nullptr ||
                           getenv("DENSECAP_GEMM_V1") != nullptr || getenv("DENSECAP_GEMM_TILE") != nullptr;
-  if ((size_t)128 * d.K * 4 >= 0xfffffff0ull || (d.conv && (size_t)d.M * d.Cin * 4 >= 0xfffffff0ull)) return 1;
+  if ((size_t)128 * d.K * 4 >= 0xfffffff0ull || (d.conv && (size_t)d.M * d.Cin * 4 >= CV_PAD)) return 1;
   if (off || d.amax_val != nullptr || d.rowterm != nullptr || d.m_dev != nullptr) return 1;
   const long tiles = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
   if (tiles >= 128 || d.N < 128) return 1;
@@ -861,7 +888,7 @@ bool mfma_gemm_tail_plan(const GemmDesc& d, int* m_split, int* tail_splitk) {
                           getenv("DENSECAP_GEMM_NOKS") != nullptr || getenv("DENSECAP_GEMM_V1") != nullptr ||
                           getenv("DENSECAP_GEMM_TILE") != nullptr || getenv("DENSECAP_GEMM_V2") != nullptr;
   if (off || d.amax_val != nullptr || d.rowterm != nullptr || d.m_dev != nullptr || d.N < 128 || d.N % 4) return false;
-  if ((size_t)128 * d.K * 4 >= 0xfffffff0ull || (d.conv && (size_t)d.M * d.Cin * 4 >= 0xfffffff0ull)) return false;
+  if ((size_t)128 * d.K * 4 >= 0xfffffff0ull || (d.conv && (size_t)d.M * d.Cin * 4 >= CV_PAD)) return false;
   const int ntm = (d.M + 127) / 128, ntn = (d.N + 127) / 128, nkt = d.K / BK;
   if ((nkt & 1) || nkt < 16 || 256 % ntn) return false;
   const long T = (long)ntm * ntn;
