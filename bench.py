@@ -36,6 +36,16 @@ def main():
                     help="skip the secondary caption-order measurement (keeps rocprof kernel statistics to one workload)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # called directly with --gpus N: start one rank per GPU the way the driver does
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                   "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+
     import numpy as np
     import torch  # device sync + torch.distributed (RCCL); loaded first so one HIP runtime is shared
 
