@@ -62,6 +62,8 @@ struct Lane {
   int pending_capacity = 0;
   float stage_ms[ST_COUNT] = {};
   bool have_times = false;
+  hipStream_t aux = nullptr;            // single-image mode: second half of the decode rows runs here
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 struct ProfEvt { hipEvent_t a, b; double flops; };
@@ -236,7 +238,10 @@ int effective_proposals(const dc_ctx* ctx, int H, int W) {
 int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P) {
   if (L.stream == nullptr) {
     HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking));
     for (auto& e : L.ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
   }
   if (L.H == H && L.W == W && L.P == P && L.arena.p) return DC_OK;
   if (L.arena.p) {
@@ -311,45 +316,85 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P) {
     if (_e != hipSuccess) return ctx->fail(DC_E_HIP, "%s: %s", #expr, hipGetErrorString(_e));           \
   } while (0)
 
-// LanguageModel:sample greedy decode (LanguageModel.lua:293-348) for n rows of `codes` (n_dev: optional
-// device-side row count <= n; rows past it are not computed).
-int lm_sample(dc_ctx* ctx, Lane& L, const float* codes, int n, const int32_t* n_dev, int32_t* seq_out) {
-  hipStream_t s = L.stream;
-  const int E = ctx->E, Hd = ctx->Hd, V1 = ctx->V + 1, T = ctx->T;
-  // image_encoder: Linear(4096,E)+ReLU (:27-30)
-  {
-    GemmDesc g;
-    g.A = codes; g.W = ctx->enc_w; g.bias = ctx->enc_b; g.C = L.enc; g.M = n; g.N = E; g.K = ctx->D; g.ldc = E;
-    g.relu = 1; g.m_dev = n_dev;
-    DCCHK(run_gemm(ctx, g, s, L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0));
+// One contiguous block of decode rows and the stream it runs on.  LSTM rows are independent, so a batch may be cut
+// into blocks that advance on different streams: every row sees exactly the same arithmetic (the K order of a GEMM
+// element does not depend on the tile it falls in), only the kernels of the blocks overlap in time.
+struct LmPart { hipStream_t s; int r0, n; float* ws; size_t ws_floats; };
+
+// LanguageModel:sample greedy decode (LanguageModel.lua:293-348) for the rows of `codes` covered by `parts`
+// (n_dev: optional device-side row count <= n of a single part starting at row 0; rows past it are not computed).
+int lm_sample_parts(dc_ctx* ctx, Lane& L, const float* codes, const LmPart* parts, int nparts, const int32_t* n_dev,
+                    int32_t* seq_out) {
+  const int E = ctx->E, Hd = ctx->Hd, V1 = ctx->V + 1, T = ctx->T, D = ctx->D;
+  const size_t ntn_max = (size_t)(V1 + 63) / 64;        // arg-max partials per row: (value, column) per 64-column tile at most
+  for (int pi = 0; pi < nparts; ++pi) {
+    const LmPart& p = parts[pi];
+    hipStream_t s = p.s;
+    // image_encoder: Linear(4096,E)+ReLU (:27-30)
+    {
+      GemmDesc g;
+      g.A = codes + (size_t)p.r0 * D; g.W = ctx->enc_w; g.bias = ctx->enc_b; g.C = L.enc + (size_t)p.r0 * E;
+      g.M = p.n; g.N = E; g.K = D; g.ldc = E; g.relu = 1; g.m_dev = n_dev;
+      DCCHK(run_gemm(ctx, g, s, p.ws, p.ws ? p.ws_floats : 0));
+    }
+    // step 0: gates = (b + enc.Wx) + 0.Wh ; c0 = 0 (output ignored, no vocab projection needed)
+    {
+      GemmDesc g;
+      g.A = L.enc + (size_t)p.r0 * E; g.W = ctx->wxT; g.bias = ctx->lstm_b; g.C = L.gates + (size_t)p.r0 * 4 * Hd;
+      g.M = p.n; g.N = 4 * Hd; g.K = E; g.ldc = 4 * Hd; g.m_dev = n_dev;
+      DCCHK(run_gemm(ctx, g, s));
+    }
+    KCHK(launch_lstm_pointwise(L.gates + (size_t)p.r0 * 4 * Hd, L.cstate + (size_t)p.r0 * Hd, L.hstate + (size_t)p.r0 * Hd,
+                               p.n, n_dev, Hd, 1, s));
+    KCHK(launch_fill_i32(L.tok + p.r0, V1, p.n, s));  // START token = V+1 (:32,320)
   }
-  // step 0: gates = (b + enc.Wx) + 0.Wh ; c0 = 0 (output ignored, no vocab projection needed)
-  {
-    GemmDesc g;
-    g.A = L.enc; g.W = ctx->wxT; g.bias = ctx->lstm_b; g.C = L.gates; g.M = n; g.N = 4 * Hd; g.K = E; g.ldc = 4 * Hd;
-    g.m_dev = n_dev;
-    DCCHK(run_gemm(ctx, g, s));
-  }
-  KCHK(launch_lstm_pointwise(L.gates, L.cstate, L.hstate, n, n_dev, Hd, 1, s));
-  KCHK(launch_fill_i32(L.tok, V1, n, s));  // START token = V+1 (:32,320)
   for (int t = 0; t < T; ++t) {
-    // gates = (b + Emb[tok].Wx) + h.Wh ; the first term is the precomputed table xg[tok]
-    GemmDesc d;
-    d.A = L.hstate; d.W = ctx->whT; d.C = L.gates; d.M = n; d.N = 4 * Hd; d.K = Hd; d.ldc = 4 * Hd;
-    d.rowterm = ctx->xg; d.rowidx = L.tok; d.rowterm_ld = 4 * Hd; d.m_dev = n_dev;
-    DCCHK(run_gemm(ctx, d, s));
-    KCHK(launch_lstm_pointwise(L.gates, L.cstate, L.hstate, n, n_dev, Hd, 0, s));
-    {  // vocab projection with the row arg-max fused into the GEMM epilogue: logits never reach HBM
-      GemmDesc v;
-      v.A = L.hstate; v.W = ctx->out_w; v.bias = ctx->out_b; v.C = nullptr; v.M = n; v.N = V1; v.K = Hd; v.ldc = V1;
-      v.m_dev = n_dev;
-      v.amax_val = L.logits;
-      const int ntn = mfma_gemm_ntiles_n(v);
-      v.amax_idx = reinterpret_cast<int32_t*>(L.logits + (size_t)n * ntn); v.amax_ld = ntn;
-      DCCHK(run_gemm(ctx, v, s));
-      KCHK(launch_argmax_finalize(v.amax_val, v.amax_idx, n, n_dev, ntn, ntn, L.tok, seq_out, T, t, s));
+    for (int pi = 0; pi < nparts; ++pi) {
+      const LmPart& p = parts[pi];
+      hipStream_t s = p.s;
+      float* gates = L.gates + (size_t)p.r0 * 4 * Hd;
+      float* hstate = L.hstate + (size_t)p.r0 * Hd;
+      // gates = (b + Emb[tok].Wx) + h.Wh ; the first term is the precomputed table xg[tok]
+      GemmDesc d;
+      d.A = hstate; d.W = ctx->whT; d.C = gates; d.M = p.n; d.N = 4 * Hd; d.K = Hd; d.ldc = 4 * Hd;
+      d.rowterm = ctx->xg; d.rowidx = L.tok + p.r0; d.rowterm_ld = 4 * Hd; d.m_dev = n_dev;
+      DCCHK(run_gemm(ctx, d, s));
+      KCHK(launch_lstm_pointwise(gates, L.cstate + (size_t)p.r0 * Hd, hstate, p.n, n_dev, Hd, 0, s));
+      {  // vocab projection with the row arg-max fused into the GEMM epilogue: logits never reach HBM
+        GemmDesc v;
+        v.A = hstate; v.W = ctx->out_w; v.bias = ctx->out_b; v.C = nullptr; v.M = p.n; v.N = V1; v.K = Hd; v.ldc = V1;
+        v.m_dev = n_dev;
+        v.amax_val = L.logits + (size_t)p.r0 * 2 * ntn_max;
+        const int ntn = mfma_gemm_ntiles_n(v);
+        v.amax_idx = reinterpret_cast<int32_t*>(v.amax_val + (size_t)p.n * ntn); v.amax_ld = ntn;
+        DCCHK(run_gemm(ctx, v, s));
+        KCHK(launch_argmax_finalize(v.amax_val, v.amax_idx, p.n, n_dev, ntn, ntn, L.tok + p.r0, seq_out + (size_t)p.r0 * T,
+                                    T, t, s));
+      }
     }
   }
+  return DC_OK;
+}
+
+int lm_sample(dc_ctx* ctx, Lane& L, const float* codes, int n, const int32_t* n_dev, int32_t* seq_out) {
+  const LmPart whole{L.stream, 0, n, L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0};
+  return lm_sample_parts(ctx, L, codes, &whole, 1, n_dev, seq_out);
+}
+
+// Single-image mode (lanes == 1): nothing else is in flight, so the small kernels and partial tile rounds of the 15
+// decode steps leave the chip idle (~25 % of the decode).  The rows are cut into two blocks on two streams; their
+// kernels fill each other's gaps.  Same outputs bit for bit (tests/test_gpu_e2e.py::test_single_lane_mode_parity).
+int lm_sample_two_streams(dc_ctx* ctx, Lane& L, const float* codes, int n, int32_t* seq_out) {
+  const int h = std::min(n, ((n / 2 + 127) / 128) * 128);
+  if (h >= n || L.aux == nullptr) return lm_sample(ctx, L, codes, n, nullptr, seq_out);
+  const size_t wsf = L.splitk_ws ? kSplitkWsFloats / 2 : 0;
+  const LmPart parts[2] = {{L.stream, 0, h, L.splitk_ws, wsf},
+                           {L.aux, h, n - h, L.splitk_ws ? L.splitk_ws + wsf : nullptr, wsf}};
+  HIPCHK(hipEventRecord(L.ev_fork, L.stream));
+  HIPCHK(hipStreamWaitEvent(L.aux, L.ev_fork, 0));
+  DCCHK(lm_sample_parts(ctx, L, codes, parts, 2, nullptr, seq_out));
+  HIPCHK(hipEventRecord(L.ev_join, L.aux));
+  HIPCHK(hipStreamWaitEvent(L.stream, L.ev_join, 0));
   return DC_OK;
 }
 
@@ -400,7 +445,12 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int img_on_device, b
   HIPCHK(hipEventRecord(L.ev[6], s));
   const bool survivors_only = ctx->captions_after_final_nms && !features_only;
   // ---- language model (reference order: all P proposals, DenseCapModel.lua:127-162) -----------------
-  if (!features_only && !survivors_only) DCCHK(lm_sample(ctx, L, L.codes, P, nullptr, L.seq));
+  if (!features_only && !survivors_only) {
+    static const bool no_split = getenv("DENSECAP_NO_DECODE_SPLIT") != nullptr;
+    // per-launch HIP-event profiling wants kernels that do not overlap: keep one stream while it is on
+    if (ctx->serial_mode && !ctx->prof && !no_split && P >= 256) DCCHK(lm_sample_two_streams(ctx, L, L.codes, P, L.seq));
+    else DCCHK(lm_sample(ctx, L, L.codes, P, nullptr, L.seq));
+  }
   HIPCHK(hipEventRecord(L.ev[7], s));
   // ---- final NMS + gather (DenseCapModel.lua:261-275) ----------------------------------------------
   KCHK(launch_xcycwh_to_x1y1x2y2(L.final_boxes, L.final_xyxy, P, s));
@@ -477,7 +527,10 @@ int lane0_stream(dc_ctx* ctx, hipStream_t* s) {
   Lane& L = lane0(ctx);
   if (L.stream == nullptr) {
     HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking));
     for (auto& e : L.ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
   }
   *s = L.stream;
   return DC_OK;
@@ -517,6 +570,9 @@ void dc_destroy(dc_ctx* ctx) {
     if (L.arena.p) hipFree(L.arena.p);
     if (L.host_stage) hipHostFree(L.host_stage);
     for (auto& ev : L.ev) if (ev) hipEventDestroy(ev);
+    if (L.ev_fork) hipEventDestroy(L.ev_fork);
+    if (L.ev_join) hipEventDestroy(L.ev_join);
+    if (L.aux) hipStreamDestroy(L.aux);
     if (L.stream) hipStreamDestroy(L.stream);
   }
   for (void* p : ctx->owned) hipFree(p);

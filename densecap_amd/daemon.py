@@ -92,6 +92,7 @@ def main(argv=None):
         from . import t7
         weights = t7.weights_from_checkpoint(t7.load(opt.checkpoint))
     model = DenseCapModel(weights, device=opt.gpu)
+    model.setLanes(1)      # one image at a time, like the reference: single-image mode has the lowest latency
     model.evaluate()
     model.setTestArgs(num_proposals=opt.num_proposals, rpn_nms_thresh=opt.rpn_nms_thresh,
                       final_nms_thresh=opt.final_nms_thresh)

@@ -74,6 +74,7 @@ def main(argv=None):
             raise SystemExit("checkpoint %s not found (use -synthetic_weights 1 for random weights)" % opt.checkpoint)
         weights = t7.weights_from_checkpoint(t7.load(opt.checkpoint))
     model = DenseCapModel(weights, device=opt.gpu)
+    model.setLanes(1)      # one image at a time, like the reference: single-image mode has the lowest latency
     model.setTestArgs(rpn_nms_thresh=opt.rpn_nms_thresh, final_nms_thresh=opt.final_nms_thresh,
                       num_proposals=opt.num_proposals)
     model.evaluate()

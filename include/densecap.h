@@ -123,9 +123,10 @@ int dc_forward_test(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_
 int dc_forward_batch(dc_ctx* ctx, const float* imgs, int n, int H, int W, int imgs_on_device,
                      dc_result* outs);
 /* Number of lanes (HIP streams with private workspaces, 1..4, default 3) dc_forward_batch
- * pipelines images over.  1 = strictly serial kernels (what per-kernel profiles and lowest single-image
- * latency want; it also enables a K-split of each layer's last partial round of tiles, i.e. a different but
- * fixed fp32 summation order).  Results are bit-identical for a given lanes setting however images are batched. */
+ * pipelines images over.  1 = single-image mode (lowest latency for one image at a time): a layer's last
+ * partial round of tiles is K-split over the idle CUs (a different but fixed fp32 summation order) and the decode
+ * rows advance as two blocks on two streams (same arithmetic per row); per-kernel profiling (dc_mfma_profile)
+ * keeps every kernel on one stream.  Results are bit-identical for a given lanes setting however images are batched. */
 int dc_set_lanes(dc_ctx* ctx, int lanes);
 /* Caption order. 0 (default) = the reference's order: LanguageModel:sample runs on all num_proposals
  * RoIs and the final NMS then keeps K rows (DenseCapModel.lua:127-162,261-275).  1 = run the final NMS
