@@ -63,7 +63,8 @@ struct Lane {
   float stage_ms[ST_COUNT] = {};
   bool have_times = false;
   hipStream_t aux = nullptr;            // single-image mode: second half of the decode rows runs here
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t aux2 = nullptr;           // single-image mode: the final NMS runs here, beside the decode
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
 };
 
 struct ProfEvt { hipEvent_t a, b; double flops; };
@@ -239,6 +240,9 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P) {
   if (L.stream == nullptr) {
     HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&L.aux2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&L.ev_fork2, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&L.ev_join2, hipEventDisableTiming));
     for (auto& e : L.ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
@@ -444,22 +448,34 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int img_on_device, b
                           ctx->D, s));
   HIPCHK(hipEventRecord(L.ev[6], s));
   const bool survivors_only = ctx->captions_after_final_nms && !features_only;
+  static const bool no_split = getenv("DENSECAP_NO_DECODE_SPLIT") != nullptr;
+  // single-image mode, reference order: decode (two row blocks on two streams) and final NMS (a third stream) are
+  // independent consumers of the heads' outputs.  Per-launch HIP-event profiling wants kernels that do not overlap:
+  // everything stays on one stream while it is on.
+  const bool side_streams = ctx->serial_mode && !ctx->prof && !no_split && !features_only && !survivors_only && P >= 256;
+  hipStream_t sn = side_streams ? L.aux2 : s;       // stream of the final NMS
+  if (side_streams) {
+    HIPCHK(hipEventRecord(L.ev_fork2, s));
+    HIPCHK(hipStreamWaitEvent(L.aux2, L.ev_fork2, 0));
+  }
   // ---- language model (reference order: all P proposals, DenseCapModel.lua:127-162) -----------------
   if (!features_only && !survivors_only) {
-    static const bool no_split = getenv("DENSECAP_NO_DECODE_SPLIT") != nullptr;
-    // per-launch HIP-event profiling wants kernels that do not overlap: keep one stream while it is on
-    if (ctx->serial_mode && !ctx->prof && !no_split && P >= 256) DCCHK(lm_sample_two_streams(ctx, L, L.codes, P, L.seq));
+    if (side_streams) DCCHK(lm_sample_two_streams(ctx, L, L.codes, P, L.seq));
     else DCCHK(lm_sample(ctx, L, L.codes, P, nullptr, L.seq));
   }
   HIPCHK(hipEventRecord(L.ev[7], s));
   // ---- final NMS + gather (DenseCapModel.lua:261-275) ----------------------------------------------
-  KCHK(launch_xcycwh_to_x1y1x2y2(L.final_boxes, L.final_xyxy, P, s));
+  KCHK(launch_xcycwh_to_x1y1x2y2(L.final_boxes, L.final_xyxy, P, sn));
   if (ctx->final_nms_thresh > 0.f) {
     KCHK(launch_nms(L.nms, L.final_xyxy, L.obj, nullptr, P, L.count1, ctx->final_nms_thresh, -1, L.picks2, L.count2,
-                    s));
+                    sn));
   } else {
     // DenseCapModel.lua:261: no final NMS when final_nms_thresh <= 0 -> all RoIs, in RPN order
-    KCHK(launch_iota_count(L.picks2, L.count2, L.count1, P, s));
+    KCHK(launch_iota_count(L.picks2, L.count2, L.count1, P, sn));
+  }
+  if (side_streams) {
+    HIPCHK(hipEventRecord(L.ev_join2, L.aux2));
+    HIPCHK(hipStreamWaitEvent(s, L.ev_join2, 0));
   }
   KCHK(launch_gather_rows(L.final_boxes, L.picks2, L.count2, P, 4, L.out_boxes, s));
   KCHK(launch_gather_rows(L.obj, L.picks2, L.count2, P, 1, L.out_scores, s));
@@ -528,6 +544,9 @@ int lane0_stream(dc_ctx* ctx, hipStream_t* s) {
   if (L.stream == nullptr) {
     HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&L.aux2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&L.ev_fork2, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&L.ev_join2, hipEventDisableTiming));
     for (auto& e : L.ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
@@ -572,7 +591,10 @@ void dc_destroy(dc_ctx* ctx) {
     for (auto& ev : L.ev) if (ev) hipEventDestroy(ev);
     if (L.ev_fork) hipEventDestroy(L.ev_fork);
     if (L.ev_join) hipEventDestroy(L.ev_join);
+    if (L.ev_fork2) hipEventDestroy(L.ev_fork2);
+    if (L.ev_join2) hipEventDestroy(L.ev_join2);
     if (L.aux) hipStreamDestroy(L.aux);
+    if (L.aux2) hipStreamDestroy(L.aux2);
     if (L.stream) hipStreamDestroy(L.stream);
   }
   for (void* p : ctx->owned) hipFree(p);
