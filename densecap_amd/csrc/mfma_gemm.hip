@@ -20,6 +20,8 @@
 // tile t+1 are issued before the MFMAs of tile t and written to the other LDS buffer after.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -374,10 +376,12 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
   __builtin_amdgcn_sched_barrier(0);
   read_frag(0, 0, 0);
 
-  int st = 0;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int st1 = st == NS - 1 ? 0 : st + 1;
-    const int stn = st == 0 ? NS - 1 : st - 1;     // stage of tile kt-1 == stage of tile kt+NS-1
+  // One K-tile whose ring stage ST is a compile-time constant: every LDS address of its fragment reads and LDS-DMA
+  // destinations is an immediate (the ring walk costs no address arithmetic between the MFMAs).
+  auto body = [&](int kt, auto ST) __attribute__((always_inline)) {
+    constexpr int st = decltype(ST)::value;
+    constexpr int st1 = st == NS - 1 ? 0 : st + 1;
+    constexpr int stn = st == 0 ? NS - 1 : st - 1;     // stage of tile kt-1 == stage of tile kt+NS-1
     group_with(0, TM + TN, [&](int k) { read_piece(st, 1, 1, k); });
     group_with(1, TM + TN, [&](int k) { read_piece(st, 2, 0, k); });
     // ---- mid-tile rendezvous: tile kt+1 has landed everywhere; the stage of tile kt-1 is free
@@ -394,8 +398,18 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
     });
     const bool next = kt + 1 < nkt;
     group_with(1, TM + TN, [&](int k) { if (next) read_piece(st1, 0, 0, k); });
-    st = st1;
-  }
+  };
+  auto ring_round = [&](int kt, bool guarded) __attribute__((always_inline)) {
+    if (!guarded || kt + 0 < nkt) body(kt + 0, std::integral_constant<int, 0>{});
+    if (!guarded || kt + 1 < nkt) body(kt + 1, std::integral_constant<int, 1>{});
+    if (!guarded || kt + 2 < nkt) body(kt + 2, std::integral_constant<int, 2>{});
+    if constexpr (NS == 4) {
+      if (!guarded || kt + 3 < nkt) body(kt + 3, std::integral_constant<int, 3>{});
+    }
+  };
+  int kt = 0;
+  for (; kt + NS <= nkt; kt += NS) ring_round(kt, false);
+  if (kt < nkt) ring_round(kt, true);
 
   if constexpr (!CONV) {
     if (d.amax_val != nullptr) {
