@@ -9,6 +9,8 @@ REPO=$(pwd)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
+# one stream throughout (the un-timed setup/warm-up images would otherwise use the two-stream decode of single-image mode)
+export DENSECAP_NO_DECODE_SPLIT=1
 BENCH="python $REPO/bench.py --lanes 1 --no-cpu-baseline --no-alt-pass"
 run() {  # name, bench args, rocprof args...
   local name=$1 args=$2; shift 2
@@ -22,5 +24,6 @@ run fetch "--steps 3 --warmup 1" --kernel-trace --pmc FETCH_SIZE
 run write "--steps 3 --warmup 1" --kernel-trace --pmc WRITE_SIZE
 run mfma "--steps 3 --warmup 1" --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT
 cd "$REPO"
+unset DENSECAP_NO_DECODE_SPLIT
 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 ls -la "$OUT"
