@@ -104,3 +104,42 @@ def test_c_harness_runs_on_gpu(tmp_path):
     p = subprocess.run([exe, "224", "288", "100", "3"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr
     assert "HARNESS OK" in p.stdout and "expected error before load_weights" in p.stdout
+
+
+def _prototypes(text):
+    """{name: normalised 'ret name(args)'} of the dc_* prototypes in a C declaration block."""
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(dc_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        norm = lambda t: re.sub(r"\s*\*\s*", "* ", re.sub(r"\s+", " ", t)).strip()
+        out[name] = "%s %s(%s)" % (norm(ret), name, norm(args))
+    return out
+
+
+def test_lua_ffi_cdef_matches_the_header():
+    """lua/densecap_hip.lua cannot be executed here (no LuaJIT): at least every prototype in its ffi.cdef must be
+    the header's, character for character after whitespace normalisation, and the structs must list the same fields."""
+    hdr = open(os.path.join(ROOT, "include", "densecap.h")).read()
+    lua = open(os.path.join(ROOT, "lua", "densecap_hip.lua")).read()
+    cdef = re.search(r"ffi\.cdef\[\[(.*?)\]\]", lua, flags=re.S).group(1)
+    hp, lp = _prototypes(hdr), _prototypes(cdef)
+    assert len(lp) >= 10
+    for name, proto in lp.items():
+        assert name in hp, "%s is not declared in densecap.h" % name
+        assert proto == hp[name], "cdef drifted:\n  lua: %s\n  hdr: %s" % (proto, hp[name])
+    # struct fields (order matters for the ABI)
+    def fields(text, struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), re.sub(r"/\*.*?\*/", "", text, flags=re.S),
+                         flags=re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            first, *rest = decl.split(",")
+            names.append(re.sub(r"\[.*?\]", "", first.split()[-1].lstrip("*")))
+            names += [re.sub(r"\[.*?\]", "", r.strip().lstrip("*")) for r in rest]
+        return names
+    for st in ("dc_weights", "dc_result"):
+        assert fields(cdef, st) == fields(hdr, st), st
