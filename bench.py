@@ -195,6 +195,21 @@ def main():
         except Exception:
             pass
         out["roofline"]["overlapped_effective_tflops"] = (prof_all_flops / elapsed / 1e12) if prof_all_flops else None
+        # HBM-side stages named by BASELINE.json (bilinear sampler, NMS): algorithmic bytes / stage time of
+        # the serial pass; the PMC-measured HBM bytes of the same kernels are in profiles/r01_pmc_summary.json
+        fh, fw = (H + 15) // 16, (W + 15) // 16
+        A = 12 * fh * fw
+        roi_bytes = 4.0 * 512 * (fh * fw + P * 49) + 16.0 * P
+        nms_bytes = 20.0 * A + 8.0 * P
+        hb = {}
+        if stage.get("bilinear_roi_pool", 0) > 0:
+            hb["bilinear_roi_pool"] = {"algorithmic_bytes": roi_bytes, "ms": stage["bilinear_roi_pool"],
+                                       "GBps": roi_bytes / (stage["bilinear_roi_pool"] * 1e-3) / 1e9, "peak_GBps": 8000.0}
+        if stage.get("rpn_nms", 0) > 0:
+            hb["rpn_nms"] = {"algorithmic_bytes": nms_bytes, "ms": stage["rpn_nms"],
+                             "GBps": nms_bytes / (stage["rpn_nms"] * 1e-3) / 1e9, "peak_GBps": 8000.0,
+                             "note": "latency-bound by construction (greedy dependency chain), see DESIGN.md 4.2"}
+        out["hbm_stages"] = hb
         out["lanes"] = args.lanes
         if alt is not None:
             out["value_captions_after_final_nms"] = alt   # same outputs, decode only final-NMS survivors
