@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void bilinear_roi_pool_kernel(const float* __r
     }
     __syncthreads();
     const int items = npts * C4;
+#pragma unroll 4
     for (int it = threadIdx.x; it < items; it += 256) {
       const int p = it / C4, c4 = it - p * C4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(256) void bilinear_roi_pool_kernel(const float* __r
                            __fmul_rn(w11, br[e]));
       }
       if (out_layout == 1) {
-        *reinterpret_cast<f32x4*>(out + ((size_t)b * npts + p) * C + (size_t)c4 * 4) = v;
+        // written once, consumed by fc6 much later: keep it out of the L2 that holds the feature map
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + ((size_t)b * npts + p) * C + (size_t)c4 * 4));
       } else {
         const int i = p / WW, j = p - i * WW;
 #pragma unroll
