@@ -24,13 +24,16 @@ __global__ __launch_bounds__(256) void bilinear_roi_pool_kernel(const float* __r
                                                                 const float* __restrict__ boxes, int B,
                                                                 const int32_t* __restrict__ B_dev, float img_h,
                                                                 float img_w, int HH, int WW, float* __restrict__ out,
-                                                                int out_layout) {
+                                                                int out_layout, int split) {
   __shared__ int s_off[ROI_MAX_PTS][4];     // element offset of each tap (or -1 when outside the map)
   __shared__ float s_w[ROI_MAX_PTS][4];     // w00, w01, w10, w11
   const int C4 = C >> 2;
   const int npts = HH * WW;
   const int b_live = B_dev ? min(*B_dev, B) : B;
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+  // `split` workgroups share a box (each takes a contiguous slice of its (point, channel-chunk) items): with few boxes
+  // the kernel is a latency chain of ~25 dependent load rounds per thread, not a bandwidth problem
+  for (int v = blockIdx.x; v < B * split; v += gridDim.x) {
+    const int b = v / split, part = v - b * split;
     const bool live = b < b_live;
     __syncthreads();
     if (live && threadIdx.x < npts) {
@@ -68,8 +71,9 @@ __global__ __launch_bounds__(256) void bilinear_roi_pool_kernel(const float* __r
     }
     __syncthreads();
     const int items = npts * C4;
+    const int it_lo = (int)((long)items * part / split), it_hi = (int)((long)items * (part + 1) / split);
 #pragma unroll 4
-    for (int it = threadIdx.x; it < items; it += 256) {
+    for (int it = it_lo + threadIdx.x; it < it_hi; it += 256) {
       const int p = it / C4, c4 = it - p * C4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (live) {
@@ -104,8 +108,11 @@ hipError_t launch_bilinear_roi_pool(const float* feat_hwc, int h, int w, int C, 
                                     const int32_t* B_dev, int img_h, int img_w, int HH, int WW, float* out,
                                     int out_layout, hipStream_t s) {
   if (C % 4 || B <= 0 || HH * WW > ROI_MAX_PTS) return hipErrorInvalidValue;
-  const int grid = B < 256 * 16 ? B : 256 * 16;
+  int split = 2048 / B;                       // aim at ~8 workgroups per CU
+  split = split < 1 ? 1 : (split > 8 ? 8 : split);
+  const long want = (long)B * split;
+  const int grid = want < 256 * 16 ? (int)want : 256 * 16;
   hipLaunchKernelGGL(bilinear_roi_pool_kernel, dim3((unsigned)grid), dim3(256), 0, s, feat_hwc, h, w, C, boxes, B,
-                     B_dev, (float)img_h, (float)img_w, HH, WW, out, out_layout);
+                     B_dev, (float)img_h, (float)img_w, HH, WW, out, out_layout, split);
   return hipGetLastError();
 }
