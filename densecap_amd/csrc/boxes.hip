@@ -537,7 +537,13 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // window k covers sorted rows [win_start(k), win_start(k+1))
 // windows: 4096 boxes, then 32768 at a time (the scan kernel's LDS bit set holds 32768).  The pick budget is
 // normally met inside the first window; every further window costs three (empty) launches.
-static int win_start(int k) { return k == 0 ? 0 : NMS_WIN0 + (k - 1) * 32768; }
+// With a large pick budget (> 1024, e.g. 2000 proposals over 36,720 anchors) the picks reach past the first window;
+// an intermediate 8192-row window then spares the full 32768-row triangle (graded = true).
+static int win_start(int k, bool graded = false) {
+  if (k == 0) return 0;
+  if (!graded) return NMS_WIN0 + (k - 1) * 32768;
+  return k == 1 ? NMS_WIN0 : NMS_WIN0 + 8192 + (k - 2) * 32768;
+}
 static size_t nms_mask_words(int n) {
   size_t best = 0;
   for (int k = 0; win_start(k) < n; ++k) {
@@ -590,9 +596,10 @@ hipError_t launch_nms(NmsWorkspace& ws, const float* boxes, const float* scores,
   hipLaunchKernelGGL(nms_bucket_rank_kernel, dim3(nb), dim3(256), 0, s, ws.tmp_key, ws.tmp_idx, boxes, n, n_dev, ws.off,
                      ws.hist, ws.order, ws.sboxes, ws.sarea);
   NmsState* st = reinterpret_cast<NmsState*>(ws.state);
+  const bool graded = max_boxes > 1024 && n > NMS_WIN0 + 8192;
   for (int k = 0;; ++k) {
-    const int r0 = win_start(k);
-    const int r1 = std::min(n, win_start(k + 1));
+    const int r0 = win_start(k, graded);
+    const int r1 = std::min(n, win_start(k + 1, graded));
     const int rows = std::max(r1 - r0, 0);
     const int wchunks = (rows + 63) / 64;
     if (rows > 0) {

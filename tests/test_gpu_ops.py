@@ -247,3 +247,23 @@ def test_nms_nan_and_inf_scores(ctx):
     b[rng.choice(2000, 20, replace=False), 4] = -np.inf
     for maxb in (None, 150):
         assert ops.nms(ctx, b, 0.5, maxb).tolist() == O.nms(b, 0.5, maxb).tolist()
+
+
+@pytest.mark.parametrize("maxb", [1000, 2500, None])
+def test_nms_clustered_boxes_cross_every_window(ctx, maxb):
+    """Near-duplicate clusters: the pick budget is met only deep into the sorted list, so the suppression state has to
+    be carried across the 4096-row window, the intermediate 8192-row window of large budgets, and the 32768-row ones."""
+    from densecap_amd import ops
+    from oracle import densecap_oracle as O
+    rng = np.random.default_rng(17)
+    ncl, per = 3000, 10
+    cxy = rng.uniform(0, 4000, (ncl, 1, 2)); wh = rng.uniform(30, 60, (ncl, 1, 2))
+    jit = rng.uniform(-2, 2, (ncl, per, 2))
+    xy = cxy + jit
+    b = np.concatenate([xy, xy + wh + rng.uniform(-2, 2, (ncl, per, 2))], 2).reshape(-1, 4)
+    s = rng.uniform(0, 1, (ncl * per, 1))
+    b5 = np.concatenate([b, s], 1).astype(np.float32)
+    got = ops.nms(ctx, b5, 0.5, maxb)
+    ref = O.nms(b5, 0.5, maxb)
+    assert got.tolist() == ref.tolist()
+    assert len(ref) > 900
