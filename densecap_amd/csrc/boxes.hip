@@ -460,10 +460,21 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const u64* __restrict__ m
       // (pick, later word) pairs spread over all 256 threads: independent loads, LDS atomic OR
       const int nlater = nw - (w + 1);
       const int total = npick * nlater;
-      for (int t = tid; t < total; t += 256) {
-        const int p = t / nlater, v = w + 1 + (t - p * nlater);
-        const u64 m = mask[(size_t)s_rows[p] * wwords + v];
-        if (m) atomicOr(&removed[v], m);
+      // all loads of a batch are issued before the first OR: one L2 round trip per 8 items instead of one per item
+      for (int t0 = tid; t0 < total; t0 += 256 * 8) {
+        u64 m[8];
+        int vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = t0 + u * 256;
+          const bool in = t < total;
+          const int p = in ? t / nlater : 0;
+          vv[u] = w + 1 + (in ? t - p * nlater : 0);
+          m[u] = in ? mask[(size_t)s_rows[p] * wwords + vv[u]] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (m[u]) atomicOr(&removed[vv[u]], m[u]);
       }
     }
     __syncthreads();
