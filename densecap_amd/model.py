@@ -83,6 +83,25 @@ class DenseCapModel:
         check(self.ctx.h, self.lib.dc_set_lanes(self.ctx.h, int(lanes)), "dc_set_lanes")
         return self
 
+    def autotuneLanes(self, dev_ptr, n, H, W, candidates=(2, 3, 4), reps=2):
+        """Pick the number of lanes (>= 2: all give bit-identical results, only the overlap of the images' kernels
+        changes) that gives the best throughput on THIS device for n resident images; which count wins differs
+        between otherwise identical GPUs (measured: 3 lanes 171 vs 2 lanes 162 images/s on one box, 160 vs 167 on
+        another).  Returns {lanes: images/s}; the best one is left set."""
+        import time
+        rates = {}
+        for lanes in candidates:
+            self.setLanes(lanes)
+            self.forward_batch_device(dev_ptr, min(n, lanes), H, W)          # lane workspaces exist before timing
+            best = 0.0
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                self.forward_batch_device(dev_ptr, n, H, W)
+                best = max(best, n / (time.perf_counter() - t0))
+            rates[lanes] = best
+        self.setLanes(max(rates, key=rates.get))
+        return rates
+
     def setCaptionOrder(self, after_final_nms):
         """False (default): decode all proposals then NMS, as the reference does.  True: final NMS first,
         decode only the survivors (bit-identical outputs, less LSTM work)."""

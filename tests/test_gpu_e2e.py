@@ -346,3 +346,25 @@ def test_randomised_shapes_and_thresholds_match_oracle():
                        text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "FUZZ OK: 10/10" in p.stdout
+
+
+def test_lane_count_is_a_pure_scheduling_knob(model, weights):
+    """Any lanes >= 2 must give bit-identical results (bench.py picks the count by an untimed trial)."""
+    from densecap_amd.weights import make_synthetic_image
+    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=200)
+    imgs = np.stack([make_synthetic_image(224, 288, 40 + s) for s in range(5)])
+    dev = model.ctx.to_device(imgs)
+    ref = None
+    for lanes in (2, 3, 4):
+        model.setLanes(lanes)
+        out = model.forward_batch_device(dev.ptr, 5, 224, 288)
+        if ref is None:
+            ref = out
+        else:
+            for (b0, s0, t0), (b1, s1, t1) in zip(ref, out):
+                np.testing.assert_array_equal(b0, b1); np.testing.assert_array_equal(s0, s1)
+                np.testing.assert_array_equal(t0, t1)
+    rates = model.autotuneLanes(dev.ptr, 5, 224, 288, reps=1)
+    assert set(rates) == {2, 3, 4} and all(v > 0 for v in rates.values())
+    model.setLanes(3)
+    dev.free()
