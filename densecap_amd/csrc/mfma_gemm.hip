@@ -199,8 +199,13 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmDesc d, int ntm, int
 //    fragments of tile t+1 are fetched from LDS while groups 2-3 of tile t execute: the MFMA
 //    pipe never waits for an LDS round trip.
 // =========================================================================================
-template <int TM, int TN, bool CONV, int NS>
+// AMAX: the fused row arg-max variant (vocab projection + torch.max).  Its MFMAs take the two operands in swapped
+// roles, so each 32x32 accumulator block is held TRANSPOSED: a lane owns one output row m (lane&31) and its registers
+// walk 16 of the block's 32 columns n.  The row arg-max is then a compare chain inside the lane -- no LDS transpose.
+// Each element is the same fp32 fmaf chain over k either way.
+template <int TM, int TN, bool CONV, int NS, bool AMAX = false>
 __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
+  static_assert(!(AMAX && CONV), "arg-max epilogue is for dense GEMMs");
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int PA = BM / 32, PB = BN / 32;
   constexpr int STAGE = (BM + BN) * BK;  // floats per ring stage
@@ -350,7 +355,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
   constexpr int NM = 4 * TM * TN;        // MFMAs per group
   auto mfma_slot = [&](int set, int q) {
     const int e = q / (TM * TN), rem = q % (TM * TN), i = rem / TN, j = rem % TN;
-    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
+    if constexpr (AMAX) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[set][j][e], fa[set][i][e], acc[i][j], 0, 0, 0);
+    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
   };
   // one MFMA group with `nside` side operations spread evenly between its MFMAs (pinned order)
   auto group_with = [&](int set, int nside, auto&& side) {
@@ -411,55 +417,59 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
   for (; kt + NS <= nkt; kt += NS) ring_round(kt, false);
   if (kt < nkt) ring_round(kt, true);
 
-  if constexpr (!CONV) {
-    if (d.amax_val != nullptr) {
-      // ---- fused row arg-max epilogue (vocab projection + torch.max, LanguageModel.lua:326-329) ----
-      // The biased tile is transposed through LDS (row stride BN+1: conflict-free column writes),
-      // then two threads scan each row's 2 x BN/2 columns sequentially.  Ties: lower column (first max).
-      __syncthreads();                      // everyone is done reading the operand ring
-      constexpr int LDT = BN + 1;
-      float* tile = smem;                   // [BM][LDT]
+  if constexpr (AMAX) {
+    // ---- fused row arg-max epilogue (vocab projection + torch.max, LanguageModel.lua:326-329) ----
+    // acc[i][j] is the transposed block: this lane's row is m = m0 + wm*32*TM + i*32 + (lane&31); register e is column
+    // n = n0 + wn*32*TN + j*32 + 8*(e>>2) + 4*hsel + (e&3), ascending in (j, e).  Ties: lower column (first max).
+    __syncthreads();                        // everyone is done reading the operand ring (reused below)
+    float* red_v = smem;                    // [2 (wn)][BM]
+    int* red_i = reinterpret_cast<int*>(smem + 2 * BM);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int cl = wn * 32 * TN + j * 32 + r;
-        const int n = n0 + cl;
-        const float bvv = (d.bias != nullptr && n < d.N) ? d.bias[n] : 0.f;
+    for (int i = 0; i < TM; ++i) {
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int row = wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hsel;
-            tile[row * LDT + cl] = n < d.N ? acc[i][j][e] + bvv : -INFINITY;
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int nb = n0 + wn * 32 * TN + j * 32 + 8 * q4 + 4 * hsel;     // 4 consecutive columns, 16-byte aligned
+          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+          if (d.bias != nullptr) {
+            if (nb + 3 < d.N) bv = *reinterpret_cast<const f32x4*>(d.bias + nb);
+            else
+#pragma unroll
+              for (int c = 0; c < 4; ++c) bv[c] = nb + c < d.N ? d.bias[nb + c] : 0.f;
           }
-      }
-      __syncthreads();
-      {
-        constexpr int TPR = 256 / BM;       // threads per row (2 or 4)
-        constexpr int CPT = BN / TPR;       // columns per thread
-        const int row = tid / TPR, part = tid % TPR;
-        const float* p = tile + row * LDT + part * CPT;
-        float best = p[0];
-        int bi = 0;
-#pragma unroll 8
-        for (int c = 1; c < CPT; ++c) {
-          const float v = p[c];
-          if (v > best) { best = v; bi = c; }
-        }
-        bi += n0 + part * CPT;
 #pragma unroll
-        for (int o = 1; o < TPR; o <<= 1) {   // partner threads hold higher columns: strict '>' keeps the first max
-          const float ov = __shfl_xor(best, o, 64);
-          const int oi = __shfl_xor(bi, o, 64);
-          if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+          for (int c = 0; c < 4; ++c) {
+            const float v = nb + c < d.N ? acc[i][j][q4 * 4 + c] + bv[c] : -INFINITY;
+            if (v > best) { best = v; bi = nb + c; }
+          }
         }
-        const int m = m0 + row;
-        if (part == 0 && m < Meff) {
-          d.amax_val[(size_t)m * d.amax_ld + tile_n] = best;
-          d.amax_idx[(size_t)m * d.amax_ld + tile_n] = bi;
-        }
+      // the other lane half holds the interleaved columns of the same row
+      const float ov = __shfl_xor(best, 32, 64);
+      const int oi = __shfl_xor(bi, 32, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      if (hsel == 0) {
+        const int row = wm * 32 * TM + i * 32 + r;
+        red_v[wn * BM + row] = best;
+        red_i[wn * BM + row] = bi;
       }
-      return;
     }
+    __syncthreads();
+    if (tid < BM) {
+      float best = red_v[tid];
+      int bi = red_i[tid];
+      const float ov = red_v[BM + tid];
+      const int oi = red_i[BM + tid];
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      const int m = m0 + tid;
+      if (m < Meff) {
+        d.amax_val[(size_t)m * d.amax_ld + tile_n] = best;
+        d.amax_idx[(size_t)m * d.amax_ld + tile_n] = bi;
+      }
+    }
+    return;
   }
   // ---- epilogue: bias (+ gathered row term) + ReLU, channels-last store -------------------
   // C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -803,6 +813,21 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
       }
     }
     if (d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0) return hipErrorInvalidValue;   // K-split kernel features
+    if constexpr (!CONV) {
+      if (d.amax_val != nullptr) {
+        const size_t lds3 = (size_t)3 * (BM + BN) * BK * sizeof(float);
+        static bool attr_amax = false;
+        if (!attr_amax) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, false, 3, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+          if (e != hipSuccess) return e;
+          attr_amax = true;
+        }
+        hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, false, 3, true>), dim3(ntm * ntn), dim3(256), lds3, stream, d, ntm,
+                           ntn, m_fastest);
+        return hipGetLastError();
+      }
+    }
     static const int ns_env = getenv("DENSECAP_GEMM_STAGES") ? atoi(getenv("DENSECAP_GEMM_STAGES")) : 0;
     const int ns = ns_env == 4 ? 4 : 3;
     const size_t lds = (size_t)ns * (BM + BN) * BK * sizeof(float);
