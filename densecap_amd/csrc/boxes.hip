@@ -92,7 +92,16 @@ __global__ void xcycwh_to_x1y1x2y2_kernel(const float* __restrict__ boxes, float
   *reinterpret_cast<f32x4*>(out + (size_t)i * 4) = f32x4{o0, o1, o2, o3};
 }
 
-// nn.BoxIoU (BoxIoU.lua:40-73); convention 1 = NMS inline (+1) form on xcycwh inputs.
+// nn.BoxIoU (BoxIoU.lua:40-73).  convention 0 = the module as written ((w-1)/2 corners, area w*h, no +1);
+// 1 = box_utils.nms inline form ((w-1)/2 corners, +1 on every extent; box_utils.lua:178-181,219-227);
+// 2 = legacy_half_w: the module's original converter (BoxIoU.lua:15-37, commented out there): corners xc -/+ w/2,
+//     area w*h, no +1 -- the convention test/BoxIoU_test.lua:13-94 pins.
+__device__ __forceinline__ void corners_half_w(float xc, float yc, float w, float h, float& x0, float& y0, float& x1,
+                                               float& y1) {
+  const float hw = __fdiv_rn(w, 2.f), hh = __fdiv_rn(h, 2.f);
+  x0 = __fadd_rn(__fmul_rn(hw, -1.f), xc); x1 = __fadd_rn(hw, xc);
+  y0 = __fadd_rn(__fmul_rn(hh, -1.f), yc); y1 = __fadd_rn(hh, yc);
+}
 __global__ void box_iou_kernel(const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ out,
                                int B1, int B2, int convention) {
   const size_t total = (size_t)B1 * B2;
@@ -102,13 +111,19 @@ __global__ void box_iou_kernel(const float* __restrict__ b1, const float* __rest
     const f32x4 p = *reinterpret_cast<const f32x4*>(b1 + (size_t)i * 4);
     const f32x4 q = *reinterpret_cast<const f32x4*>(b2 + (size_t)j * 4);
     float px1, py1, px2, py2, qx1, qy1, qx2, qy2;
-    corners(p[0], p[1], p[2], p[3], px1, py1, px2, py2);
-    corners(q[0], q[1], q[2], q[3], qx1, qy1, qx2, qy2);
-    const float one = convention ? 1.f : 0.f;
-    const float a1 = convention ? __fmul_rn(__fadd_rn(__fsub_rn(px2, px1), 1.f), __fadd_rn(__fsub_rn(py2, py1), 1.f))
-                                : __fmul_rn(p[2], p[3]);
-    const float a2 = convention ? __fmul_rn(__fadd_rn(__fsub_rn(qx2, qx1), 1.f), __fadd_rn(__fsub_rn(qy2, qy1), 1.f))
-                                : __fmul_rn(q[2], q[3]);
+    if (convention == 2) {
+      corners_half_w(p[0], p[1], p[2], p[3], px1, py1, px2, py2);
+      corners_half_w(q[0], q[1], q[2], q[3], qx1, qy1, qx2, qy2);
+    } else {
+      corners(p[0], p[1], p[2], p[3], px1, py1, px2, py2);
+      corners(q[0], q[1], q[2], q[3], qx1, qy1, qx2, qy2);
+    }
+    const bool plus1 = convention == 1;
+    const float one = plus1 ? 1.f : 0.f;
+    const float a1 = plus1 ? __fmul_rn(__fadd_rn(__fsub_rn(px2, px1), 1.f), __fadd_rn(__fsub_rn(py2, py1), 1.f))
+                           : __fmul_rn(p[2], p[3]);
+    const float a2 = plus1 ? __fmul_rn(__fadd_rn(__fsub_rn(qx2, qx1), 1.f), __fadd_rn(__fsub_rn(qy2, qy1), 1.f))
+                           : __fmul_rn(q[2], q[3]);
     const float x0 = fmaxf(px1, qx1), y0 = fmaxf(py1, qy1), x1 = fminf(px2, qx2), y1 = fminf(py2, qy2);
     float w = __fadd_rn(__fsub_rn(x1, x0), one), h = __fadd_rn(__fsub_rn(y1, y0), one);
     w = w > 0.f ? w : 0.f;

@@ -466,7 +466,9 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int img_on_device, b
   HIPCHK(hipEventRecord(L.ev[7], s));
   // ---- final NMS + gather (DenseCapModel.lua:261-275) ----------------------------------------------
   KCHK(launch_xcycwh_to_x1y1x2y2(L.final_boxes, L.final_xyxy, P, sn));
-  if (ctx->final_nms_thresh > 0.f) {
+  // forward_test skips the final NMS when final_nms_thresh <= 0 (DenseCapModel.lua:261); extractFeatures calls
+  // box_utils.nms unconditionally (DenseCapModel.lua:285-304)
+  if (ctx->final_nms_thresh > 0.f || features_only) {
     KCHK(launch_nms(L.nms, L.final_xyxy, L.obj, nullptr, P, L.count1, ctx->final_nms_thresh, -1, L.picks2, L.count2,
                     sn));
   } else {
@@ -730,10 +732,45 @@ int dc_load_weights(dc_ctx* ctx, const dc_weights* w) {
   return DC_OK;
 }
 
+// A failed enqueue/harvest must not leave lanes that still point at the caller's result buffers (the caller frees them
+// when the error surfaces) or work in flight on a workspace that the next call may rebuild: wait for every lane and
+// forget its pending destination without copying anything out.
+static void drain_lanes(dc_ctx* ctx) {
+  for (auto& lp : ctx->lanes) {
+    Lane& L = *lp;
+    if (L.stream) (void)hipStreamSynchronize(L.stream);
+    if (L.aux) (void)hipStreamSynchronize(L.aux);
+    if (L.aux2) (void)hipStreamSynchronize(L.aux2);
+    L.busy = false;
+    L.pending = nullptr;
+    L.pending_box_dst = nullptr; L.pending_feat_dst = nullptr; L.pending_k_dst = nullptr;
+  }
+  (void)hipGetLastError();
+}
+#define DCCHK_DRAIN(expr)                 \
+  do {                                    \
+    int _r = (expr);                      \
+    if (_r != DC_OK) { drain_lanes(ctx); return _r; } \
+  } while (0)
+
+// The NMS bit-mask workspace addresses at most NMS_MAX_WORDS*64 = 65536 candidates (boxes.hip): images whose conv5_3
+// map has more than 65536/k cells (about 1184x1184 px for k = 12) are refused up front with a message.
+static int check_anchor_count(dc_ctx* ctx, int H, int W, const char* who) {
+  int fh = H, fw = W;
+  for (int i = 0; i < DC_NUM_VGG_CONVS; ++i)
+    if (kVgg[i].pool_after) { fh = (fh + 1) / 2; fw = (fw + 1) / 2; }
+  const long A = (long)ctx->k * fh * fw;
+  if (A > 65536)
+    return ctx->fail(DC_E_UNSUPPORTED, "%s: %dx%d image -> %dx%d map x %d anchors = %ld RPN boxes; the NMS supports at most 65536",
+                     who, W, H, fw, fh, ctx->k, A);
+  return DC_OK;
+}
+
 static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, int on_dev, dc_result* outs) {
   if (!ctx) return DC_E_INVALID;
   if (!ctx->have_weights) return ctx->fail(DC_E_STATE, "dc_forward_*: weights not loaded");
   if (!imgs || !outs || n <= 0 || H < 32 || W < 32) return ctx->fail(DC_E_INVALID, "dc_forward_*: bad arguments");
+  DCCHK(check_anchor_count(ctx, H, W, "dc_forward_*"));
   HIPCHK(hipSetDevice(ctx->device));
   const int P = effective_proposals(ctx, H, W);
   for (int i = 0; i < n; ++i)
@@ -746,13 +783,13 @@ static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, i
   double enq_ms = 0;
   for (int i = 0; i < n; ++i) {
     Lane& L = *ctx->lanes[i % nl];
-    DCCHK(harvest(ctx, L));
+    DCCHK_DRAIN(harvest(ctx, L));
     L.pending = &outs[i];
     const auto t0 = std::chrono::steady_clock::now();
-    DCCHK(enqueue_forward(ctx, L, imgs + img_elems * i, on_dev, false));
+    DCCHK_DRAIN(enqueue_forward(ctx, L, imgs + img_elems * i, on_dev, false));
     enq_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
-  for (int l = 0; l < nl; ++l) DCCHK(harvest(ctx, *ctx->lanes[l]));
+  for (int l = 0; l < nl; ++l) DCCHK_DRAIN(harvest(ctx, *ctx->lanes[l]));
   if (host_timing) fprintf(stderr, "[densecap] %d images: host enqueue %.3f ms/image\n", n, enq_ms / n);
   prof_collect(ctx);
   return DC_OK;
@@ -769,15 +806,16 @@ int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img
                         float* boxes, float* feats, int32_t* K) {
   if (!ctx) return DC_E_INVALID;
   if (!ctx->have_weights) return ctx->fail(DC_E_STATE, "dc_extract_features: weights not loaded");
-  if (!img_chw || capacity <= 0) return ctx->fail(DC_E_INVALID, "dc_extract_features: bad arguments");
+  if (!img_chw || capacity <= 0 || H < 32 || W < 32) return ctx->fail(DC_E_INVALID, "dc_extract_features: bad arguments");
+  DCCHK(check_anchor_count(ctx, H, W, "dc_extract_features"));
   HIPCHK(hipSetDevice(ctx->device));
   Lane& L = lane0(ctx);
   DCCHK(harvest(ctx, L));
   DCCHK(lane_prepare(ctx, L, H, W, effective_proposals(ctx, H, W)));
   L.pending = nullptr;
   L.pending_capacity = capacity; L.pending_box_dst = boxes; L.pending_feat_dst = feats; L.pending_k_dst = K;
-  DCCHK(enqueue_forward(ctx, L, img_chw, img_on_device, true));
-  DCCHK(harvest(ctx, L));
+  DCCHK_DRAIN(enqueue_forward(ctx, L, img_chw, img_on_device, true));
+  DCCHK_DRAIN(harvest(ctx, L));
   prof_collect(ctx);
   return DC_OK;
 }

@@ -25,6 +25,28 @@ def _np32(t):
     return np.ascontiguousarray(t, dtype=np.float32)
 
 
+def decode_sequence(seq, idx_to_token, vocab_size):
+    """LanguageModel:decodeSequence (LanguageModel.lua:86-103): per row, join idx_to_token[tok] with ' ' until the END
+    token (vocab_size + 1) or a 0.  idx_to_token: dict or list keyed by the 1-based token id (int or str keys, as the
+    checkpoint's JSON-born table has them); None -> the ids themselves."""
+    end = int(vocab_size) + 1
+    caps = []
+    for row in np.asarray(seq):
+        words = []
+        for tok in row:
+            tok = int(tok)
+            if tok == end or tok == 0:
+                break
+            if idx_to_token is None:
+                words.append(str(tok))
+            elif isinstance(idx_to_token, dict):
+                words.append(idx_to_token[tok] if tok in idx_to_token else idx_to_token[str(tok)])
+            else:
+                words.append(idx_to_token[tok])
+        caps.append(" ".join(words))
+    return caps
+
+
 class DenseCapModel:
     def __init__(self, weights, device=0, ctx=None):
         """weights: dict in checkpoint layouts (see densecap_amd/weights.py); device: HIP index
@@ -160,7 +182,7 @@ class DenseCapModel:
     def forward_batch_device(self, imgs_dev_ptr, n, H, W):
         """run_model.lua's image loop over n device-resident images of one size; returns a list of
         (boxes, scores, tokens).  imgs_dev_ptr: device pointer to (n,3,H,W) fp32."""
-        P = int(self.opt["num_proposals"])
+        P = self._capacity(H, W)
         arr = (DcResult * n)()
         keep = []
         for i in range(n):
@@ -174,7 +196,7 @@ class DenseCapModel:
         imgs = np.ascontiguousarray(imgs, dtype=np.float32)
         n, c, H, W = imgs.shape
         assert c == 3
-        P = int(self.opt["num_proposals"])
+        P = self._capacity(H, W)
         arr = (DcResult * n)()
         keep = []
         for i in range(n):
@@ -187,7 +209,7 @@ class DenseCapModel:
     def extractFeatures(self, img):
         """DenseCapModel:extractFeatures -> (boxes_xcycwh (K,4), feats (K,fc_dim))."""
         img = self._check_input(img)
-        P = int(self.opt["num_proposals"])
+        P = self._capacity(img.shape[1], img.shape[2])
         boxes = np.zeros((P, 4), np.float32); feats = np.zeros((P, self.fc_dim), np.float32)
         K = C.c_int32(0)
         check(self.ctx.h, self.lib.dc_extract_features(self.ctx.h, img.ctypes.data, img.shape[1], img.shape[2], 0, P,
@@ -197,17 +219,7 @@ class DenseCapModel:
 
     def decodeSequence(self, seq):
         """LanguageModel:decodeSequence (LanguageModel.lua:86-103)."""
-        end = self.vocab_size + 1
-        caps = []
-        for row in np.asarray(seq):
-            words = []
-            for tok in row:
-                tok = int(tok)
-                if tok == end or tok == 0:
-                    break
-                words.append(self.idx_to_token[tok] if self.idx_to_token else str(tok))
-            caps.append(" ".join(words))
-        return caps
+        return decode_sequence(seq, self.idx_to_token, self.vocab_size)
 
     # ---- instrumentation ---------------------------------------------------------------------
     def stage_times(self):

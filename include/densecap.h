@@ -191,8 +191,14 @@ int dc_op_clip_boxes(dc_ctx* ctx, const float* boxes, float* clipped, uint8_t* v
                      float x_min, float y_min, float x_max, float y_max);
 /* box_utils.xcycwh_to_x1y1x2y2 (box_utils.lua:270-298). */
 int dc_op_xcycwh_to_x1y1x2y2(dc_ctx* ctx, const float* boxes, float* out, int n);
-/* nn.BoxIoU (BoxIoU.lua:40-73): (B1,4),(B2,4) xcycwh -> (B1,B2).  convention 0 =
- * module as written ((w-1)/2 corners, no +1), 1 = NMS inline (+1) convention. */
+/* nn.BoxIoU (BoxIoU.lua:40-73): (B1,4),(B2,4) xcycwh -> (B1,B2).  convention:
+ * DC_IOU_BOXIOU_MODULE (0) the module as written ((w-1)/2 corners, area w*h, no +1);
+ * DC_IOU_NMS_PLUS1 (1) box_utils.nms inline form (box_utils.lua:178-181,219-227: +1 on every extent);
+ * DC_IOU_LEGACY_HALF_W (2) the module's original converter (BoxIoU.lua:15-37, xc -/+ w/2), the one
+ * test/BoxIoU_test.lua:13-94 was written for. */
+#define DC_IOU_BOXIOU_MODULE 0
+#define DC_IOU_NMS_PLUS1 1
+#define DC_IOU_LEGACY_HALF_W 2
 int dc_op_box_iou(dc_ctx* ctx, const float* b1, const float* b2, float* out, int B1, int B2, int convention);
 /* Fused LocalizationLayer._forward_test lines 265-308 after the head convs: heads (h,w,6k)
  * HWC with channels [0,4k) box (a*4+d) and [4k,6k) score (a*2+d) -> per anchor-row

@@ -317,6 +317,36 @@ def box_iou_module(b1, b2):
     return (inter / ((area1 + area2) - inter)).astype(F32)
 
 
+def box_iou(b1, b2, convention="boxiou_module"):
+    """Pairwise IoU of xcycwh boxes under the three conventions found in the reference:
+    "boxiou_module"  nn.BoxIoU as written today (BoxIoU.lua:40-73): (w-1)/2 corners, area w*h, no +1;
+    "nms_plus1"      box_utils.nms inline (box_utils.lua:178-181,219-227): (w-1)/2 corners, +1 on every extent;
+    "legacy_half_w"  the module's original converter (BoxIoU.lua:15-37, commented out): corners xc -/+ w/2, area w*h,
+                     no +1 -- the convention test/BoxIoU_test.lua:13-94 was written for."""
+    b1 = np.asarray(b1, F32); b2 = np.asarray(b2, F32)
+    if convention == "boxiou_module":
+        return box_iou_module(b1, b2)
+    if convention == "legacy_half_w":
+        def conv(b):
+            o = np.empty_like(b)
+            o[:, 0] = (b[:, 2] / F32(2)) * F32(-1) + b[:, 0]; o[:, 2] = b[:, 2] / F32(2) + b[:, 0]
+            o[:, 1] = (b[:, 3] / F32(2)) * F32(-1) + b[:, 1]; o[:, 3] = b[:, 3] / F32(2) + b[:, 1]
+            return o
+        a, b, one = conv(b1), conv(b2), F32(0)
+        area1 = (b1[:, 2] * b1[:, 3])[:, None]; area2 = (b2[:, 2] * b2[:, 3])[None, :]
+    elif convention == "nms_plus1":
+        a, b, one = xcycwh_to_x1y1x2y2(b1), xcycwh_to_x1y1x2y2(b2), F32(1)
+        area1 = ((a[:, 2] - a[:, 0] + one) * (a[:, 3] - a[:, 1] + one))[:, None]
+        area2 = ((b[:, 2] - b[:, 0] + one) * (b[:, 3] - b[:, 1] + one))[None, :]
+    else:
+        raise ValueError(convention)
+    x0 = np.maximum(a[:, None, 0], b[None, :, 0]); y0 = np.maximum(a[:, None, 1], b[None, :, 1])
+    x1 = np.minimum(a[:, None, 2], b[None, :, 2]); y1 = np.minimum(a[:, None, 3], b[None, :, 3])
+    w = np.maximum(x1 - x0 + one, F32(0)); h = np.maximum(y1 - y0 + one, F32(0))
+    inter = w * h
+    return (inter / ((area1 + area2) - inter)).astype(F32)
+
+
 # ----------------------------------------------------------------------------
 # Dense stages (torch CPU fp32 stands in for THNN im2col+sgemm)
 # ----------------------------------------------------------------------------

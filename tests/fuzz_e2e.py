@@ -1,0 +1,44 @@
+"""Randomised end-to-end comparison HIP vs CPU oracle over image sizes, proposal counts and thresholds
+(small vocabulary so the oracle is quick); every case goes through tests/parity.py's strict comparison of the final
+outputs (identical lists, or an oracle near-tie proof).  usage: python tests/fuzz_e2e.py [n_cases] [seed]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from densecap_amd import DenseCapModel  # noqa: E402
+from densecap_amd.weights import make_synthetic_image, make_synthetic_weights  # noqa: E402
+from tests import parity  # noqa: E402
+
+
+def main(n_cases, seed):
+    rng = np.random.default_rng(seed)
+    W = make_synthetic_weights(seed=99, vocab_size=333, seq_length=7)
+    m = DenseCapModel(W, device=0)
+    bad = 0
+    for case in range(n_cases):
+        H = int(rng.integers(33, 420)); Wd = int(rng.integers(33, 520))
+        P = int(rng.choice([1, 2, 7, 50, 64, 65, 128, 300, 1000, -1]))
+        rthr = float(rng.choice([0.0, 0.3, 0.7, 1.0])); fthr = float(rng.choice([-1.0, 0.0, 0.3, 0.5, 1.0]))
+        lanes = int(rng.choice([1, 3])); order = bool(rng.integers(0, 2))
+        img = make_synthetic_image(H, Wd, 1000 + case)
+        m.setLanes(lanes); m.setCaptionOrder(order)
+        rec = dict(case=case, H=H, W=Wd, P=P, rpn_thr=rthr, final_thr=fthr, lanes=lanes, caption_after_nms=order)
+        try:
+            # stage tensors are only inspected in the reference caption order (the device "seq" buffer is filled there)
+            rec.update(parity.strict_check(m, W, img, P, rpn_thr=rthr, final_thr=fthr, stages=not order))
+            rec["ok"] = True
+        except AssertionError as e:
+            rec["ok"] = False
+            rec["why"] = str(e)[:400]
+            bad += 1
+        print(json.dumps(rec, default=str), flush=True)
+    print("FUZZ %s: %d/%d cases ok" % ("OK" if bad == 0 else "FAILED", n_cases - bad, n_cases))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 0))

@@ -84,6 +84,20 @@ vec = {
     idx_to_token={"1": "a", "2": "cat", "3": "dog", "4": "eating", "5": "hungry"},
     seq=[[1, 5, 2, 4, 1, 3, 6], [1, 3, 6, 0, 0, 0, 0], [2, 3, 1, 3, 2, 6, 0]],
     expected=["a hungry cat eating a dog", "a dog", "cat dog a dog cat"]),
+  # test/BoxIoU_test.lua:13-94 -- written for the module's ORIGINAL converter (x0 = xc - w/2, kept as a comment at
+  # BoxIoU.lua:15-37); the live module calls box_utils.xcycwh_to_x1y1x2y2 ((w-1)/2) and no longer gives these values.
+  # They pin the `legacy_half_w` convention.  Batches are listed one (boxes1, boxes2, expected) each.
+  "box_iou_legacy_half_w": [
+    dict(cite="test/BoxIoU_test.lua:13-24", tol=1e-10, boxes1=[[10, 10, 10, 10]], boxes2=[[15, 15, 10, 10]],
+         expected=[[25 / 175]]),
+    dict(cite="test/BoxIoU_test.lua:27-38", tol=1e-10, boxes1=[[10, 10, 5, 5]], boxes2=[[15, 15, 5, 5]], expected=[[0]]),
+    dict(cite="test/BoxIoU_test.lua:41-61", tol=1e-8, boxes1=[[2, 4, 2, 6], [5, 7.5, 2, 5]],
+         boxes2=[[5, 8, 4, 2], [4.5, 4.5, 5, 3], [4.5, 0, 5, 4]],
+         expected=[[0, 3 / 24, 1 / 31], [4 / 14, 2 / 23, 0]]),
+    dict(cite="test/BoxIoU_test.lua:64-94 (batch element 2)", tol=1e-8, boxes1=[[4, 2, 2, 6], [6, -2, 2, 2]],
+         boxes2=[[4, 2, 4, 2], [4.5, -1, 3, 2], [6, -2, 4, 4]],
+         expected=[[1 / 4, 1 / 8, 1 / 27], [0, 1 / 9, 1 / 4]]),
+  ],
   "reshape_consistency": dict(  # test/ReshapeBoxFeatures_test.lua:33-58 (exact)
     cite="test/ReshapeBoxFeatures_test.lua:33-58", k=2, D=5, H=4, W=3,
     x0=1, y0=1, sx=2, sy=2, anchors=[[10, 20], [20, 10]],

@@ -1,0 +1,25 @@
+"""Prints (and writes to gpurun_out/parity_report.json) the end-to-end parity statistics of the HIP path vs the CPU
+oracle over the BASELINE.json configurations; the same strict comparison the -m gpu tests assert (tests/parity.py).
+usage (GPU box): python tests/parity_report.py   [PARITY_EXTRA=n more 720x600 images]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from densecap_amd import DenseCapModel  # noqa: E402
+from densecap_amd.weights import make_synthetic_image, make_synthetic_weights  # noqa: E402
+from tests import parity  # noqa: E402
+
+W = make_synthetic_weights(seed=1234)
+m = DenseCapModel(W, device=0)
+rows = []
+SETTINGS = [(600, 720, 1000, 0), (600, 720, 1000, 1), (600, 720, 300, 2), (720, 1080, 2000, 5), (480, 720, 1000, 7)]
+SETTINGS += [(600, 720, 1000, sd) for sd in range(10, 10 + int(os.environ.get("PARITY_EXTRA", "0")))]
+for (H, Wd, P, seed) in SETTINGS:
+    r = dict(H=H, W=Wd, P=P, seed=seed)
+    r.update(parity.strict_check(m, W, make_synthetic_image(H, Wd, seed), P))
+    rows.append(r)
+    print(json.dumps(r, default=str), flush=True)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "parity_report.json"), "w"), indent=1, default=str)

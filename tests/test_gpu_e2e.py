@@ -2,9 +2,10 @@
 synthetic 720x600 / 1000-proposal configuration (BASELINE.json configs[1]) and a small one.
 
 Greedy NMS and arg-max are discontinuous: an fp32 rounding difference upstream (device expf
-vs glibc, MFMA summation order vs BLAS) can flip a near-tie.  Exact integer parity is asserted
-under teacher forcing in test_gpu_ops.py; here the comparison is flip-aware: rows are matched
-by box identity and every mismatch must be explained by a near-tie margin in the oracle."""
+vs glibc, MFMA summation order vs BLAS) can flip a near-tie.  The comparison (tests/parity.py) therefore has three
+parts, none of them a percentage: continuous tensors within 1e-4 relative; integer stages bit-exact when the oracle is
+fed the HIP path's own stage inputs; final outputs identical to the oracle's unless the oracle's own data prove a
+near-tie (IoU-threshold / score / top-2 logit margin < 1e-4) at the point of departure."""
 import os
 
 import numpy as np
@@ -28,59 +29,12 @@ def model(weights):
     m.ctx.close()
 
 
-def _oracle(weights, img, P, T=15):
-    import torch
-    from oracle import densecap_oracle as O
-    torch.set_num_threads(max(1, torch.get_num_threads()))
-    st = {}
-    out = O.forward_test(img, weights, 0.7, 0.3, P, T, stages=st)
-    return out, st
-
-
-def _rel_err(a, b):
-    return float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-30)
-
-
 def _check_against_oracle(model, weights, H, W, P, seed):
+    """tests/parity.py::strict_check: continuous stages within 1e-4 relative, integer stages bit-exact under teacher
+    forcing, final outputs identical to the oracle's or the departure proven an fp32 near-tie in the oracle."""
     from densecap_amd.weights import make_synthetic_image
-    from oracle import densecap_oracle as O
-    img = make_synthetic_image(H, W, seed)
-    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
-    boxes, scores, tokens = model.forward_raw(img)
-    (oboxes, oscores, oseq), st = _oracle(weights, img, P)
-    fh, fw = st["feat"].shape[1:]
-    # -- trunk features (MFMA conv trunk) : 1e-4 relative
-    feat, _ = model.debug_fetch("feat_hwc", (fh, fw, 512))
-    assert _rel_err(feat.transpose(2, 0, 1), st["feat"]) < REL
-    # -- RPN scores / boxes for every anchor
-    A = 12 * fh * fw
-    p, _ = model.debug_fetch("rpn_p", (A,))
-    assert st["rpn"]["valid"].all()
-    np.testing.assert_allclose(p, st["rpn"]["p"], rtol=2e-4, atol=1e-6)
-    rb, _ = model.debug_fetch("rpn_boxes", (A, 4))
-    np.testing.assert_allclose(rb, st["rpn"]["boxes"], rtol=1e-4, atol=1e-2)
-    # -- RPN NMS picks: identical up to near-tie flips
-    idx, _ = model.debug_fetch("rpn_nms_idx", (P,), np.int32)
-    cnt, _ = model.debug_fetch("rpn_nms_count", (1,), np.int32)
-    assert cnt[0] == len(st["rpn_nms_idx"])
-    same = np.intersect1d(idx[:cnt[0]], st["rpn_nms_idx"]).size / float(cnt[0])
-    assert same >= 0.99, "RPN NMS pick overlap %.4f" % same
-    # -- final outputs, matched by box identity
-    assert abs(len(boxes) - len(oboxes)) <= max(2, len(oboxes) // 50)
-    matched = 0
-    tok_same = 0
-    for i, ob in enumerate(oboxes):
-        d = np.abs(boxes - ob).max(axis=1) if len(boxes) else np.array([np.inf])
-        j = int(np.argmin(d))
-        if d[j] <= 1e-4 * max(1.0, np.abs(ob).max()) * 10:
-            matched += 1
-            assert abs(scores[j] - oscores[i]) <= REL * max(1.0, abs(oscores[i])) * 10
-            tok_same += int((tokens[j] == oseq[i]).all())
-    assert matched >= 0.98 * len(oboxes), "matched %d of %d final boxes" % (matched, len(oboxes))
-    assert tok_same >= 0.98 * matched, "identical token rows %d of %d" % (tok_same, matched)
-    # scores are returned in decreasing order (box_utils.nms contract)
-    assert (np.diff(scores) <= 0).all()
-    return dict(K=len(boxes), K_oracle=len(oboxes), matched=matched, tok_same=tok_same, pick_overlap=same)
+    from tests import parity
+    return parity.strict_check(model, weights, make_synthetic_image(H, W, seed), P)
 
 
 def test_forward_small_image(model, weights):
@@ -88,9 +42,11 @@ def test_forward_small_image(model, weights):
     assert r["K"] > 0
 
 
-def test_forward_720x600_1000_proposals(model, weights):
-    r = _check_against_oracle(model, weights, 600, 720, 1000, seed=0)
-    assert r["K"] > 0
+@pytest.mark.parametrize("seed", [0, 1])
+def test_forward_720x600_1000_proposals(model, weights, seed):
+    """BASELINE.json configs[1]."""
+    r = _check_against_oracle(model, weights, 600, 720, 1000, seed=seed)
+    assert r["K"] > 0 and r["matched"] == r["K_oracle"]
     t = model.stage_times()
     assert set(t) >= {"vgg16_trunk", "rpn_nms", "bilinear_roi_pool", "lstm_decode"}
     assert all(v >= 0 for v in t.values())
@@ -117,7 +73,6 @@ def test_lm_sample_teacher_forced(model, weights):
         top2 = torch.topk(logits[t][r], 2).values
         margin = float(top2[0] - top2[1]) / max(1.0, float(top2[0].abs()))
         assert margin < 1e-4, "row %d step %d diverged with margin %g" % (r, t, margin)
-    assert len(bad_rows) <= max(1, n // 50)
     assert seq.min() >= 1 and seq.max() <= weights["vocab_size"] + 1
 
 
@@ -134,13 +89,69 @@ def test_forward_batch_equals_single(model, weights):
 
 
 def test_extract_features(model, weights):
+    """DenseCapModel:extractFeatures (DenseCapModel.lua:285-304): boxes AND fc7 codes against the oracle."""
     from densecap_amd.weights import make_synthetic_image
-    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=100)
+    from oracle import densecap_oracle as O
+    from tests import parity
+    parity.oracle_threads()
+    for (H, W, P, seed) in [(224, 288, 100, 3), (600, 720, 1000, 0)]:
+        model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
+        img = make_synthetic_image(H, W, seed)
+        b, s, _ = model.forward_raw(img)
+        fb, ff = model.extractFeatures(img)
+        np.testing.assert_array_equal(fb, b)
+        st = {}
+        ob, _, _ = O.forward_test(img, weights, 0.7, 0.3, P, 15, stages=st)
+        ocodes = st["codes"][st["final_nms_idx"]]
+        assert len(fb) == len(ob) and ff.shape == ocodes.shape
+        assert parity.row_rel_err(fb, ob) <= parity.REL
+        assert parity.rel_err(ff, ocodes) <= parity.REL, "fc7 codes of the surviving boxes"
+
+
+def test_extract_features_always_runs_final_nms(model, weights):
+    """DenseCapModel.lua:285-304 calls box_utils.nms unconditionally (no `final_nms_thresh > 0` guard as in
+    forward_test): threshold 0 keeps only boxes that overlap no earlier pick."""
+    from densecap_amd.weights import make_synthetic_image
+    from oracle import densecap_oracle as O
+    from tests import parity
+    parity.oracle_threads()
     img = make_synthetic_image(224, 288, 3)
-    b, s, _ = model.forward_raw(img)
-    fb, ff = model.extractFeatures(img)
-    np.testing.assert_array_equal(fb, b)
-    assert ff.shape == (len(b), 4096) and (ff >= 0).all() and ff.max() > 0
+    try:
+        model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.0, num_proposals=100)
+        fb, ff = model.extractFeatures(img)
+        st = {}
+        O.forward_test(img, weights, 0.7, 0.0, 100, 15, stages=st)
+        b5 = np.concatenate([O.xcycwh_to_x1y1x2y2(st["final_boxes_pre_nms"]), st["obj"][:, None]], 1)
+        keep = O.nms(b5, 0.0, None)
+        assert 0 < len(keep) < 100 and len(fb) == len(keep)
+        assert parity.row_rel_err(fb, st["final_boxes_pre_nms"][keep]) <= parity.REL
+        assert parity.rel_err(ff, st["codes"][keep]) <= parity.REL
+    finally:
+        model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=100)
+
+
+def test_config4_shard_64_images_1000_proposals(model, weights):
+    """BASELINE.json configs[3], one GPU's shard: 64 images x 1000 proposals through dc_forward_batch (the lane
+    pipeline); every image's final (boxes, scores, tokens) against the oracle -- identical or proven near-tie."""
+    from densecap_amd.weights import make_synthetic_image
+    from oracle import densecap_oracle as O
+    from tests import parity
+    parity.oracle_threads()
+    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=1000)
+    imgs = np.stack([make_synthetic_image(600, 720, 100 + s) for s in range(64)])
+    dev = model.ctx.to_device(imgs)
+    batch = model.forward_batch_device(dev.ptr, 64, 600, 720)
+    dev.free()
+    flips = 0
+    boxes_total = 0
+    for i in range(64):
+        st = {}
+        ora = O.forward_test(imgs[i], weights, 0.7, 0.3, 1000, 15, stages=st)
+        rep = parity.compare_final(O, weights, batch[i], ora, st, 0.3, 15, {})
+        flips += len(rep.get("final_list_flips", [])) + len(rep.get("token_near_ties", []))
+        boxes_total += rep["matched"]
+    assert boxes_total > 64 * 100
+    assert flips <= 3, "%d near-tie departures in 64 images: fp32 noise does not explain that many" % flips
 
 
 def test_errors_are_reported_not_thrown(model):
@@ -165,12 +176,19 @@ def test_config3_batch32_300_proposals(model, weights):
     Size-independent properties: every image of the batch equals its single-image run; duplicate images
     give duplicate results; scores are sorted; token ids are in range."""
     from densecap_amd.weights import make_synthetic_image
+    from oracle import densecap_oracle as O
+    from tests import parity
     model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=300)
     base = [make_synthetic_image(600, 720, s) for s in range(4)]
     imgs = np.stack([base[i % 4] for i in range(32)])
     batch = model.forward_batch(imgs)
     assert len(batch) == 32
+    parity.oracle_threads()
     for i in range(4):
+        # P=300 against the ORACLE (not against the HIP path itself): final lists identical or proven near-tie
+        st = {}
+        ora = O.forward_test(base[i], weights, 0.7, 0.3, 300, 15, stages=st)
+        parity.compare_final(O, weights, batch[i], ora, st, 0.3, 15, {})
         b, s, t = model.forward_raw(base[i])
         for rep in range(i, 32, 4):
             np.testing.assert_array_equal(batch[rep][0], b)
@@ -282,23 +300,24 @@ def test_single_lane_mode_parity(model, weights):
 
 def test_uncapped_proposals_and_no_final_nms(model, weights):
     """num_proposals = -1 (LocalizationLayer.lua:322-324) and final_nms_thresh <= 0 (DenseCapModel.lua:261),
-    against the oracle on a small image."""
+    against the oracle on a small image -- full strict check, in forward_raw, forward_batch and extractFeatures."""
     from densecap_amd.weights import make_synthetic_image
-    from oracle import densecap_oracle as O
+    from tests import parity
     img = make_synthetic_image(128, 160, 9)            # 8x10 map -> 960 anchors
-    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=-1)
-    b, s, t = model.forward_raw(img)
-    ob, os_, oseq = O.forward_test(img, weights, 0.7, 0.3, -1, 15)
-    assert len(b) == len(ob) > 0
-    np.testing.assert_allclose(b, ob, rtol=1e-4, atol=1e-3)
-    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.0, num_proposals=40)
-    b, s, t = model.forward_raw(img)
-    ob, os_, oseq = O.forward_test(img, weights, 0.7, 0.0, 40, 15)
-    assert len(b) == len(ob) == 40
-    np.testing.assert_allclose(b, ob, rtol=1e-4, atol=1e-3)       # RPN order, no sorting by objectness
-    np.testing.assert_allclose(s, os_, rtol=1e-4, atol=1e-4)
-    assert (t == oseq).all(axis=1).mean() > 0.9
-    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=100)
+    try:
+        r = parity.strict_check(model, weights, img, -1)
+        assert r["K"] > 0 and r["matched"] == r["K_oracle"]
+        b, s, t = model.forward_raw(img)
+        bb = model.forward_batch(np.stack([img, img]))          # ADVICE r1: -1 must work on every entry point
+        for out in bb:
+            np.testing.assert_array_equal(out[0], b); np.testing.assert_array_equal(out[2], t)
+        fb, ff = model.extractFeatures(img)
+        np.testing.assert_array_equal(fb, b)
+        assert ff.shape == (len(b), 4096)
+        r = parity.strict_check(model, weights, img, 40, final_thr=0.0)
+        assert r["K"] == r["K_oracle"] == 40                   # RPN order, no sorting by objectness
+    finally:
+        model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=100)
 
 
 def test_argmax_takes_first_index_on_exact_ties():

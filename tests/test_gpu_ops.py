@@ -79,6 +79,62 @@ def test_linear_matches_fp64(ctx, mnk):
     _close(ops.linear(ctx, x, w, None), (ref - b).astype(np.float32), rel=2e-5)
 
 
+def test_fc6_shape_k25088(ctx):
+    """recog_base fc6 (DenseCapModel.lua:133) at its real size: M=1000 RoIs, N=4096, K=25088 -- the K-split 128x128
+    kernel with 784 K-tiles, 8 M-tiles sharing each 411 MB weight panel -- against an fp64 reference."""
+    import torch
+    from densecap_amd import ops
+    M, N, K = 1000, 4096, 25088
+    g = torch.Generator().manual_seed(6)
+    x = torch.relu(torch.randn(M, K, generator=g))
+    w = torch.randn(N, K, generator=g) * (2.0 / K) ** 0.5
+    b = torch.randn(N, generator=g)
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    ref = torch.relu(torch.addmm(b.double(), x.double(), w.double().t())).float().numpy()
+    _close(ops.linear(ctx, x.numpy(), w.numpy(), b.numpy(), relu=True), ref, rel=2e-5)
+
+
+@pytest.mark.parametrize("case", [("conv5_x split-K", 1, 512, 38, 45, 512), ("rpn conv split-K", 1, 512, 38, 45, 256),
+                                  ("conv2_2 tail plan", 1, 128, 300, 360, 128), ("conv3_2 tail plan", 1, 256, 150, 180, 256),
+                                  ("conv4_2 tail plan", 1, 512, 75, 90, 512)])
+def test_conv_splitk_and_tail_plans_single_lane(case):
+    """dc_set_lanes(1) (single-image mode) routes layers whose 128x128 tile count is small or not a multiple of 256
+    through split-K / the tail plan (another fixed fp32 summation order): each such shape against fp64 torch."""
+    import torch
+    from densecap_amd import ops
+    from densecap_amd._lib import check
+    name, N, Cin, H, W, Cout = case
+    c = ops.Context(0)
+    try:
+        check(c.h, c.lib.dc_set_lanes(c.h, 1), "dc_set_lanes")
+        g = torch.Generator().manual_seed(Cin + H + Cout)
+        x = torch.relu(torch.randn(N, Cin, H, W, generator=g))
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+        b = torch.randn(Cout, generator=g)
+        torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+        ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)).float().numpy()
+        _close(ops.conv3x3(c, x.numpy(), w.numpy(), b.numpy(), relu=True), ref, rel=2e-5)
+    finally:
+        c.close()
+
+
+def test_lm_encoder_splitk_single_lane():
+    """image_encoder Linear(4096,512) at M=1000 (32 tiles, K=4096 -> split-K in single-image mode)."""
+    from densecap_amd import ops
+    from densecap_amd._lib import check
+    c = ops.Context(0)
+    try:
+        check(c.h, c.lib.dc_set_lanes(c.h, 1), "dc_set_lanes")
+        rng = np.random.default_rng(11)
+        x = np.maximum(rng.standard_normal((1000, 4096)), 0).astype(np.float32)
+        w = (rng.standard_normal((512, 4096)) / 64).astype(np.float32)
+        b = rng.standard_normal(512).astype(np.float32)
+        ref = np.maximum(x.astype(np.float64) @ w.astype(np.float64).T + b, 0).astype(np.float32)
+        _close(ops.linear(c, x, w, b, relu=True), ref, rel=2e-5)
+    finally:
+        c.close()
+
+
 def test_linear_transpose_detecting(ctx):
     # A = I with an asymmetric W catches a swapped C/D register map
     from densecap_amd import ops
@@ -142,6 +198,38 @@ def test_box_iou_module(ctx):
     b1 = np.concatenate([rng.uniform(0, 300, (70, 2)), rng.uniform(5, 200, (70, 2))], 1).astype(np.float32)
     b2 = np.concatenate([rng.uniform(0, 300, (33, 2)), rng.uniform(5, 200, (33, 2))], 1).astype(np.float32)
     np.testing.assert_array_equal(ops.box_iou(ctx, b1, b2, 0), O.box_iou_module(b1, b2))
+
+
+@pytest.mark.parametrize("conv", [(0, "boxiou_module"), (1, "nms_plus1"), (2, "legacy_half_w")])
+def test_box_iou_conventions_exact(ctx, conv):
+    """dc_op_box_iou under the three conventions of SURVEY.md 8 a21, bit-exact against the oracle; the +1 convention
+    must also reproduce the IoU that box_utils.nms computes inline (checked through a pick/suppress decision)."""
+    from densecap_amd import ops
+    from oracle import densecap_oracle as O
+    code, name = conv
+    rng = np.random.default_rng(code)
+    b1 = np.concatenate([rng.uniform(0, 300, (70, 2)), rng.uniform(1, 120, (70, 2))], 1).astype(np.float32)
+    b2 = np.concatenate([rng.uniform(0, 300, (133, 2)), rng.uniform(1, 120, (133, 2))], 1).astype(np.float32)
+    b2[:20] = b1[:20]                                            # identical boxes: IoU exactly 1 in every convention
+    got = ops.box_iou(ctx, b1, b2, code)
+    np.testing.assert_array_equal(got, O.box_iou(b1, b2, name))
+    assert (np.diag(got[:20, :20]) == 1).all() and got.min() >= 0 and got.max() <= 1
+    if name == "nms_plus1":
+        # a pair is suppressed by box_utils.nms at threshold t  <=>  its +1 IoU > t
+        i, j = np.unravel_index(np.argmax(np.where(got < 0.999, got, 0)), got.shape)
+        pair = np.stack([b1[i], b2[j]])
+        b5 = np.concatenate([O.xcycwh_to_x1y1x2y2(pair), np.array([[2.0], [1.0]], np.float32)], 1)
+        t = float(got[i, j])
+        assert len(O.nms(b5, np.nextafter(np.float32(t), np.float32(0)), None)) == 1     # thr just below: suppressed
+        assert len(O.nms(b5, t, None)) == 2                                               # iou <= thr: kept
+
+
+def test_box_iou_legacy_half_w_golden(ctx, golden):
+    """test/BoxIoU_test.lua:13-94 vectors (written for the module's original xc -/+ w/2 converter) on the GPU."""
+    from densecap_amd import ops
+    for case in golden["box_iou_legacy_half_w"]:
+        got = ops.box_iou(ctx, np.array(case["boxes1"], np.float32), np.array(case["boxes2"], np.float32), 2)
+        np.testing.assert_allclose(got, np.array(case["expected"]), atol=1e-6, rtol=1e-6)
 
 
 def test_rpn_decode_matches_oracle(ctx):

@@ -93,6 +93,31 @@ def test_decode_sequence_golden(golden):
     assert O.decode_sequence(np.array(g["seq"]), itt, g["vocab_size"]) == g["expected"]
 
 
+def test_box_iou_legacy_half_w_golden(golden):
+    """test/BoxIoU_test.lua:13-94: reproduced by the legacy converter only -- and NOT by the live module's (w-1)/2
+    converter, which is why the survey calls those expectations stale."""
+    from oracle import densecap_oracle as O
+    stale = 0
+    for case in golden["box_iou_legacy_half_w"]:
+        b1, b2 = np.array(case["boxes1"], np.float32), np.array(case["boxes2"], np.float32)
+        exp = np.array(case["expected"])
+        np.testing.assert_allclose(O.box_iou(b1, b2, "legacy_half_w"), exp, atol=1e-6)
+        stale += not np.allclose(O.box_iou(b1, b2, "boxiou_module"), exp, atol=1e-6)
+    assert stale >= 2
+    b = np.array([[10, 10, 10, 10], [15, 15, 10, 10]], np.float32)
+    np.testing.assert_array_equal(O.box_iou(b, b, "boxiou_module"), O.box_iou_module(b, b))
+
+
+def test_product_decode_sequence_golden(golden):
+    """The PRODUCT host's decodeSequence (densecap_amd/model.py) on test/LanguageModel_test.lua:135-160."""
+    from densecap_amd.model import decode_sequence
+    g = golden["decode_sequence"]
+    assert decode_sequence(np.array(g["seq"]), g["idx_to_token"], g["vocab_size"]) == g["expected"]
+    assert decode_sequence(np.array(g["seq"]), {int(k): v for k, v in g["idx_to_token"].items()}, g["vocab_size"]) == g["expected"]
+    assert decode_sequence(np.array([[6, 1, 2]]), g["idx_to_token"], 5) == [""]          # END first -> empty caption
+    assert decode_sequence(np.array([[2, 0, 3]]), None, 5) == ["2"]
+
+
 def test_box_conversion_roundtrip():
     # test/box_conversion_test.lua:12-23
     rng = np.random.default_rng(1)
