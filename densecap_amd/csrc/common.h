@@ -29,6 +29,11 @@ struct GemmDesc {
   float* amax_val = nullptr;
   int32_t* amax_idx = nullptr;
   int amax_ld = 0;
+  // arg-max over a PREFIX of the columns (decode step: W = [vocab rows; pad; Wh rows], both products share A = h_t):
+  // columns [0, amax_cols) (a multiple of 64) get the arg-max epilogue, of which [0, amax_n) are real vocabulary
+  // entries; columns [amax_cols, N) are stored raw to C[m*ldc + (n - amax_cols)].  amax_cols = 0: every column.
+  int amax_cols = 0;
+  int amax_n = 0;
   // optional device-side row count: effective M = min(M, *m_dev); workgroups past it exit at once
   const int32_t* m_dev = nullptr;
   // split-K (K-split 128x128 kernel only): `splitk` workgroups share one tile, each sums a contiguous K range
@@ -79,6 +84,14 @@ hipError_t launch_iota_count(int32_t* idx, int32_t* count_out, const int32_t* co
 // reduce the per-N-tile arg-max partials of the fused vocab epilogue: tok[m] = seq[m*T+t] = 1 + argmax
 hipError_t launch_argmax_finalize(const float* pval, const int32_t* pidx, int n, const int32_t* n_dev, int ntiles,
                                   int ld, int32_t* tok, int32_t* seq, int T, int t, hipStream_t s);
+// One decode step's row-wise tail (LanguageModel.lua:316-335 between two GEMMs), one workgroup per row:
+//   pval != null: tok = 1 + argmax over the row's `ntiles` partials (first max on ties), seq[m*T+t] = tok;
+//                 else tok = fixed_tok (START, or 0 = no input-gate row term);
+//   gates = (tok ? xg[(tok-1)*4Hd ..] : 0) + gates_pre[m]  (same association as torch-rnn: (b + x.Wx) + h.Wh);
+//   [i f o g] -> c' = f*c + i*g (c = 0 if zero_c), h' = o*tanh(c').  gates_pre == null: arg-max only.
+hipError_t launch_lstm_step_tail(const float* pval, const int32_t* pidx, int ntiles, int ld, int fixed_tok,
+                                 const float* xg, const float* gates_pre, float* c, float* h, int n,
+                                 const int32_t* n_dev, int Hd, int zero_c, int32_t* seq, int T, int t, hipStream_t s);
 // objectness + box regression heads + final ApplyBoxTransform (DenseCapModel.lua:134,139-140)
 hipError_t launch_recog_heads(const float* codes, const float* w5 /*(5,D): obj, 4 boxreg*/, const float* b5,
                               const float* roi_boxes, float* obj, float* trans, float* final_boxes, int n, int D,

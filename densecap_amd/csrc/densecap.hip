@@ -91,6 +91,8 @@ struct dc_ctx {
   float *fc6_w = nullptr, *fc6_b = nullptr, *fc7_w = nullptr, *fc7_b = nullptr, *head5_w = nullptr, *head5_b = nullptr;
   float *enc_w = nullptr, *enc_b = nullptr, *wxT = nullptr, *whT = nullptr, *lstm_b = nullptr, *xg = nullptr;
   float *out_w = nullptr, *out_b = nullptr, *anchors = nullptr;
+  float* dec_w = nullptr;   // (V1pad + 4Hd, Hd): rows [0,V+1) = lm_out_w, zero rows up to V1pad (multiple of 64), then Wh^T
+  int V1pad = 0;
   std::vector<std::unique_ptr<Lane>> lanes;
   // MFMA profile
   bool prof = false;
@@ -329,52 +331,69 @@ struct LmPart { hipStream_t s; int r0, n; float* ws; size_t ws_floats; };
 // (n_dev: optional device-side row count <= n of a single part starting at row 0; rows past it are not computed).
 int lm_sample_parts(dc_ctx* ctx, Lane& L, const float* codes, const LmPart* parts, int nparts, const int32_t* n_dev,
                     int32_t* seq_out) {
+  // Schedule of one decode (h_t = LSTM state after t steps past the image step, tok_0 = START):
+  //   enc = ReLU(codes.Wenc^T + b)                      GEMM   (:27-30)
+  //   G   = (b + enc.Wx)                                GEMM   step 0 of LM:sample: the image code is the first input
+  //   tail: c_0, h_0 from G (c = 0)                     row kernel
+  //   G   = h_0.Wh                                      GEMM
+  //   tail: h_1 from xg[START] + G                      row kernel
+  //   for t = 1..T-1:  [arg-max partials of h_t.Wout^T + b | G = h_t.Wh]   ONE GEMM launch (W = [Wout; pad; Wh])
+  //                    tail: tok_t = arg-max; h_{t+1} from xg[tok_t] + G   row kernel
+  //   arg-max partials of h_T.Wout^T + b                GEMM;  tail: tok_T
+  // i.e. 2 launches per step.  The h.Wh product of the NEXT step rides in the vocabulary projection's launch (both
+  // only need h_t) and fills its partial last round of tiles; the token-dependent half of the gates (a row of the
+  // precomputed xg = b + Emb.Wx table) is added where the token is produced.  Per element the arithmetic and its order
+  // are those of torch-rnn's nn.LSTM: (b + x.Wx) + h.Wh, sigmoid/tanh, c' = f*c + i*g, h' = o*tanh(c').
   const int E = ctx->E, Hd = ctx->Hd, V1 = ctx->V + 1, T = ctx->T, D = ctx->D;
-  const size_t ntn_max = (size_t)(V1 + 63) / 64;        // arg-max partials per row: (value, column) per 64-column tile at most
+  const int V1pad = ctx->V1pad, ntn = V1pad / 64;       // arg-max partials per row: one (value, column) per 64-column tile
   for (int pi = 0; pi < nparts; ++pi) {
     const LmPart& p = parts[pi];
     hipStream_t s = p.s;
-    // image_encoder: Linear(4096,E)+ReLU (:27-30)
-    {
+    float* gates = L.gates + (size_t)p.r0 * 4 * Hd;
+    float* hstate = L.hstate + (size_t)p.r0 * Hd;
+    float* cstate = L.cstate + (size_t)p.r0 * Hd;
+    {  // image_encoder: Linear(4096,E)+ReLU (:27-30)
       GemmDesc g;
       g.A = codes + (size_t)p.r0 * D; g.W = ctx->enc_w; g.bias = ctx->enc_b; g.C = L.enc + (size_t)p.r0 * E;
       g.M = p.n; g.N = E; g.K = D; g.ldc = E; g.relu = 1; g.m_dev = n_dev;
       DCCHK(run_gemm(ctx, g, s, p.ws, p.ws ? p.ws_floats : 0));
     }
-    // step 0: gates = (b + enc.Wx) + 0.Wh ; c0 = 0 (output ignored, no vocab projection needed)
-    {
+    {  // step 0: gates = (b + enc.Wx) + 0.Wh ; c0 = 0 (output ignored, no vocab projection needed)
       GemmDesc g;
-      g.A = L.enc + (size_t)p.r0 * E; g.W = ctx->wxT; g.bias = ctx->lstm_b; g.C = L.gates + (size_t)p.r0 * 4 * Hd;
+      g.A = L.enc + (size_t)p.r0 * E; g.W = ctx->wxT; g.bias = ctx->lstm_b; g.C = gates;
       g.M = p.n; g.N = 4 * Hd; g.K = E; g.ldc = 4 * Hd; g.m_dev = n_dev;
       DCCHK(run_gemm(ctx, g, s));
     }
-    KCHK(launch_lstm_pointwise(L.gates + (size_t)p.r0 * 4 * Hd, L.cstate + (size_t)p.r0 * Hd, L.hstate + (size_t)p.r0 * Hd,
-                               p.n, n_dev, Hd, 1, s));
-    KCHK(launch_fill_i32(L.tok + p.r0, V1, p.n, s));  // START token = V+1 (:32,320)
+    KCHK(launch_lstm_step_tail(nullptr, nullptr, 0, 0, 0, nullptr, gates, cstate, hstate, p.n, n_dev, Hd, 1, nullptr, T, 0, s));
+    {  // h_0.Wh, then the START token's xg row (:32,320) joins it in the tail
+      GemmDesc g;
+      g.A = hstate; g.W = ctx->whT; g.C = gates; g.M = p.n; g.N = 4 * Hd; g.K = Hd; g.ldc = 4 * Hd; g.m_dev = n_dev;
+      DCCHK(run_gemm(ctx, g, s));
+    }
+    KCHK(launch_lstm_step_tail(nullptr, nullptr, 0, 0, V1, ctx->xg, gates, cstate, hstate, p.n, n_dev, Hd, 0, nullptr, T, 0, s));
   }
   for (int t = 0; t < T; ++t) {
+    const bool last = t == T - 1;
     for (int pi = 0; pi < nparts; ++pi) {
       const LmPart& p = parts[pi];
       hipStream_t s = p.s;
       float* gates = L.gates + (size_t)p.r0 * 4 * Hd;
       float* hstate = L.hstate + (size_t)p.r0 * Hd;
-      // gates = (b + Emb[tok].Wx) + h.Wh ; the first term is the precomputed table xg[tok]
-      GemmDesc d;
-      d.A = hstate; d.W = ctx->whT; d.C = gates; d.M = p.n; d.N = 4 * Hd; d.K = Hd; d.ldc = 4 * Hd;
-      d.rowterm = ctx->xg; d.rowidx = L.tok + p.r0; d.rowterm_ld = 4 * Hd; d.m_dev = n_dev;
-      DCCHK(run_gemm(ctx, d, s));
-      KCHK(launch_lstm_pointwise(gates, L.cstate + (size_t)p.r0 * Hd, hstate, p.n, n_dev, Hd, 0, s));
-      {  // vocab projection with the row arg-max fused into the GEMM epilogue: logits never reach HBM
-        GemmDesc v;
-        v.A = hstate; v.W = ctx->out_w; v.bias = ctx->out_b; v.C = nullptr; v.M = p.n; v.N = V1; v.K = Hd; v.ldc = V1;
-        v.m_dev = n_dev;
-        v.amax_val = L.logits + (size_t)p.r0 * 2 * ntn_max;
-        const int ntn = mfma_gemm_ntiles_n(v);
-        v.amax_idx = reinterpret_cast<int32_t*>(v.amax_val + (size_t)p.n * ntn); v.amax_ld = ntn;
-        DCCHK(run_gemm(ctx, v, s));
-        KCHK(launch_argmax_finalize(v.amax_val, v.amax_idx, p.n, n_dev, ntn, ntn, L.tok + p.r0, seq_out + (size_t)p.r0 * T,
-                                    T, t, s));
+      // vocab projection with the row arg-max fused into the GEMM epilogue (logits never reach HBM); except after
+      // the last step the same launch also produces h.Wh for the next step's gates
+      GemmDesc v;
+      v.A = hstate; v.W = ctx->dec_w; v.bias = ctx->out_b; v.M = p.n; v.K = Hd; v.m_dev = n_dev;
+      v.amax_val = L.logits + (size_t)p.r0 * 2 * ntn;
+      v.amax_idx = reinterpret_cast<int32_t*>(v.amax_val + (size_t)p.n * ntn);
+      v.amax_ld = ntn;
+      if (last) {
+        v.N = V1; v.ldc = V1;
+      } else {
+        v.N = V1pad + 4 * Hd; v.amax_cols = V1pad; v.amax_n = V1; v.C = gates; v.ldc = 4 * Hd;
       }
+      DCCHK(run_gemm(ctx, v, s));
+      KCHK(launch_lstm_step_tail(v.amax_val, v.amax_idx, ntn, ntn, 0, ctx->xg, last ? nullptr : gates,
+                                 L.cstate + (size_t)p.r0 * Hd, hstate, p.n, n_dev, Hd, 0, seq_out + (size_t)p.r0 * T, T, t, s));
     }
   }
   return DC_OK;
@@ -723,7 +742,17 @@ int dc_load_weights(dc_ctx* ctx, const dc_weights* w) {
     DCCHK(linear(ctx, s, emb, ctx->wxT, ctx->lstm_b, ctx->xg, V + 2, 4 * Hd, E, 0));
     HIPCHK(hipStreamSynchronize(s));
   }
-  DCCHK(upload(ctx, &ctx->out_w, w->lm_out_w, (size_t)(V + 1) * Hd));
+  {  // decode-step operand: [Wout (V+1 rows); zero rows to a multiple of 64; Wh^T (4Hd rows)], all with K = Hd -- one GEMM
+     // launch per step produces the vocabulary arg-max of h_t and h_t.Wh for the next step's gates
+    if (!w->lm_out_w || !w->lm_out_b) return ctx->fail(DC_E_INVALID, "null lm_out weight");
+    ctx->V1pad = (V + 1 + 63) / 64 * 64;
+    const size_t rows = (size_t)ctx->V1pad + 4 * Hd;
+    DCCHK(dev_alloc(ctx, (void**)&ctx->dec_w, rows * Hd * 4));
+    HIPCHK(hipMemset(ctx->dec_w, 0, rows * Hd * 4));
+    HIPCHK(hipMemcpy(ctx->dec_w, w->lm_out_w, (size_t)(V + 1) * Hd * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->dec_w + (size_t)ctx->V1pad * Hd, ctx->whT, (size_t)4 * Hd * Hd * 4, hipMemcpyDeviceToDevice));
+    ctx->out_w = ctx->dec_w;
+  }
   DCCHK(upload(ctx, &ctx->out_b, w->lm_out_b, (size_t)V + 1));
   DCCHK(upload(ctx, &ctx->anchors, w->anchors, (size_t)2 * k));
   HIPCHK(hipStreamSynchronize(s));

@@ -210,6 +210,95 @@ __global__ __launch_bounds__(256) void argmax_finalize_kernel(const float* __res
   }
 }
 
+// ---- decode step tail: arg-max finalize + LSTM point-wise, one workgroup (256 threads) per row ---------------------
+// Replaces argmax_finalize + the gate row-term epilogue + lstm_pointwise of one step (3 launches and an 8 MB gate
+// round trip) by one launch: the token a row just produced selects its xg row here, so the h.Wh product of the NEXT
+// step's gates can run inside the same GEMM launch as the vocabulary projection (both only need h_t).
+__global__ __launch_bounds__(256) void lstm_step_tail_kernel(const float* __restrict__ pval,
+                                                             const int32_t* __restrict__ pidx, int ntiles, int ld,
+                                                             int fixed_tok, const float* __restrict__ xg,
+                                                             const float* __restrict__ gates_pre,
+                                                             float* __restrict__ c, float* __restrict__ h, int n,
+                                                             const int32_t* __restrict__ n_dev, int Hd, int zero_c,
+                                                             int32_t* __restrict__ seq, int T, int t) {
+  if (n_dev) n = min(n, *n_dev);
+  const int m = blockIdx.x;
+  if (m >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  // the token-independent operands are requested first: they travel while the arg-max is being reduced
+  constexpr int UPT = 2;                            // hidden units per thread and pass (Hd = 512: one pass)
+  float gpre[UPT][4], cprev[UPT];
+  const float* g = gates_pre ? gates_pre + (size_t)m * 4 * Hd : nullptr;
+  if (g != nullptr) {
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+      const int j = tid + u * 256;
+      if (j < Hd) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gpre[u][q] = g[q * Hd + j];
+        cprev[u] = zero_c ? 0.f : c[(size_t)m * Hd + j];
+      }
+    }
+  }
+  int tok = fixed_tok;
+  if (pval != nullptr) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = tid; j < ntiles; j += 256) {
+      const float v = pval[(size_t)m * ld + j];
+      const int i = pidx[(size_t)m * ld + j];
+      if (bi == 0x7fffffff || v > best) { best = v; bi = i; }      // ascending j = ascending column: first max stays
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { sv[wid] = best; si[wid] = bi; }
+    __syncthreads();
+    best = sv[0]; bi = si[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float ov = sv[w];
+      const int oi = si[w];
+      if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+    }
+    tok = bi + 1;
+    if (tid == 0) seq[(size_t)m * T + t] = tok;
+  }
+  if (g == nullptr) return;
+  const float* x = tok > 0 ? xg + (size_t)(tok - 1) * 4 * Hd : nullptr;
+  for (int j0 = 0; j0 < Hd; j0 += 256 * UPT) {
+    if (j0 > 0) {                                   // Hd > 512: further passes load in place
+#pragma unroll
+      for (int u = 0; u < UPT; ++u) {
+        const int j = j0 + tid + u * 256;
+        if (j < Hd) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gpre[u][q] = g[q * Hd + j];
+          cprev[u] = zero_c ? 0.f : c[(size_t)m * Hd + j];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+      const int j = j0 + tid + u * 256;
+      if (j >= Hd) continue;
+      float gi = gpre[u][0], gf = gpre[u][1], go = gpre[u][2], gg = gpre[u][3];
+      if (x != nullptr) { gi = x[j] + gi; gf = x[Hd + j] + gf; go = x[2 * Hd + j] + go; gg = x[3 * Hd + j] + gg; }
+      const float ig = sigmoidf_(gi), fg = sigmoidf_(gf), og = sigmoidf_(go);
+      const float gt = tanhf(gg);
+      const size_t i = (size_t)m * Hd + j;
+      const float cn = fg * cprev[u] + ig * gt;
+      c[i] = cn;
+      h[i] = og * tanhf(cn);
+    }
+  }
+}
+
 // split-K finish: C = act(sum_s ws[s] + bias), fixed order
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, const float* __restrict__ bias,
                                      float* __restrict__ C, int M, int N, int ldc, int relu) {
@@ -339,6 +428,14 @@ hipError_t launch_argmax_finalize(const float* pval, const int32_t* pidx, int n,
                                   int ld, int32_t* tok, int32_t* seq, int T, int t, hipStream_t s) {
   hipLaunchKernelGGL(argmax_finalize_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pval, pidx, n, n_dev, ntiles, ld, tok,
                      seq, T, t);
+  return hipGetLastError();
+}
+hipError_t launch_lstm_step_tail(const float* pval, const int32_t* pidx, int ntiles, int ld, int fixed_tok,
+                                 const float* xg, const float* gates_pre, float* c, float* h, int n,
+                                 const int32_t* n_dev, int Hd, int zero_c, int32_t* seq, int T, int t, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lstm_step_tail_kernel, dim3(n), dim3(256), 0, s, pval, pidx, ntiles, ld, fixed_tok, xg, gates_pre,
+                     c, h, n, n_dev, Hd, zero_c, seq, T, t);
   return hipGetLastError();
 }
 hipError_t launch_splitk_reduce(const float* ws, int S, const float* bias, float* C, int M, int N, int ldc, int relu,

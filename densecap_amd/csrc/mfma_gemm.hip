@@ -10,16 +10,23 @@
 //     (LanguageModel.lua:27-61) and the fused 1x1 RPN heads.
 //
 // Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain, 64 cycles/SIMD, 157 TF chip peak).
-// Tiling: 256-thread workgroup = 4 waves in a 2x2 grid; wave tile (32*TM)x(32*TN);
-// block tile BM=64*TM, BN=64*TN, BK=32.  A and B tiles live in LDS as [rows][BK+4] fp32
-// (16-byte row pad => conflict-free ds_read_b128 / ds_write_b128).  Each lane fetches 4
-// consecutive k with ONE ds_read_b128 and feeds 4 MFMAs: lane-half h=lane>>5 supplies
-// k = 8g+4h+j to the j-th MFMA of group g, so the hardware's k-pair is (8g+j, 8g+4+j) --
-// a fixed permutation of the summation order, identical for A and B.
-// Pipeline: register-staged double buffering, one s_barrier per K-tile: global loads of
-// tile t+1 are issued before the MFMAs of tile t and written to the other LDS buffer after.
+// Three kernels share the interface (GemmDesc) and the K order of every output element:
+//   * mfma_gemm_v2_kernel<TM,TN,CONV,NS[,AMAX]>  -- the workhorse: 2x2 waves, wave tile (32*TM)x(32*TN), operands
+//     HBM/L2 -> LDS by LDS-DMA (buffer_load ... lds) into an NS-stage ring of unpadded, XOR-swizzled 128-byte rows,
+//     one barrier per K-tile in the middle of the tile's MFMAs.  AMAX = fused row arg-max epilogue (vocabulary
+//     projection) with transposed accumulator blocks; with GemmDesc::amax_cols it also carries the h.Wh half of the
+//     next decode step's gates in the same launch;
+//   * mfma_gemm_ks_kernel<CONV>                  -- 128x128 tile, the four waves split K instead of the tile (half the
+//     LDS->VGPR traffic), cross-wave reduction through LDS at the end; optional split-K over workgroups and row
+//     windows (tail plans);
+//   * mfma_gemm_kernel<TM,TN,CONV> (v1)          -- register-staged, padded LDS rows [BK+4], double buffer: kept for A/B
+//     runs (DENSECAP_GEMM_V1=1) and for operands beyond 32-bit buffer offsets.
+// Each lane fetches 4 consecutive k with ONE ds_read_b128 and feeds 4 MFMAs: lane-half h=lane>>5 supplies
+// k = 8g+4h+j to the j-th MFMA of group g, so the hardware's k-pair is (8g+j, 8g+4+j) -- a fixed permutation of the
+// summation order, identical for A and B and for all three kernels.
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -421,6 +428,32 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
     // ---- fused row arg-max epilogue (vocab projection + torch.max, LanguageModel.lua:326-329) ----
     // acc[i][j] is the transposed block: this lane's row is m = m0 + wm*32*TM + i*32 + (lane&31); register e is column
     // n = n0 + wn*32*TN + j*32 + 8*(e>>2) + 4*hsel + (e&3), ascending in (j, e).  Ties: lower column (first max).
+    const int an = d.amax_cols > 0 ? d.amax_n : d.N;           // real vocabulary columns
+    if (d.amax_cols > 0 && n0 >= d.amax_cols) {
+      // ---- columns past the arg-max prefix (the h.Wh half of the next step's gates): raw store of the transposed
+      // blocks; a lane owns row m and writes 16-byte runs of 4 consecutive columns
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * 32 * TM + i * 32 + r;
+        if (m >= Meff) continue;
+        float* crow = d.C + (size_t)m * d.ldc - d.amax_cols;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int nb = n0 + wn * 32 * TN + j * 32 + 8 * q4 + 4 * hsel;
+            if (nb + 3 < d.N) {
+              *reinterpret_cast<f32x4*>(crow + nb) =
+                  f32x4{acc[i][j][q4 * 4 + 0], acc[i][j][q4 * 4 + 1], acc[i][j][q4 * 4 + 2], acc[i][j][q4 * 4 + 3]};
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                if (nb + c < d.N) crow[nb + c] = acc[i][j][q4 * 4 + c];
+            }
+          }
+      }
+      return;
+    }
     __syncthreads();                        // everyone is done reading the operand ring (reused below)
     float* red_v = smem;                    // [2 (wn)][BM]
     int* red_i = reinterpret_cast<int*>(smem + 2 * BM);
@@ -435,14 +468,14 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
           const int nb = n0 + wn * 32 * TN + j * 32 + 8 * q4 + 4 * hsel;     // 4 consecutive columns, 16-byte aligned
           f32x4 bv = {0.f, 0.f, 0.f, 0.f};
           if (d.bias != nullptr) {
-            if (nb + 3 < d.N) bv = *reinterpret_cast<const f32x4*>(d.bias + nb);
+            if (nb + 3 < an) bv = *reinterpret_cast<const f32x4*>(d.bias + nb);
             else
 #pragma unroll
-              for (int c = 0; c < 4; ++c) bv[c] = nb + c < d.N ? d.bias[nb + c] : 0.f;
+              for (int c = 0; c < 4; ++c) bv[c] = nb + c < an ? d.bias[nb + c] : 0.f;
           }
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const float v = nb + c < d.N ? acc[i][j][q4 * 4 + c] + bv[c] : -INFINITY;
+            const float v = nb + c < an ? acc[i][j][q4 * 4 + c] + bv[c] : -INFINITY;
             if (v > best) { best = v; bi = nb + c; }
           }
         }
@@ -698,12 +731,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
   // ---- cross-wave reduction of the four K-partials + epilogue, one 64x64 quadrant per phase -------------
   // phase q: every wave stores its partial of quadrant q in MFMA register order (wave w -> slot w, 16 KiB);
   // then ALL waves sum the four slots (fixed order ((w0+w1)+w2)+w3): wave w' takes register group e4 = w' of
-  // the quadrant's four 32x32 tiles and either stores bias/row-term/ReLU results (128-byte row segments) or,
-  // for the fused arg-max, drops biased logits into an LDS tile that is scanned afterwards.
-  const bool amax = !CONV && d.amax_val != nullptr;
-  constexpr int LDT = BN + 1;
+  // the quadrant's four 32x32 tiles and stores bias/row-term/ReLU results (128-byte row segments).
   float* const slots = smem;                         // [4 waves][4 tiles][4 e4][64 lanes][4]
-  float* const tile = smem + 4 * 4096;               // [BM][LDT] (arg-max only)
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -741,9 +770,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
         for (int c = 0; c < 4; ++c) {
           const int row_l = (qi + i) * 32 + c + 8 * wid + 4 * hsel;
           const int m = m0 + row_l;
-          if (amax) {
-            tile[row_l * LDT + col_l] = n_ok ? s0[c] + bv : -INFINITY;
-          } else if (d.splitk > 1) {
+          if (d.splitk > 1) {
             if (n_ok && m < Meff) d.splitk_ws[((size_t)slice * (d.M - d.m_begin) + (m - d.m_begin)) * d.N + n] = s0[c];
           } else if (n_ok && m < Meff) {
             float v;
@@ -756,31 +783,30 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
       }
     __syncthreads();
   }
-  if (amax) {
-    // fused row arg-max (vocab projection + torch.max, LanguageModel.lua:326-329): two threads per row
-    constexpr int TPR = 256 / BM, CPT = BN / TPR;
-    const int row = tid / TPR, part = tid % TPR;
-    const float* p = tile + row * LDT + part * CPT;
-    float best = p[0];
-    int bi = 0;
-#pragma unroll 8
-    for (int c = 1; c < CPT; ++c) {
-      const float v = p[c];
-      if (v > best) { best = v; bi = c; }
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: a process that drives several
+// devices (N contexts in N host threads, include/densecap.h) must raise it on each of them.  (device, kernel) pairs
+// already raised are remembered; a host mutex makes the table safe for one ctx per thread.
+hipError_t ensure_dyn_lds(const void* fn, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  struct Ent { int dev; const void* fn; size_t bytes; };
+  static std::mutex mu;
+  static std::vector<Ent> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  for (Ent& t : done)
+    if (t.dev == dev && t.fn == fn) {
+      if (t.bytes >= bytes) return hipSuccess;
+      e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (e == hipSuccess) t.bytes = bytes;
+      return e;
     }
-    bi += n0 + part * CPT;
-#pragma unroll
-    for (int o = 1; o < TPR; o <<= 1) {
-      const float ov = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-    }
-    const int m = m0 + row;
-    if (part == 0 && m < Meff) {
-      d.amax_val[(size_t)m * d.amax_ld + tile_n] = best;
-      d.amax_idx[(size_t)m * d.amax_ld + tile_n] = bi;
-    }
-  }
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) done.push_back({dev, fn, bytes});
+  return e;
 }
 
 template <int TM, int TN, bool CONV>
@@ -795,74 +821,51 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
     if constexpr (TM == 2 && TN == 2) {
       static const bool no_ks = getenv("DENSECAP_GEMM_NOKS") != nullptr;
       const bool forced = d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0;
+      if (d.amax_val != nullptr) return hipErrorInvalidValue;    // the arg-max epilogue lives in the 64-column v2 variant
       if (!no_ks && (d.K % (2 * BK * d.splitk)) == 0 && (forced || d.K >= 32 * BK)) {   // short K loops do not amortise the 4-phase reduction
-        // 64 KiB operand ring, reused as the 4 x 16 KiB reduction slots; + a 128 x 129 tile for the fused arg-max
-        const size_t lds_ks_max = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)BM * (BN + 1) * sizeof(float);
-        // without the arg-max tile a K-split workgroup leaves 96 KiB of the CU's LDS to co-resident workgroups
-        const size_t lds_ks = d.amax_val != nullptr ? lds_ks_max : (size_t)2 * (BM + BN) * BK * sizeof(float);
-        static bool attrk = false;
-        if (!attrk) {
-          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_ks_kernel<CONV>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ks_max);
-          if (e != hipSuccess) return e;
-          attrk = true;
-        }
+        // 64 KiB operand ring, reused as the 4 x 16 KiB reduction slots; leaves 96 KiB of the CU's LDS to co-resident workgroups
+        const size_t lds_ks = (size_t)2 * (BM + BN) * BK * sizeof(float);
+        const void* fn = reinterpret_cast<const void*>(&mfma_gemm_ks_kernel<CONV>);
+        if (hipError_t e = ensure_dyn_lds(fn, lds_ks); e != hipSuccess) return e;
         hipLaunchKernelGGL((mfma_gemm_ks_kernel<CONV>), dim3(ntm * ntn * d.splitk), dim3(256), lds_ks, stream, d, ntm, ntn,
                            m_fastest);
         return hipGetLastError();
       }
     }
     if (d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0) return hipErrorInvalidValue;   // K-split kernel features
-    if constexpr (!CONV) {
+    if constexpr (!CONV && TN == 1) {
       if (d.amax_val != nullptr) {
+        if (d.amax_cols % BN != 0 || (d.amax_cols > 0 && (d.C == nullptr || d.amax_n > d.amax_cols || d.amax_cols > d.N)))
+          return hipErrorInvalidValue;
         const size_t lds3 = (size_t)3 * (BM + BN) * BK * sizeof(float);
-        static bool attr_amax = false;
-        if (!attr_amax) {
-          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, false, 3, true>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-          if (e != hipSuccess) return e;
-          attr_amax = true;
-        }
+        const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, false, 3, true>);
+        if (hipError_t e = ensure_dyn_lds(fn, lds3); e != hipSuccess) return e;
         hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, false, 3, true>), dim3(ntm * ntn), dim3(256), lds3, stream, d, ntm,
                            ntn, m_fastest);
         return hipGetLastError();
       }
     }
+    if (d.amax_val != nullptr) return hipErrorInvalidValue;
     static const int ns_env = getenv("DENSECAP_GEMM_STAGES") ? atoi(getenv("DENSECAP_GEMM_STAGES")) : 0;
     const int ns = ns_env == 4 ? 4 : 3;
     const size_t lds = (size_t)ns * (BM + BN) * BK * sizeof(float);
     if (ns == 4) {
-      static bool attr4 = false;
-      if (!attr4) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, CONV, 4>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr4 = true;
-      }
+      const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, CONV, 4>);
+      if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
       hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, CONV, 4>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn,
                          m_fastest);
       return hipGetLastError();
     }
-    static bool attr2 = false;
-    if (!attr2) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, CONV, 3>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      attr2 = true;
-    }
+    const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, CONV, 3>);
+    if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, CONV, 3>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn,
                        m_fastest);
     return hipGetLastError();
   }
   if (d.amax_val != nullptr || d.m_dev != nullptr || d.splitk > 1) return hipErrorInvalidValue;  // v2/ks-only features
   const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_gemm_kernel<TM, TN, CONV>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  const void* fn = reinterpret_cast<const void*>(&mfma_gemm_kernel<TM, TN, CONV>);
+  if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL((mfma_gemm_kernel<TM, TN, CONV>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn,
                      m_fastest);
   return hipGetLastError();
@@ -879,7 +882,11 @@ hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
   // fused arg-max: 128x64 tiles (72 KiB LDS, two workgroups per CU) overlap one tile's LDS-transpose epilogue
   // with the other's K loop -- measured 2.43 vs 2.51 ms for the 15 decode steps at 1000 x 10498
   // and the same holds for every K loop too short for the K-split kernel (conv2_1: 214 -> 178 us)
-  if ((d.amax_val != nullptr || d.K < 32 * BK) && d.N > 64 && blocks(128, 128) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
+  if (d.amax_val != nullptr) {           // arg-max epilogue: 64-column tiles only (the partial rows are indexed by tile_n)
+    if (blocks(128, 64) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
+    return launch_cfg<1, 1, CONV>(d, stream);
+  }
+  if (d.K < 32 * BK && d.N > 64 && blocks(128, 128) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
   if (d.N > 64 && blocks(128, 128) >= 384) return launch_cfg<2, 2, CONV>(d, stream);
   if (d.N <= 64 && blocks(128, 64) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
   if (d.N > 64 && blocks(128, 128) >= 200 && blocks(128, 128) <= 256) return launch_cfg<2, 2, CONV>(d, stream);
@@ -890,9 +897,10 @@ hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
 }  // namespace
 
 int mfma_gemm_ntiles_n(const GemmDesc& d) {
+  if (d.amax_val != nullptr) return (d.N + 63) / 64;        // mirrors launch_pick: the arg-max variants use BN = 64
   auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
   int bn;
-  if (d.N > 64 && blocks(128, 128) >= 384) bn = (d.amax_val != nullptr || d.K < 32 * BK) ? 64 : 128;   // mirrors launch_pick
+  if (d.N > 64 && blocks(128, 128) >= 384) bn = d.K < 32 * BK ? 64 : 128;   // mirrors launch_pick
   else if (d.N <= 64 && blocks(128, 64) >= 384) bn = 64;
   else if (d.N > 64 && blocks(128, 128) >= 200 && blocks(128, 128) <= 256) bn = 128;
   else bn = 64;
@@ -963,7 +971,11 @@ hipError_t launch_mfma_gemm_ks(const GemmDesc& d, hipStream_t stream) {
   return launch_cfg<2, 2, false>(d, stream);
 }
 
-double gemm_flops(const GemmDesc& d) { return 2.0 * (double)d.M * (double)d.N * (double)d.K; }
+// algorithmic FLOPs (the zero rows that pad the arg-max prefix to a tile boundary do not count)
+double gemm_flops(const GemmDesc& d) {
+  const double n = d.amax_cols > 0 ? (double)d.amax_n + (double)(d.N - d.amax_cols) : (double)d.N;
+  return 2.0 * (double)d.M * n * (double)d.K;
+}
 
 hipError_t launch_mfma_gemm(const GemmDesc& d, hipStream_t stream) {
   if (d.M <= 0 || d.N <= 0 || d.K <= 0 || (d.K % BK) != 0) return hipErrorInvalidValue;
