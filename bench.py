@@ -6,13 +6,19 @@ One "step" = DenseCapModel:forward_test on ONE synthetic 720x600 image with 1000
 heads -> greedy LSTM decode (T=15, V=10497) -> final NMS.  Images are resident in HBM before
 the timed region; results (boxes, scores, tokens) come back to the host inside it.
 
-N GPUs: one process per GPU (torch.distributed / RCCL), images sharded contiguously, weak
-scaling (K images per GPU), one gather of the padded (boxes,scores,tokens) records at the end of
-the timed region.  Prints ONE JSON line on rank 0.
+Timed region = exactly K steps between barrier + device sync on both sides, max over ranks.  It is
+repeated `--repeats` times inside one invocation (0.12 s is too short to stand alone) and the MEDIAN
+repeat is reported; every repeat's rate is in the line.
+
+N GPUs: one process per GPU (torch.distributed), images sharded contiguously, weak scaling (K images
+per GPU), ONE gather of the typed (boxes,scores,tokens) records on rank 0 at the end of each timed
+region: dc_gather_results of the C ABI (RCCL send/recv over xGMI) or, with --gather torch, one
+torch.distributed gather of the same packed records.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -20,6 +26,62 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+HBM_PEAK_GBPS = 8000.0
+PMC_PROFILE = os.path.join("profiles", "r02_pmc_summary.json")
+
+VGG = [(3, 64, 0), (64, 64, 1), (64, 128, 0), (128, 128, 1), (128, 256, 0), (256, 256, 0), (256, 256, 1),
+       (256, 512, 0), (512, 512, 0), (512, 512, 1), (512, 512, 0), (512, 512, 0), (512, 512, 0)]
+
+
+def stage_gflop(H, W, P, T, V, k=12, R=256, D=4096, E=512, Hd=512):
+    """Algorithmic GFLOP (2 x MAC) per image and stage -- SURVEY.md 8(d)."""
+    h, w, trunk = H, W, 0.0
+    for cin, cout, pool in VGG:
+        trunk += 2.0 * h * w * cin * cout * 9
+        if pool:
+            h, w = (h + 1) // 2, (w + 1) // 2
+    rpn = 2.0 * h * w * (512 * R * 9 + R * 6 * k)
+    fc = 2.0 * P * (512 * 49 * D + D * D)
+    # encoder + step-0 gates + T x (h.Wh + vocabulary projection); the discarded step-0 projection is not computed
+    lm = 2.0 * P * (D * E + E * 4 * Hd + T * Hd * 4 * Hd + T * Hd * (V + 1))
+    return {"vgg16_trunk": trunk / 1e9, "rpn_conv_heads_decode": rpn / 1e9, "fc6_fc7": fc / 1e9, "lstm_decode": lm / 1e9}
+
+
+class StubModel:
+    """CPU stand-in with the product model's batch interface (bench.py --stub): lets the multi-rank control flow of this
+    file (sharding, warm-up, barriers, gather, max-over-ranks timing, JSON) run under gloo without a GPU.  Its numbers
+    are not measurements (the line says "data": "stub")."""
+    seq_length = 15
+
+    def __init__(self, P):
+        self.P = P
+
+    def setLanes(self, n):
+        return self
+
+    def forward_batch_device(self, imgs, n, H, W):
+        import numpy as np
+        out = []
+        for i in range(n):
+            rng = np.random.default_rng(int(imgs[i]))
+            k = int(rng.integers(1, self.P + 1))
+            out.append((rng.standard_normal((k, 4)).astype(np.float32),
+                        np.sort(rng.standard_normal(k).astype(np.float32))[::-1].copy(),
+                        rng.integers(1, 10499, (k, 15)).astype(np.int32)))
+        return out
+
+    def stage_times(self):
+        return {}
+
+    def mfma_profile(self, reset=0):
+        return dict(launches=0, ms=0.0, flops=0.0)
+
+
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
 
 
 def main():
@@ -27,6 +89,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=720)
     ap.add_argument("--proposals", type=int, default=1000)
@@ -35,6 +98,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-pass", action="store_true",
                     help="skip the secondary caption-order measurement (keeps rocprof kernel statistics to one workload)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for barriers / timing (gloo: ranks may share one GPU, or none with --stub)")
+    ap.add_argument("--gather", default="auto", choices=["auto", "abi", "torch"],
+                    help="carrier of the end-of-run gather: abi = dc_gather_results (RCCL), torch = torch.distributed.gather")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -48,116 +116,160 @@ def main():
                                    "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
 
     import numpy as np
-    import torch  # device sync + torch.distributed (RCCL); loaded first so one HIP runtime is shared
+    import torch  # device sync + torch.distributed; loaded first so one HIP runtime is shared
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    on_gpu = not args.stub
+    # ranks may outnumber the visible GPUs only in the gloo configuration (two ranks on GPU 0 in the tests)
+    ndev = torch.cuda.device_count() if on_gpu else 0
+    device_index = local_rank % max(ndev, 1)
+    if on_gpu and args.dist_backend == "nccl" and world > ndev:
+        raise SystemExit("bench.py: %d ranks but %d GPUs visible (RCCL needs one GPU per rank)" % (world, ndev))
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if on_gpu:
+            torch.cuda.set_device(device_index)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo")
     else:
         dist = None
-
-    import ctypes as C
-    from densecap_amd import DenseCapModel
-    from densecap_amd._lib import check
-    from densecap_amd.weights import make_synthetic_image, make_synthetic_weights
+    gather_kind = args.gather
+    if gather_kind == "auto":
+        gather_kind = "abi" if (args.dist_backend == "nccl" and on_gpu) else "torch"
+    coll_device = torch.device("cuda", device_index) if (args.dist_backend == "nccl" and on_gpu) else None
 
     H, W, P, K, Wm = args.height, args.width, args.proposals, args.steps, args.warmup
-    weights = make_synthetic_weights(seed=1234)           # V=10497, T=15 in checkpoint shapes
-    model = DenseCapModel(weights, device=local_rank)
-    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
-    model.setLanes(args.lanes if args.lanes > 0 else 3)
-    ctx = model.ctx
-
-    # K distinct images per rank (global image id = rank*K + i), resident in HBM
+    T, V = 15, 10497
     n_img = max(K, Wm, args.lanes, 4, 1)
-    host = np.stack([make_synthetic_image(H, W, rank * n_img + i) for i in range(n_img)])
-    dev = ctx.to_device(host)
+    if on_gpu:
+        from densecap_amd import DenseCapModel
+        from densecap_amd._lib import check
+        from densecap_amd.weights import make_synthetic_image, make_synthetic_weights
+        weights = make_synthetic_weights(seed=1234)           # V=10497, T=15 in checkpoint shapes
+        model = DenseCapModel(weights, device=device_index)
+        model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
+        model.setLanes(args.lanes if args.lanes > 0 else 3)
+        ctx = model.ctx
+        # K distinct images per rank (global image id = rank*n_img + i), resident in HBM
+        host = np.stack([make_synthetic_image(H, W, rank * n_img + i) for i in range(n_img)])
+        dev = ctx.to_device(host)
+        imgs = dev.ptr
 
-    def sync():
-        check(ctx.h, ctx.lib.dc_synchronize(ctx.h), "dc_synchronize")
-        if torch.cuda.is_available():
+        def sync():
+            check(ctx.h, ctx.lib.dc_synchronize(ctx.h), "dc_synchronize")
             torch.cuda.synchronize()
+    else:
+        model = StubModel(P)
+        imgs = [rank * n_img + i for i in range(n_img)]
 
-    # setup (not a step): one image per lane so that every lane's workspace exists before anything is timed
+        def sync():
+            pass
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # ---- the path's single collective -------------------------------------------------------------------
+    comm = None
+    if dist is not None and gather_kind == "abi":
+        from densecap_amd import dist as D
+        idt = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            idt = torch.frombuffer(bytearray(D.Comm.unique_id(ctx.lib)), dtype=torch.uint8).clone()
+        idt = idt.to(coll_device) if coll_device is not None else idt
+        dist.broadcast(idt, src=0)                       # rendezvous id of the RCCL communicator, out of band
+        comm = D.Comm(ctx, rank, world, bytes(idt.cpu().numpy().tobytes()))
+
+    def gather(results):
+        if dist is None:
+            return [results]
+        from densecap_amd import dist as D
+        if comm is not None:
+            return comm.gather(results, P, model.seq_length)
+        return D.gather_records(dist, results, P, model.seq_length, rank, world, device=coll_device)
+
+    # ---- setup (not a step): lane workspaces, lane-count trial, warm-up incl. the collective ------------------
     lane_trials = None
-    if args.lanes <= 0:
+    if on_gpu and args.lanes <= 0:
         # scheduling knob only (results are bit-identical for any lanes >= 2): which count overlaps best differs
         # between otherwise identical boxes, so it is chosen by a short untimed trial on this device
-        lane_trials = model.autotuneLanes(dev.ptr, min(n_img, 12), H, W)
+        lane_trials = model.autotuneLanes(imgs, min(n_img, 12), H, W)
         args.lanes = max(lane_trials, key=lane_trials.get)
-    model.forward_batch_device(dev.ptr, min(args.lanes, n_img), H, W)
-    if Wm > 0:
-        wres = model.forward_batch_device(dev.ptr, Wm, H, W)
-    else:
-        wres = model.forward_batch_device(dev.ptr, 1, H, W)
+        if dist is not None:
+            # one setting for the whole job (a rank-local choice would still be valid, this keeps the line simple)
+            lt = torch.tensor([args.lanes], dtype=torch.int32, device=coll_device)
+            dist.broadcast(lt, src=0)
+            args.lanes = int(lt.item())
+            model.setLanes(args.lanes)
+    elif args.lanes <= 0:
+        args.lanes = 1
+    model.forward_batch_device(imgs, min(args.lanes, n_img), H, W)
+    wres = model.forward_batch_device(imgs, max(Wm, 1), H, W)
     if dist is not None:
-        # warm the collective too (communicator setup of the first RCCL call is not part of a step)
-        from densecap_amd import dist as D
-        wrec = D.pack_records([wres[0]] * K, P, model.seq_length)
-        D.gather_records(dist, wrec[0], wrec[1], rank, world, device=torch.device("cuda", local_rank))
+        gather(([wres[0]] * K)[:K])      # communicator / buffer setup of the first collective is not part of a step
     sync()
-    if args.lanes == 1:
-        model.mfma_profile(reset=1)  # HIP events around every MFMA launch during the timed region
-    if dist is not None:
-        dist.barrier()
-    sync()
-    t0 = time.perf_counter()
-    results = model.forward_batch_device(dev.ptr, K, H, W)
-    if dist is not None:
-        # the single collective of the path: gather padded records on rank 0 over RCCL/xGMI
-        from densecap_amd import dist as D
-        rec, cnt = D.pack_records(results, P, model.seq_length)
-        gathered = D.gather_records(dist, rec, cnt, rank, world, device=torch.device("cuda", local_rank))
+    if on_gpu and args.lanes == 1:
+        model.mfma_profile(reset=1)      # HIP events around every MFMA launch during the timed regions
+
+    # ---- timed regions ----------------------------------------------------------------------------------------
+    elapsed_all, total_boxes = [], 0
+    for rep in range(max(1, args.repeats)):
+        barrier()
+        sync()
+        t0 = time.perf_counter()
+        results = model.forward_batch_device(imgs, K, H, W)
+        gathered = gather(results)
+        sync()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        elapsed_all.append(elapsed)
         if rank == 0:
             total_boxes = int(sum(len(b) for shard in gathered for b, _, _ in shard))
-    else:
-        total_boxes = int(sum(len(b) for b, _, _ in results))
-    sync()
-    if dist is not None:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+            if dist is not None:
+                assert len(gathered) == world and all(len(s) == K for s in gathered), "gather returned a wrong shape"
+    order = sorted(range(len(elapsed_all)), key=lambda i: elapsed_all[i])
+    elapsed = elapsed_all[order[len(order) // 2]]          # median repeat
+    nrep = len(elapsed_all)
     prof = model.mfma_profile(reset=-1)
     stage = model.stage_times()
+
     # Secondary figure (not `value`): final NMS first, captions only for the surviving boxes -- bit-identical
     # outputs (tests/test_gpu_e2e.py::test_caption_order_is_output_invariant), less LSTM work.
     alt = None
-    if dist is None and not args.no_alt_pass:
+    if on_gpu and dist is None and not args.no_alt_pass:
         model.setCaptionOrder(True)
-        model.forward_batch_device(dev.ptr, min(2, K), H, W)
+        model.forward_batch_device(imgs, min(2, K), H, W)
         sync()
         a0 = time.perf_counter()
-        model.forward_batch_device(dev.ptr, K, H, W)
+        model.forward_batch_device(imgs, K, H, W)
         sync()
         alt = K / (time.perf_counter() - a0)
         model.setCaptionOrder(False)
     serial_pass = False
-    if rank == 0 and args.lanes != 1:
-        # Per-kernel durations are only meaningful when kernels do not overlap: with >1 lanes the MFMA
-        # launches of different images run concurrently.  Roofline pass: the same workload on ONE lane,
-        # HIP events around every MFMA launch (on the stream it is launched on).
+    nprof = K * nrep
+    if on_gpu and rank == 0 and args.lanes != 1:
+        # Per-kernel durations are only meaningful when kernels do not overlap: with >1 lanes the MFMA launches of
+        # different images run concurrently.  Roofline pass: the same workload on ONE lane, HIP events around every
+        # MFMA launch (on the stream it is launched on).  It describes the serial schedule, not the timed one.
         model.setLanes(1)
-        nroof = min(K, 5)
-        model.forward_batch_device(dev.ptr, 1, H, W)
+        nprof = min(K, 5)
+        model.forward_batch_device(imgs, 1, H, W)
         sync()
         model.mfma_profile(reset=1)
-        model.forward_batch_device(dev.ptr, nroof, H, W)
+        model.forward_batch_device(imgs, nprof, H, W)
         sync()
         prof = model.mfma_profile(reset=-1)
         stage = model.stage_times()
         model.setLanes(args.lanes)
         serial_pass = True
-    nprof = (min(K, 5) if serial_pass else K)
-    # whole-timed-region figure: MFMA FLOPs of the K images / wall time (launches of the lanes overlap)
-    prof_all_flops = world * K * (prof["flops"] / nprof) if prof["flops"] else 0.0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
 
     if rank == 0:
         out = {
@@ -172,58 +284,79 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if on_gpu else "stub",
             "config": {"workload": "forward_test: one %dx%d image, VGG-16 trunk + %d proposals + greedy LSTM "
                                    "decode (T=15,V=10497), synthetic weights" % (W, H, P),
                        "images_per_gpu": K, "parallelism": "image-sharded x%d" % world,
-                       "total_output_boxes": total_boxes},
+                       "total_output_boxes": total_boxes,
+                       "gather": None if dist is None else ("dc_gather_results (RCCL send/recv)" if comm is not None
+                                                             else "torch.distributed.gather (%s)" % args.dist_backend)},
+            "repeats": {"n": nrep, "statistic": "median", "images_per_s": [world * K / e for e in elapsed_all]},
         }
-        ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
-        out["roofline"] = {
-            "bound": "mfma", "kernel": "mfma_gemm_kernel (fp32 32x32x2 MFMA: conv trunk, fc6/fc7, LSTM, vocab)",
-            "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-            "launches_per_image": prof["launches"] / float(nprof),
-            "algorithmic_gflop_per_image": prof["flops"] / 1e9 / nprof,
-            "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
-            "mfma_ms_per_image": prof["ms"] / nprof,
-            "measured_on": ("separate 1-lane pass of %d images after the timed region" % nprof) if serial_pass
-                           else "the timed region (1 lane)",
-        }
-        # HBM bytes per MFMA launch cannot be measured from inside the process: taken from the committed
-        # rocprofv3 PMC passes of this same command with --lanes 1 (tools/pmc_summary.py -> profiles/)
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-            fam = [v for k, v in pm.items() if k.startswith("mfma_gemm") and "avg_hbm_bytes_per_launch" in v]
-            calls = sum(v["calls"] for v in fam)
-            out["roofline"]["traffic"] = sum(v["avg_hbm_bytes_per_launch"] * v["calls"] for v in fam) / calls
-            out["roofline"]["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), profiles/r01_pmc_summary.json"
-            out["roofline"]["mfma_util_pmc"] = sum(v.get("mfma_util", 0) * v["total_us"] for v in fam) / sum(v["total_us"] for v in fam)
-        except Exception:
-            pass
-        out["roofline"]["overlapped_effective_tflops"] = (prof_all_flops / elapsed / 1e12) if prof_all_flops else None
-        # HBM-side stages named by BASELINE.json (bilinear sampler, NMS): algorithmic bytes / stage time of
-        # the serial pass; the PMC-measured HBM bytes of the same kernels are in profiles/r01_pmc_summary.json
-        fh, fw = (H + 15) // 16, (W + 15) // 16
-        A = 12 * fh * fw
-        roi_bytes = 4.0 * 512 * (fh * fw + P * 49) + 16.0 * P
-        nms_bytes = 20.0 * A + 8.0 * P
-        hb = {}
-        if stage.get("bilinear_roi_pool", 0) > 0:
-            hb["bilinear_roi_pool"] = {"algorithmic_bytes": roi_bytes, "ms": stage["bilinear_roi_pool"],
-                                       "GBps": roi_bytes / (stage["bilinear_roi_pool"] * 1e-3) / 1e9, "peak_GBps": 8000.0}
-        if stage.get("rpn_nms", 0) > 0:
-            hb["rpn_nms"] = {"algorithmic_bytes": nms_bytes, "ms": stage["rpn_nms"],
-                             "GBps": nms_bytes / (stage["rpn_nms"] * 1e-3) / 1e9, "peak_GBps": 8000.0,
-                             "note": "latency-bound by construction (greedy dependency chain), see DESIGN.md 4.2"}
-        out["hbm_stages"] = hb
-        out["lanes"] = args.lanes
-        if lane_trials is not None:
-            out["lanes_trial_images_per_s"] = {str(k): v for k, v in lane_trials.items()}
-        if alt is not None:
-            out["value_captions_after_final_nms"] = alt   # same outputs, decode only final-NMS survivors
-        out["stage_ms_serial_image"] = stage
-        if world == 1 and not args.no_cpu_baseline:
+        if on_gpu:
+            gf = stage_gflop(H, W, P, T, V)
+            ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
+            mfma_flops_per_image = prof["flops"] / max(nprof, 1)
+            roof = {
+                "bound": "mfma",
+                "kernel": "fp32 MFMA contraction family (v_mfma_f32_32x32x2_f32): mfma_gemm_ks_kernel<CONV> (K-split "
+                          "128x128: conv2_1..5_3, RPN conv, fc6, fc7, LM encoder), mfma_gemm_v2_kernel<TM,TN,CONV,3[,AMAX]> "
+                          "(conv1_2, RPN heads, LSTM gates, decode step = vocabulary arg-max + h.Wh)",
+                "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "launches_per_image": prof["launches"] / float(max(nprof, 1)),
+                "algorithmic_gflop_per_image": mfma_flops_per_image / 1e9,
+                "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
+                "serial_mfma_ms_per_image": prof["ms"] / max(nprof, 1),
+                "measured_on": ("separate 1-lane (serial) pass of %d images after the timed regions: per-launch HIP events "
+                                "need non-overlapping kernels" % nprof) if serial_pass
+                               else "the timed regions themselves (1 lane)",
+            }
+            # per-stage fractions of the fp32 MFMA peak from the serial stage times of the same pass (the metric's
+            # "conv MFMA util" is trunk_frac)
+            for key, name in (("vgg16_trunk", "trunk_frac"), ("fc6_fc7", "fc_frac"), ("lstm_decode", "decode_frac")):
+                if stage.get(key, 0) > 0:
+                    roof[name] = gf[key] / stage[key] / FP32_MFMA_PEAK_TFLOPS
+            roof["stage_gflop_per_image"] = gf
+            roof["serial_ms_per_image"] = sum(stage.values()) if stage else None
+            # whole-timed-region figure: MFMA FLOPs of the K images / wall time (launches of the lanes overlap)
+            roof["timed_region_effective_tflops"] = world * K * mfma_flops_per_image / elapsed / 1e12
+            # HBM bytes per MFMA launch cannot be measured from inside the process: quoted from the committed rocprofv3
+            # PMC passes of this same command with --lanes 1 (tools/collect_profiles.sh + tools/pmc_summary.py)
+            try:
+                pm = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
+                fam = [v for k, v in pm.items() if k.startswith("mfma_gemm") and "avg_hbm_bytes_per_launch" in v]
+                calls = sum(v["calls"] for v in fam)
+                roof["traffic_from_profile"] = {
+                    "hbm_bytes_per_launch": sum(v["avg_hbm_bytes_per_launch"] * v["calls"] for v in fam) / calls,
+                    "mfma_util_pmc": sum(v.get("mfma_util", 0) * v["total_us"] for v in fam) / sum(v["total_us"] for v in fam),
+                    "file": PMC_PROFILE, "profile_commit": pm.get("_commit"), "bench_commit": git_head(),
+                    "unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), separate --pmc passes"}
+            except Exception:
+                roof["traffic_from_profile"] = None
+            out["roofline"] = roof
+            # HBM-side stages named by BASELINE.json (bilinear sampler, NMS): algorithmic bytes / stage time
+            fh, fw = (H + 15) // 16, (W + 15) // 16
+            A = 12 * fh * fw
+            roi_bytes = 4.0 * 512 * (fh * fw + P * 49) + 16.0 * P
+            nms_bytes = 20.0 * A + 8.0 * P
+            hb = {}
+            if stage.get("bilinear_roi_pool", 0) > 0:
+                hb["bilinear_roi_pool"] = {"algorithmic_bytes": roi_bytes, "ms": stage["bilinear_roi_pool"],
+                                           "GBps": roi_bytes / (stage["bilinear_roi_pool"] * 1e-3) / 1e9,
+                                           "peak_GBps": HBM_PEAK_GBPS}
+            if stage.get("rpn_nms", 0) > 0:
+                hb["rpn_nms"] = {"algorithmic_bytes": nms_bytes, "ms": stage["rpn_nms"],
+                                 "GBps": nms_bytes / (stage["rpn_nms"] * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBPS,
+                                 "note": "latency-bound by construction (greedy dependency chain), see DESIGN.md 4.2"}
+            out["hbm_stages"] = hb
+            out["lanes"] = args.lanes
+            if lane_trials is not None:
+                out["lanes_trial_images_per_s"] = {str(k): v for k, v in lane_trials.items()}
+            if alt is not None:
+                out["value_captions_after_final_nms"] = alt   # same outputs, decode only final-NMS survivors
+            out["stage_ms_serial_image"] = stage
+        if on_gpu and world == 1 and not args.no_cpu_baseline:
             # the restated reference CPU path (oracle) on a bounded sample of the same workload
             from oracle import densecap_oracle as O
             ncores = os.cpu_count() or 1
@@ -240,8 +373,11 @@ def main():
                                    "host_cores": ncores,
                                    "sample": "%d images %dx%d P=%d, restated reference CPU path (torch-CPU fp32 "
                                              "GEMM/conv + C NMS/sampler; Torch7 unavailable)" % (nb, W, H, P)}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -10,6 +10,10 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- ctx accessors for the other translation units (densecap.hip) ------------------
+int dc_ctx_device(const dc_ctx* ctx);
+void dc_ctx_set_error(dc_ctx* ctx, const char* msg);
+
 // ---- MFMA contraction engine (mfma_gemm.hip) --------------------------------
 struct GemmDesc {
   const float* A = nullptr;   // dense: (M,K) row-major; conv: (nimg,H,W,Cin) HWC activations

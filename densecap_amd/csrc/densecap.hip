@@ -578,6 +578,9 @@ int lane0_stream(dc_ctx* ctx, hipStream_t* s) {
 
 }  // namespace
 
+int dc_ctx_device(const dc_ctx* ctx) { return ctx->device; }
+void dc_ctx_set_error(dc_ctx* ctx, const char* msg) { ctx->err = msg; g_last_error = msg; }
+
 // ======================================================================================
 // C ABI
 // ======================================================================================

@@ -154,6 +154,28 @@ int dc_mfma_profile(dc_ctx* ctx, int reset, int64_t* launches, double* total_ms,
  * Returns the number of elements copied (or <0). */
 int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t capacity_bytes);
 
+/* ---- multi-GPU: image shards + ONE gather ------------------------------------ */
+/* The reference binds one device (densecap/utils.lua:22-36) and loops over images on it
+ * (run_model.lua:160-180).  Here images shard by index over ranks (one process or thread and one
+ * dc_ctx per GPU, weights replicated, no data-path exchange); the only communication is one gather
+ * of the per-image results on rank 0: RCCL point-to-point over xGMI, rank 0 posting world-1 receives
+ * and every peer one send inside a single group.  librccl is dlopen()ed by dc_comm_create (world > 1)
+ * or dc_comm_unique_id; the single-GPU path does not depend on it. */
+#define DC_COMM_ID_BYTES 128
+typedef struct dc_comm dc_comm;
+/* Rank 0 creates the 128-byte rendezvous id (ncclUniqueId) and hands it to the other ranks out of
+ * band (file, environment, launcher). */
+int dc_comm_unique_id(void* id_out);
+/* Collective over all ranks (blocks until everyone has joined).  world == 1 needs no id and no RCCL. */
+int dc_comm_create(dc_comm** out, dc_ctx* ctx, const void* id, int rank, int world);
+void dc_comm_destroy(dc_comm* comm);
+const char* dc_comm_last_error(const dc_comm* comm);
+/* Gather `n_local` results (as filled by dc_forward_test / dc_forward_batch: same capacity and T on
+ * every rank) from every rank on rank 0.  gathered: rank 0 passes world*n_local caller-allocated
+ * results (capacity >= the senders'); entry r*n_local + i receives image i of rank r.  Other ranks
+ * pass NULL.  One record per image travels as {K, T, capacity; boxes; scores; int32 tokens}. */
+int dc_gather_results(dc_comm* comm, const dc_result* local, int n_local, dc_result* gathered);
+
 /* ---- device memory helpers (for hosts without a GPU allocator, e.g. LuaJIT) -- */
 int dc_malloc(dc_ctx* ctx, void** dev_ptr, size_t bytes);
 int dc_free(dc_ctx* ctx, void* dev_ptr);

@@ -92,6 +92,7 @@ function Model.fromCheckpoint(ref, gpu)
   keep = nil
   self.opt = {rpn_nms_thresh = 0.7, final_nms_thresh = 0.3, num_proposals = 300}
   self.vocab_size, self.seq_length, self.fc_dim = lm.vocab_size, lm.seq_length, fcs[2].weight:size(1)
+  self.num_anchors = make_anchors.anchors:size(2)
   self.idx_to_token = lm.idx_to_token
   -- keep the reference's field layout for callers that reach into it
   self.nets = {language_model = {decodeSequence = function(_, seq) return self:decodeSequence(seq) end}}
@@ -103,6 +104,14 @@ function Model:setTestArgs(kwargs)
   for k, v in pairs(kwargs or {}) do self.opt[k] = v end
   hip.check(self.ctx, C.dc_set_test_args(self.ctx, self.opt.rpn_nms_thresh, self.opt.final_nms_thresh,
                                          self.opt.num_proposals), 'dc_set_test_args')
+end
+-- rows the result buffers need: num_proposals, or every anchor of the image when it is -1 (uncapped RPN NMS,
+-- LocalizationLayer.lua:322-324): k * ceil(H/16) * ceil(W/16) after the four ceil-mode pools, at most 65536
+function Model:_capacity(H, W)
+  local P = self.opt.num_proposals
+  if P ~= -1 then return P end
+  for _ = 1, 4 do H, W = math.floor((H + 1) / 2), math.floor((W + 1) / 2) end
+  return math.min(self.num_anchors * H * W, 65536)
 end
 function Model:convert(dtype, use_cudnn) return self end
 function Model:evaluate() return self end
@@ -127,7 +136,8 @@ end
 function Model:forward_test(input)
   assert(input:dim() == 4 and input:size(1) == 1 and input:size(2) == 3)  -- DenseCapModel.lua:244
   local img = input:float():contiguous()
-  local H, W, P, T = img:size(3), img:size(4), self.opt.num_proposals, self.seq_length
+  local H, W, T = img:size(3), img:size(4), self.seq_length
+  local P = self:_capacity(H, W)
   local boxes, scores = torch.FloatTensor(P, 4), torch.FloatTensor(P, 1)
   local tokens = torch.IntTensor(P, T)
   local r = ffi.new('dc_result')
@@ -143,12 +153,58 @@ end
 
 function Model:extractFeatures(input)
   local img = input:float():contiguous()
-  local H, W, P = img:size(3), img:size(4), self.opt.num_proposals
+  local H, W = img:size(3), img:size(4)
+  local P = self:_capacity(H, W)
   local boxes, feats = torch.FloatTensor(P, 4), torch.FloatTensor(P, self.fc_dim)
   local K = ffi.new('int32_t[1]')
   hip.check(self.ctx, C.dc_extract_features(self.ctx, fptr(img), H, W, 0, P, torch.data(boxes),
                                             torch.data(feats), K), 'dc_extract_features')
   return boxes[{{1, K[0]}}]:clone(), feats[{{1, K[0]}}]:clone()
+end
+
+-- Multi-GPU (one LuaJIT process per GPU; the reference is single-device, densecap/utils.lua:22-36): every rank runs
+-- forward_raw on its shard of the image list, then ONE gather on rank 0 (RCCL point-to-point over xGMI).
+--   id = DenseCapModelHIP.commUniqueId()                       -- rank 0; pass the 128-byte string to the others
+--   model:commInit(id, rank, world)
+--   all = model:gatherResults(results)                         -- results: array of dc_result filled by forward_raw
+function Model.commUniqueId()
+  local id = ffi.new('uint8_t[128]')
+  hip.check(nil, C.dc_comm_unique_id(id), 'dc_comm_unique_id')
+  return ffi.string(id, 128)
+end
+function Model:commInit(id, rank, world)
+  local pc = ffi.new('dc_comm*[1]')
+  hip.check(self.ctx, C.dc_comm_create(pc, self.ctx, id, rank, world), 'dc_comm_create')
+  self.comm, self.rank, self.world = ffi.gc(pc[0], C.dc_comm_destroy), rank, world
+end
+-- forward_test without string decoding: returns a dc_result (and the tensors that own its buffers)
+function Model:forward_raw(input)
+  local img = input:float():contiguous()
+  local H, W, T = img:size(3), img:size(4), self.seq_length
+  local P = self:_capacity(H, W)
+  local keep = {torch.FloatTensor(P, 4), torch.FloatTensor(P), torch.IntTensor(P, T)}
+  local r = ffi.new('dc_result')
+  r.capacity, r.boxes, r.scores, r.tokens = P, torch.data(keep[1]), torch.data(keep[2]), torch.data(keep[3])
+  hip.check(self.ctx, C.dc_forward_test(self.ctx, fptr(img), H, W, 0, r), 'dc_forward_test')
+  return r, keep
+end
+function Model:gatherResults(results)   -- results: Lua array of dc_result with one capacity
+  local n = #results
+  local loc = ffi.new('dc_result[?]', n)
+  for i = 1, n do loc[i - 1] = results[i] end
+  local all, keep = nil, {}
+  if self.rank == 0 then
+    all = ffi.new('dc_result[?]', n * self.world)
+    local P, T = loc[0].capacity, self.seq_length
+    for i = 0, n * self.world - 1 do
+      local k = {torch.FloatTensor(P, 4), torch.FloatTensor(P), torch.IntTensor(P, T)}
+      keep[#keep + 1] = k
+      all[i].capacity, all[i].boxes, all[i].scores, all[i].tokens = P, torch.data(k[1]), torch.data(k[2]), torch.data(k[3])
+    end
+  end
+  local rc = C.dc_gather_results(self.comm, loc, n, all)
+  if rc < 0 then error('dc_gather_results: ' .. ffi.string(C.dc_comm_last_error(self.comm))) end
+  return all, keep
 end
 
 return Model

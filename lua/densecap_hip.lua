@@ -41,6 +41,12 @@ int dc_forward_batch(dc_ctx* ctx, const float* imgs, int n, int H, int W, int im
 int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_device,
                         int capacity, float* boxes, float* feats, int32_t* K);
 int dc_stage_times(dc_ctx* ctx, const char** names, float* ms, int max_stages);
+typedef struct dc_comm dc_comm;
+int dc_comm_unique_id(void* id_out);
+int dc_comm_create(dc_comm** out, dc_ctx* ctx, const void* id, int rank, int world);
+void dc_comm_destroy(dc_comm* comm);
+const char* dc_comm_last_error(const dc_comm* comm);
+int dc_gather_results(dc_comm* comm, const dc_result* local, int n_local, dc_result* gathered);
 ]]
 
 local M = {}

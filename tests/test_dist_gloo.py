@@ -1,6 +1,6 @@
-"""world_size-2 gloo test of the N>1 path's host logic: contiguous image sharding and the single
-end-of-run gather of padded (boxes, scores, tokens) records (bench.py uses the same functions over
-RCCL).  The per-image compute is replaced by a deterministic stand-in: no GPU here."""
+"""world_size-2 gloo tests of the N>1 path's host logic: contiguous image sharding, the single end-of-run gather
+of typed (boxes, scores, tokens) records, and bench.py's real world=2 control flow (with its --stub model: no GPU
+here; the same branch runs with the HIP model and two ranks on GPU 0 in tests/test_gpu_dist.py)."""
 import os
 import socket
 
@@ -25,9 +25,8 @@ def _worker(rank, world, port, n_images, P, T, q):
     per = (n_images + world - 1) // world
     while len(results) < per:                      # pad the last shard so gather shapes agree
         results.append((np.zeros((0, 4), np.float32), np.zeros((0,), np.float32), np.zeros((0, T), np.int32)))
-    rec, cnt = D.pack_records(results, P, T)
     dist.barrier()
-    out = D.gather_records(dist, rec, cnt, rank, world)
+    out = D.gather_records(dist, results, P, T, rank, world)      # ONE collective: typed records, K inside
     if rank == 0:
         flat = [r for shard in out for r in shard][:n_images]
         ok = True
@@ -61,3 +60,42 @@ def test_gather_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_record_pack_roundtrip_and_layout():
+    """Typed record: {int32 K,T,P,0; f32 boxes[P][4]; f32 scores[P]; int32 tokens[P][T]} -- the layout comm.hip sends."""
+    from densecap_amd import dist as D
+    P, T = 9, 4
+    res = [_fake_forward(i, P, T) for i in range(5)] + [(np.zeros((0, 4), np.float32), np.zeros(0, np.float32), np.zeros((0, T), np.int32))]
+    buf = D.pack_records(res, P, T)
+    assert buf.dtype == np.uint8 and buf.shape == (6, 16 + P * (16 + 4 + 4 * T))
+    k0 = len(res[0][0])
+    assert tuple(buf[0, :16].view(np.int32)) == (k0, T, P, 0)
+    assert buf[0, 16 + 20 * P:16 + 20 * P + 4].view(np.int32)[0] == (res[0][2][0, 0] if k0 else 0)    # tokens stay int32
+    for (b, s, t), (b2, s2, t2) in zip(res, D.unpack_records(buf)):
+        np.testing.assert_array_equal(b, b2); np.testing.assert_array_equal(s, s2); np.testing.assert_array_equal(t, t2)
+        assert t2.dtype == np.int32
+    import pytest
+    with pytest.raises(ValueError):
+        D.pack_records([(np.zeros((P + 1, 4), np.float32), np.zeros(P + 1, np.float32), np.zeros((P + 1, T), np.int32))], P, T)
+
+
+def test_bench_world2_branch_runs_under_gloo_with_stub_model():
+    """bench.py's world>1 branch end to end (torch.distributed.run, 2 ranks, gloo, --stub model): one JSON line from
+    rank 0, n_gpus = 2, the gather delivered both shards."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--stub", "--dist-backend", "gloo", "--steps", "4", "--warmup", "1",
+                        "--repeats", "3", "--proposals", "50"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["data"] == "stub"
+    assert d["config"]["total_output_boxes"] > 0 and len(d["repeats"]["images_per_s"]) == 3
+    assert abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
