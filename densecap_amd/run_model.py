@@ -6,9 +6,10 @@ Same flags, preprocessing and result JSON as the reference's `run_model.lua` (fl
     python -m densecap_amd.run_model -input_image imgs/elephant.jpg -checkpoint model.t7
     python -m densecap_amd.run_model -input_dir imgs -synthetic_weights 1      # no checkpoint offline
 
-Decode + `image.scale` are host-side third-party code in the reference (torch/image: libjpeg + its own
-bilinear); here PIL decodes and resizes (bilinear, max side = -image_size).  Pixel-exact agreement with
-torch/image is unpinned (no Torch7 here); everything after the resize is the checked path.
+File decode is third-party in the reference too (torch/image over libjpeg); PIL does it here.  `image.scale` is
+restated from torch/image's C source (`image_scale` below: separable, interpolating when enlarging, area-averaging when
+shrinking -- not PIL's resize) and checked against hand-computed values and the oracle's scalar restatement; no Torch7
+binary exists here to pin it further.
 """
 from __future__ import annotations
 
@@ -43,19 +44,84 @@ def build_parser():
     return p
 
 
+def _scale_linear_axis(src, dst_len, axis):
+    """torch/image generic/image.c `scaleLinear_rowcol` along one axis, float32 like the library:
+    longer output  -> linear interpolation at di*(src_len-1)/(dst_len-1), last sample copied;
+    shorter output -> area average: output di integrates the source over [di*s, (di+1)*s), s = src_len/dst_len, with
+                      fractional end weights, divided by the accumulated weight;
+    equal          -> copy.  Vectorised over the other axes; the order of the fp32 operations along the axis is the
+    library's (accumulate, then divide)."""
+    src = np.moveaxis(np.asarray(src, np.float32), axis, 0)
+    src_len = src.shape[0]
+    F = np.float32
+    if dst_len == src_len:
+        out = src.copy()
+    elif dst_len > src_len:
+        out = np.empty((dst_len,) + src.shape[1:], np.float32)
+        if src_len == 1:
+            out[:] = src[0]
+        else:
+            scale = F(src_len - 1) / F(dst_len - 1)
+            for di in range(dst_len - 1):
+                si_f = F(di) * scale
+                si_i = int(si_f)
+                si_f = F(si_f - F(si_i))
+                out[di] = (F(1) - si_f) * src[si_i] + si_f * src[si_i + 1]
+            out[dst_len - 1] = src[src_len - 1]
+    else:
+        out = np.empty((dst_len,) + src.shape[1:], np.float32)
+        scale = F(src_len) / F(dst_len)
+        si0_i, si0_f = 0, F(0)
+        for di in range(dst_len):
+            si1_f = F(di + 1) * scale
+            si1_i = int(si1_f)
+            si1_f = F(si1_f - F(si1_i))
+            acc = (F(1) - si0_f) * src[si0_i]
+            n = F(1) - si0_f
+            for si in range(si0_i + 1, si1_i):
+                acc = acc + src[si]
+                n = F(n + F(1))
+            if si1_i < src_len:
+                acc = acc + si1_f * src[si1_i]
+                n = F(n + si1_f)
+            out[di] = acc / n
+            si0_i, si0_f = si1_i, si1_f
+    return np.moveaxis(out, 0, axis)
+
+
+def image_scale(img_chw, size):
+    """torch/image `image.scale(src, size)` with a number (run_model.lua:68): the LONGER side becomes `size`, the
+    other keeps the aspect ratio (height = iheight*size/imax, truncated like a Lua number handed to Tensor:resize);
+    mode 'bilinear' = `scaleBilinear`: rows first (width), then columns (height), each with `scaleLinear_rowcol`.
+    img_chw: (C,H,W) float32.  torch/image is not vendored in the reference: restated from its published C source."""
+    img = np.asarray(img_chw, np.float32)
+    _, ih, iw = img.shape
+    imax = max(ih, iw)
+    oh, ow = int(ih * size / imax), int(iw * size / imax)
+    if oh < 1 or ow < 1:
+        raise ValueError("image.scale: %dx%d -> %dx%d" % (iw, ih, ow, oh))
+    tmp = _scale_linear_axis(img, ow, 2)          # compress/expand rows first
+    return _scale_linear_axis(tmp, oh, 1)         # then columns
+
+
+def preprocess_rgb01(img_rgb_chw, image_size):
+    """run_model.lua:68-74 after image.load: scale, RGB->BGR, x255, minus the VGG mean.  (3,H,W) in [0,1] -> (1,3,H',W')."""
+    img = image_scale(img_rgb_chw, image_size)
+    bgr = img[::-1] * np.float32(255.0) - VGG_MEAN_BGR[:, None, None]
+    return np.ascontiguousarray(bgr[None], dtype=np.float32), img
+
+
 def load_image_caffe(path, image_size):
-    """run_model.lua:67-74: load RGB [0,1], scale max side to image_size, BGR, x255, minus VGG mean.
-    Returns (img_caffe (1,3,H,W) float32, scaled RGB uint8 (H,W,3))."""
+    """run_model.lua:67-74: image.load(path, 3) (float RGB in [0,1] = byte/255), image.scale (max side = image_size),
+    BGR, x255, minus VGG mean.  Returns (img_caffe (1,3,H,W) float32, scaled RGB uint8 (H,W,3) for the visualiser).
+    Only the file DECODE is third-party here (PIL); the resize is image_scale above, not PIL's."""
     from PIL import Image
     im = Image.open(path).convert("RGB")
-    w, h = im.size
-    s = float(image_size) / max(w, h)
-    nw, nh = max(1, int(round(w * s))), max(1, int(round(h * s)))
-    im = im.resize((nw, nh), Image.BILINEAR)
-    rgb = np.asarray(im, dtype=np.uint8)
-    x = rgb.astype(np.float32) / 255.0
-    bgr = x[:, :, ::-1].transpose(2, 0, 1) * 255.0 - VGG_MEAN_BGR[:, None, None]
-    return np.ascontiguousarray(bgr[None], dtype=np.float32), rgb
+    x = np.asarray(im, dtype=np.uint8).astype(np.float32).transpose(2, 0, 1) / np.float32(255.0)
+    img_caffe, scaled = preprocess_rgb01(x, image_size)
+    # image.save clamps to [0,1] and writes bytes (x255, truncated)
+    rgb = (np.clip(scaled, 0, 1) * 255.0).astype(np.uint8).transpose(1, 2, 0)
+    return img_caffe, np.ascontiguousarray(rgb)
 
 
 def xcycwh_to_xywh(boxes):

@@ -4,9 +4,12 @@ SURVEY.md 8(f) row 1: `run_model.lua:146-147` does `torch.load(checkpoint).model
 whole `nn.DenseCapModel` object graph written by `train.lua:174-185` (float tensors).  This module reads
 that format without Torch7 and extracts the tensors `dc_load_weights` needs.
 
-Status: written from the published Torch7 `File.lua` format; no real checkpoint is available offline, so
-it is exercised only against files produced by the writer below (tests/test_t7.py) -- "parity unpinned"
-until a real `.t7` is at hand.  The writer exists for those tests and for exporting synthetic checkpoints.
+Status: written from the published Torch7 `File.lua` format; no real checkpoint is available offline.  It is
+exercised against (a) `tests/golden/handmade_checkpoint.t7`, a miniature checkpoint assembled byte by byte from the
+format by an independent script (closures in all three encodings, back-references, an nn.gModule with graph.Node
+objects, a legacy SpatialConvolutionMM 2-D weight, strided/offset tensor views, shared storages, unversioned class
+names) and (b) round trips through the writer below (which exists for those tests and for exporting synthetic
+checkpoints) -- still "parity unpinned" against a real `.t7` until one is at hand.
 """
 from __future__ import annotations
 
@@ -40,6 +43,17 @@ class TorchObject:
 
     def __repr__(self):
         return "TorchObject(%s)" % self.torch_type
+
+
+class LuaFunction:
+    """Placeholder for a serialized Lua closure (its bytecode is not kept)."""
+
+    def __init__(self, size):
+        self.bytecode_size = size
+        self.upvalues = None
+
+    def __repr__(self):
+        return "LuaFunction(%d bytes)" % self.bytecode_size
 
 
 def _lua_list(t):
@@ -139,7 +153,19 @@ class T7Reader:
             obj.fields = self.read_object()     # default torch class read(): one table of fields
             return obj
         if t in (TYPE_FUNCTION, TYPE_RECUR_FUNCTION, TYPE_LEGACY_RECUR_FUNCTION):
-            raise ValueError("t7: serialized Lua functions are not supported")
+            # File.lua: [index][int size][string.dump bytecode][upvalue table].  Closures carry no weights: the bytecode
+            # is skipped; the upvalue table is still parsed so that object indices stay in step for later back-references.
+            idx = self.read_int()
+            if idx in self.memo:
+                return self.memo[idx]
+            size = self.read_int()
+            code = self.f.read(size)
+            if len(code) != size:
+                raise EOFError("truncated t7 file (function body)")
+            fn = LuaFunction(size)
+            self.memo[idx] = fn
+            fn.upvalues = self.read_object()
+            return fn
         raise ValueError("t7: unknown type tag %d" % t)
 
 
@@ -242,6 +268,26 @@ def _modules(seq):
     if mods is None:
         raise ValueError("expected an nn container with a `modules` array")
     return mods
+
+
+def iter_modules(obj, _seen=None):
+    """Depth-first walk over every torch object reachable from `obj`: container `modules` arrays, modules held in
+    named fields (nn.LanguageModel's image_encoder / rnn / lookup_table) and nn.gModule graphs (`forwardnodes` of
+    graph.Node objects whose data.module is the wrapped module, DenseCapModel.lua:127-162).  Shared objects are
+    yielded once; tensors and closures are leaves."""
+    seen = _seen if _seen is not None else set()
+    if isinstance(obj, TorchObject):
+        if id(obj) in seen:
+            return
+        seen.add(id(obj))
+        yield obj
+        yield from iter_modules(obj.fields, seen)
+    elif isinstance(obj, dict):
+        if id(obj) in seen:
+            return
+        seen.add(id(obj))
+        for k in sorted(obj, key=lambda k: (not isinstance(k, (int, float)), str(type(k)), k if isinstance(k, (int, float)) else str(k))):
+            yield from iter_modules(obj[k], seen)
 
 
 def _is(obj, *names):

@@ -463,6 +463,68 @@ def decode_sequence(seq, idx_to_token, vocab_size):
     return caps
 
 
+# ----------------------------------------------------------------------------
+# run_image preprocessing (run_model.lua:67-74); image.scale lives in torch/image (un-vendored)
+# ----------------------------------------------------------------------------
+def _scale_linear_rowcol(src, dst_len):
+    """torch/image generic/image.c scaleLinear_rowcol on one 1-D float32 sequence, scalar loops (small cases only)."""
+    src = [F32(v) for v in src]
+    n_src = len(src)
+    if dst_len == n_src:
+        return list(src)
+    dst = [F32(0)] * dst_len
+    if dst_len > n_src:
+        if n_src == 1:
+            return [src[0]] * dst_len
+        scale = F32(n_src - 1) / F32(dst_len - 1)
+        for di in range(dst_len - 1):
+            si_f = F32(di) * scale
+            si_i = int(si_f)
+            si_f = F32(si_f - F32(si_i))
+            dst[di] = F32(F32(F32(1) - si_f) * src[si_i] + si_f * src[si_i + 1])
+        dst[dst_len - 1] = src[n_src - 1]
+        return dst
+    scale = F32(n_src) / F32(dst_len)
+    si0_i, si0_f = 0, F32(0)
+    for di in range(dst_len):
+        si1_f = F32(di + 1) * scale
+        si1_i = int(si1_f)
+        si1_f = F32(si1_f - F32(si1_i))
+        acc = F32(F32(F32(1) - si0_f) * src[si0_i])
+        n = F32(F32(1) - si0_f)
+        for si in range(si0_i + 1, si1_i):
+            acc = F32(acc + src[si]); n = F32(n + F32(1))
+        if si1_i < n_src:
+            acc = F32(acc + si1_f * src[si1_i]); n = F32(n + si1_f)
+        dst[di] = F32(acc / n)
+        si0_i, si0_f = si1_i, si1_f
+    return dst
+
+
+def image_scale(img_chw, size):
+    """image.scale(img, size) (run_model.lua:68): longer side -> size, bilinear = rows then columns."""
+    img = np.asarray(img_chw, F32)
+    C, ih, iw = img.shape
+    imax = max(ih, iw)
+    oh, ow = int(ih * size / imax), int(iw * size / imax)
+    tmp = np.empty((C, ih, ow), F32)
+    for c in range(C):
+        for y in range(ih):
+            tmp[c, y] = _scale_linear_rowcol(img[c, y], ow)
+    out = np.empty((C, oh, ow), F32)
+    for c in range(C):
+        for x in range(ow):
+            out[c, :, x] = _scale_linear_rowcol(tmp[c, :, x], oh)
+    return out
+
+
+def preprocess(img_rgb01_chw, image_size):
+    """run_model.lua:68-74: scale, index {3,2,1} (BGR), mul 255, add -vgg_mean."""
+    img = image_scale(img_rgb01_chw, image_size)
+    mean = np.array([103.939, 116.779, 123.68], F32)
+    return (img[::-1] * F32(255) - mean[:, None, None])[None].astype(F32)
+
+
 def forward_test(img, Wt, rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=1000,
                  T=15, stages=None):
     """DenseCapModel:forward_test numerics (DenseCapModel.lua:242-275,319-327 via

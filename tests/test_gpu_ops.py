@@ -210,10 +210,15 @@ def test_box_iou_conventions_exact(ctx, conv):
     rng = np.random.default_rng(code)
     b1 = np.concatenate([rng.uniform(0, 300, (70, 2)), rng.uniform(1, 120, (70, 2))], 1).astype(np.float32)
     b2 = np.concatenate([rng.uniform(0, 300, (133, 2)), rng.uniform(1, 120, (133, 2))], 1).astype(np.float32)
-    b2[:20] = b1[:20]                                            # identical boxes: IoU exactly 1 in every convention
+    b2[:20] = b1[:20]                                            # identical boxes
     got = ops.box_iou(ctx, b1, b2, code)
     np.testing.assert_array_equal(got, O.box_iou(b1, b2, name))
-    assert (np.diag(got[:20, :20]) == 1).all() and got.min() >= 0 and got.max() <= 1
+    assert got.min() >= 0 and got.max() <= 1
+    if name != "boxiou_module":
+        assert (np.diag(got[:20, :20]) == 1).all()
+    else:
+        # the live module mixes (w-1) extents in the intersection with w*h areas: IoU(b, b) = (w-1)(h-1) / (2wh - (w-1)(h-1)) < 1
+        assert (np.diag(got[:20, :20]) < 1).all()
     if name == "nms_plus1":
         # a pair is suppressed by box_utils.nms at threshold t  <=>  its +1 IoU > t
         i, j = np.unravel_index(np.argmax(np.where(got < 0.999, got, 0)), got.shape)

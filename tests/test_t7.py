@@ -42,6 +42,45 @@ def test_checkpoint_walk_roundtrip(tmp_path):
     assert back["vocab_size"] == 30 and back["seq_length"] == 4 and back["idx_to_token"][30] == "tok30"
 
 
+def test_reads_hand_assembled_checkpoint_bytes():
+    """tests/golden/handmade_checkpoint.t7 was assembled byte by byte from the Torch7 format by
+    tests/golden/make_t7_fixture.py (not by T7Writer): closures in the three encodings are skipped, back-references,
+    the nn.gModule with graph.Node objects, the legacy 2-D SpatialConvolutionMM weight, the strided/offset view and the
+    shared storage are all resolved, and every tensor comes back bit for bit."""
+    from densecap_amd import t7
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ck = t7.load(os.path.join(here, "handmade_checkpoint.t7"))
+    exp = np.load(os.path.join(here, "handmade_checkpoint_expected.npz"))
+    assert ck["iter"] == 20000 and ck["loss_history"] == {1: 2.5, 2: 2.25}
+    model = ck["model"]
+    assert model.torch_type == "nn.DenseCapModel"
+    loc = model["nets"]["localization_layer"]
+    for k in ("timer_hook", "legacy_hook", "old_hook"):
+        assert isinstance(loc[k], t7.LuaFunction), k                    # skipped, not fatal
+    assert loc["timer_hook"].upvalues == {1: {"name": "_ENV"}} and loc["image_height"] is None
+    # the gModule's nodes hold the SAME objects as nets.* (back-references, not copies)
+    g = model["nets"]["recog_net"]
+    mods = {m.torch_type for m in t7.iter_modules(g)}
+    assert {"nn.gModule", "nn.Sequential", "nn.Linear", "nn.LanguageModel", "nn.LSTM"} <= mods
+    nodes = t7._lua_list(g["forwardnodes"])
+    assert nodes[0]["data"]["module"] is model["nets"]["recog_base"]
+    assert nodes[2]["data"]["module"] is model["nets"]["language_model"]
+    W = t7.weights_from_checkpoint(ck)
+    for li in range(13):
+        np.testing.assert_array_equal(W["conv_w"][li], exp["conv%d_w" % li])       # incl. the 2-D legacy one and the view
+        np.testing.assert_array_equal(W["conv_b"][li], exp["conv%d_b" % li])
+    assert W["conv_w"][2].shape == (3, 2, 3, 3)
+    for k in ("rpn_conv", "rpn_box", "rpn_score", "fc6", "fc7", "obj", "boxreg", "lm_enc", "lm_out"):
+        np.testing.assert_array_equal(W[k + "_w"], exp[k + "_w"].reshape(W[k + "_w"].shape))
+        np.testing.assert_array_equal(W[k + "_b"], exp[k + "_b"])
+    np.testing.assert_array_equal(W["lm_emb"], exp["lm_emb"])                      # two tensors on one storage
+    np.testing.assert_array_equal(W["lstm_b"], exp["lstm_b"])
+    np.testing.assert_array_equal(W["lstm_w"], exp["lstm_w"])
+    np.testing.assert_array_equal(W["anchors"], exp["anchors"])
+    assert W["field_centers"] == (8.5, 8.5, 16.0, 16.0) and W["vocab_size"] == 5 and W["seq_length"] == 3
+    assert W["idx_to_token"] == {i: "tok%d" % i for i in range(1, 6)}
+
+
 def test_run_model_preprocessing_and_json(tmp_path):
     from PIL import Image
     from densecap_amd import run_model as R
@@ -62,6 +101,35 @@ def test_run_model_preprocessing_and_json(tmp_path):
     assert j == {"boxes": [[8.0, 17.0, 5.0, 7.0]], "scores": [0.5], "captions": ["a cat"]}
     opt = R.build_parser().parse_args(["-input_image", "x.jpg", "-num_proposals", "300"])
     assert opt.rpn_nms_thresh == 0.7 and opt.final_nms_thresh == 0.3 and opt.num_proposals == 300
+
+
+def test_image_scale_hand_computed_and_oracle():
+    """image.scale (run_model.lua:68; torch/image scaleBilinear = scaleLinear_rowcol over rows, then columns):
+    hand-computed 1-D cases, the size rule, and host == the oracle's scalar restatement bit for bit."""
+    from densecap_amd import run_model as R
+    from oracle import densecap_oracle as O
+    f = lambda v, n: R._scale_linear_axis(np.array(v, np.float32), n, 0).tolist()
+    assert f([1, 3, 5, 7], 2) == [2.0, 6.0]                    # shrink by 2: plain pair averages
+    assert f([3, 6, 9], 2) == [4.0, 8.0]                       # shrink by 1.5: (s0 + .5 s1)/1.5, (.5 s1 + s2)/1.5
+    assert f([2, 4], 3) == [2.0, 3.0, 4.0]                     # enlarge: samples at 0, .5, 1 (last copied)
+    assert f([5], 4) == [5.0, 5.0, 5.0, 5.0]
+    assert f([1, 2, 3], 3) == [1.0, 2.0, 3.0]
+    np.testing.assert_allclose(f([0, 10, 20, 30], 7), [0, 5, 10, 15, 20, 25, 30], atol=1e-5)
+    # 2-D: rows first then columns; a 2x4 image shrunk to max side 2 -> 1x2
+    img = np.array([[[1, 3, 5, 7], [3, 5, 7, 9]]], np.float32)
+    np.testing.assert_array_equal(R.image_scale(img, 2), [[[3.0, 7.0]]])
+    # size rule: the LONGER side becomes `size`, the other is truncated (600x800 -> 540x720; 480x720 stays)
+    assert R.image_scale(np.zeros((3, 600, 800), np.float32), 720).shape == (3, 540, 720)
+    assert R.image_scale(np.zeros((3, 480, 720), np.float32), 720).shape == (3, 480, 720)
+    assert R.image_scale(np.zeros((3, 333, 500), np.float32), 720).shape == (3, 479, 720)     # 333*720/500 = 479.52
+    rng = np.random.default_rng(0)
+    for (h, w, size) in [(7, 13, 5), (9, 5, 20), (40, 30, 17), (3, 50, 64)]:
+        x = rng.random((3, h, w)).astype(np.float32)
+        np.testing.assert_array_equal(R.image_scale(x, size), O.image_scale(x, size))
+        np.testing.assert_array_equal(R.preprocess_rgb01(x, size)[0], O.preprocess(x, size))
+    # shrinking is an area average, not point sampling: a 1-px checkerboard collapses to its mean
+    cb = (np.indices((8, 8)).sum(0) % 2).astype(np.float32)[None]
+    np.testing.assert_allclose(R.image_scale(cb, 4), np.full((1, 4, 4), 0.5), atol=1e-6)
 
 
 def test_daemon_protocol_with_fake_model(tmp_path):
