@@ -101,6 +101,19 @@ hipError_t launch_recog_heads(const float* codes, const float* w5 /*(5,D): obj, 
                               const float* roi_boxes, float* obj, float* trans, float* final_boxes, int n, int D,
                               hipStream_t s);
 
+// ---- beam search row kernels (beam.hip; LanguageModel.lua:170-290) --------------------------
+hipError_t launch_beam_logsoftmax_topk(const float* logits, int rows, int V1, int ld, const uint8_t* finished, int k,
+                                       float* top_lp, int32_t* top_idx, hipStream_t s);
+hipError_t launch_beam_init(const float* top_lp, const int32_t* top_idx, int nprop, int beam, int T, int END,
+                            float* beam_lp, int32_t* beams, int32_t* parent, int32_t* cur_tok, uint8_t* finished,
+                            hipStream_t s);
+hipError_t launch_beam_merge(const float* top_lp, const int32_t* top_idx, const float* beam_lp_in,
+                             const int32_t* beams_in, int nprop, int beam, int T, int t, int END, float* beam_lp_out,
+                             int32_t* beams_out, int32_t* parent, int32_t* cur_tok, uint8_t* finished, hipStream_t s);
+hipError_t launch_beam_gather_state(const float* h_in, const float* c_in, const int32_t* parent, int rows, int beam,
+                                    int src_per_prop, int Hd, float* h_out, float* c_out, hipStream_t s);
+hipError_t launch_beam_best(const int32_t* beams, int nprop, int beam, int T, int32_t* seq, hipStream_t s);
+
 // ---- box pipeline (boxes.hip) ------------------------------------------------------
 hipError_t launch_make_anchors(float* out, int h, int w, float x0, float y0, float sx, float sy,
                                const float* anchors, int k, hipStream_t s);

@@ -62,6 +62,13 @@ struct Lane {
   int pending_capacity = 0;
   float stage_ms[ST_COUNT] = {};
   bool have_times = false;
+  // beam search scratch (allocated on first use; kBeamChunk proposals x beam rows at a time)
+  void* beam_base = nullptr;
+  int beam_rows = 0;
+  float *bm_enc = nullptr, *bm_gates = nullptr, *bm_h[2] = {nullptr, nullptr}, *bm_c[2] = {nullptr, nullptr};
+  float *bm_logits = nullptr, *bm_top_lp = nullptr, *bm_lp[2] = {nullptr, nullptr};
+  int32_t *bm_top_idx = nullptr, *bm_beams[2] = {nullptr, nullptr}, *bm_parent = nullptr, *bm_tok = nullptr;
+  uint8_t* bm_fin = nullptr;
   hipStream_t aux = nullptr;            // single-image mode: second half of the decode rows runs here
   hipStream_t aux2 = nullptr;           // single-image mode: the final NMS runs here, beside the decode
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
@@ -78,6 +85,7 @@ struct dc_ctx {
   float rpn_nms_thresh = 0.7f, final_nms_thresh = 0.3f;
   int max_lanes = 3;
   bool captions_after_final_nms = false;
+  int beam_size = 0;         // 0 = greedy LM:sample; > 0 = LM:beamsearch (LanguageModel.lua:129-131)
   bool serial_mode = false;  // lanes == 1: idle CUs in a layer's last round are worth a tail split-K (dc_set_lanes)
   int num_proposals = 300;  // LocalizationLayer default (LocalizationLayer.lua:237); run_model sets 1000
   // dims
@@ -404,6 +412,78 @@ int lm_sample(dc_ctx* ctx, Lane& L, const float* codes, int n, const int32_t* n_
   return lm_sample_parts(ctx, L, codes, &whole, 1, n_dev, seq_out);
 }
 
+// LanguageModel:beamsearch (LanguageModel.lua:170-290), dispatched by LM:updateOutput when self.beam_size is set
+// (:129-131; no reference script sets it).  The reference walks the proposals one by one with the beams in the
+// minibatch dimension; here kBeamChunk proposals advance together (rows = proposals x beams), row for row the same
+// arithmetic: LSTM step (MFMA GEMM + point-wise), vocabulary projection (full logits this time), LogSoftMax + top-k per
+// beam, beam x beam merge, states re-indexed by parent.  Ties: lower index first (docs/SEMANTICS.md).
+constexpr int kBeamChunk = 64;
+int beam_prepare(dc_ctx* ctx, Lane& L) {
+  const int beam = ctx->beam_size, rows = kBeamChunk * beam;
+  if (L.beam_base && L.beam_rows >= rows) return DC_OK;
+  if (L.beam_base) { HIPCHK(hipStreamSynchronize(L.stream)); HIPCHK(hipFree(L.beam_base)); L.beam_base = nullptr; }
+  const int E = ctx->E, Hd = ctx->Hd, V1 = ctx->V + 1, T = ctx->T;
+  struct Carve { void** p; size_t bytes; };
+  std::vector<Carve> cv = {
+      {(void**)&L.bm_enc, (size_t)kBeamChunk * E * 4}, {(void**)&L.bm_gates, (size_t)rows * 4 * Hd * 4},
+      {(void**)&L.bm_h[0], (size_t)rows * Hd * 4},     {(void**)&L.bm_h[1], (size_t)rows * Hd * 4},
+      {(void**)&L.bm_c[0], (size_t)rows * Hd * 4},     {(void**)&L.bm_c[1], (size_t)rows * Hd * 4},
+      {(void**)&L.bm_logits, (size_t)rows * V1 * 4},   {(void**)&L.bm_top_lp, (size_t)rows * beam * 4},
+      {(void**)&L.bm_top_idx, (size_t)rows * beam * 4}, {(void**)&L.bm_lp[0], (size_t)rows * 4},
+      {(void**)&L.bm_lp[1], (size_t)rows * 4},         {(void**)&L.bm_beams[0], (size_t)rows * T * 4},
+      {(void**)&L.bm_beams[1], (size_t)rows * T * 4},  {(void**)&L.bm_parent, (size_t)rows * 4},
+      {(void**)&L.bm_tok, (size_t)rows * 4},           {(void**)&L.bm_fin, (size_t)rows},
+  };
+  size_t total = 0;
+  for (auto& c : cv) total += al(c.bytes);
+  HIPCHK(hipMalloc(&L.beam_base, total));
+  char* p = static_cast<char*>(L.beam_base);
+  for (auto& c : cv) { *c.p = p; p += al(c.bytes); }
+  L.beam_rows = rows;
+  return DC_OK;
+}
+
+int lm_beamsearch(dc_ctx* ctx, Lane& L, const float* codes, int n, int32_t* seq_out, hipStream_t s) {
+  DCCHK(beam_prepare(ctx, L));
+  const int beam = ctx->beam_size, E = ctx->E, Hd = ctx->Hd, V1 = ctx->V + 1, T = ctx->T, D = ctx->D;
+  auto step = [&](float* h, float* c, int rows) -> int {        // one LSTM step on the words in bm_tok, in place
+    GemmDesc d;
+    d.A = h; d.W = ctx->whT; d.C = L.bm_gates; d.M = rows; d.N = 4 * Hd; d.K = Hd; d.ldc = 4 * Hd;
+    d.rowterm = ctx->xg; d.rowidx = L.bm_tok; d.rowterm_ld = 4 * Hd;
+    DCCHK(run_gemm(ctx, d, s));
+    KCHK(launch_lstm_pointwise(L.bm_gates, c, h, rows, nullptr, Hd, 0, s));
+    return DC_OK;
+  };
+  for (int p0 = 0; p0 < n; p0 += kBeamChunk) {
+    const int c = std::min(kBeamChunk, n - p0);
+    // image step (:198-201) and START step (:203-206), one state row per proposal
+    DCCHK(linear(ctx, s, codes + (size_t)p0 * D, ctx->enc_w, ctx->enc_b, L.bm_enc, c, E, D, 1));
+    DCCHK(linear(ctx, s, L.bm_enc, ctx->wxT, ctx->lstm_b, L.bm_gates, c, 4 * Hd, E, 0));
+    KCHK(launch_lstm_pointwise(L.bm_gates, L.bm_c[0], L.bm_h[0], c, nullptr, Hd, 1, s));
+    KCHK(launch_fill_i32(L.bm_tok, V1, c, s));
+    DCCHK(step(L.bm_h[0], L.bm_c[0], c));
+    DCCHK(linear(ctx, s, L.bm_h[0], ctx->out_w, ctx->out_b, L.bm_logits, c, V1, Hd, 0));
+    KCHK(launch_beam_logsoftmax_topk(L.bm_logits, c, V1, V1, nullptr, beam, L.bm_top_lp, L.bm_top_idx, s));
+    KCHK(launch_beam_init(L.bm_top_lp, L.bm_top_idx, c, beam, T, V1, L.bm_lp[0], L.bm_beams[0], L.bm_parent, L.bm_tok,
+                          L.bm_fin, s));
+    KCHK(launch_beam_gather_state(L.bm_h[0], L.bm_c[0], L.bm_parent, c * beam, beam, 1, Hd, L.bm_h[1], L.bm_c[1], s));
+    int cur = 1, bcur = 0;
+    const int rows = c * beam;
+    for (int t = 1; t < T; ++t) {
+      DCCHK(step(L.bm_h[cur], L.bm_c[cur], rows));
+      DCCHK(linear(ctx, s, L.bm_h[cur], ctx->out_w, ctx->out_b, L.bm_logits, rows, V1, Hd, 0));
+      KCHK(launch_beam_logsoftmax_topk(L.bm_logits, rows, V1, V1, L.bm_fin, beam, L.bm_top_lp, L.bm_top_idx, s));
+      KCHK(launch_beam_merge(L.bm_top_lp, L.bm_top_idx, L.bm_lp[bcur], L.bm_beams[bcur], c, beam, T, t, V1,
+                             L.bm_lp[bcur ^ 1], L.bm_beams[bcur ^ 1], L.bm_parent, L.bm_tok, L.bm_fin, s));
+      KCHK(launch_beam_gather_state(L.bm_h[cur], L.bm_c[cur], L.bm_parent, rows, beam, beam, Hd, L.bm_h[cur ^ 1],
+                                    L.bm_c[cur ^ 1], s));
+      cur ^= 1; bcur ^= 1;
+    }
+    KCHK(launch_beam_best(L.bm_beams[bcur], c, beam, T, seq_out + (size_t)p0 * T, s));
+  }
+  return DC_OK;
+}
+
 // Single-image mode (lanes == 1): nothing else is in flight, so the small kernels and partial tile rounds of the 15
 // decode steps leave the chip idle (~25 % of the decode).  The rows are cut into two blocks on two streams; their
 // kernels fill each other's gaps.  Same outputs bit for bit (tests/test_gpu_e2e.py::test_single_lane_mode_parity).
@@ -471,7 +551,8 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int img_on_device, b
   // single-image mode, reference order: decode (two row blocks on two streams) and final NMS (a third stream) are
   // independent consumers of the heads' outputs.  Per-launch HIP-event profiling wants kernels that do not overlap:
   // everything stays on one stream while it is on.
-  const bool side_streams = ctx->serial_mode && !ctx->prof && !no_split && !features_only && !survivors_only && P >= 256;
+  const bool side_streams = ctx->serial_mode && !ctx->prof && !no_split && !features_only && !survivors_only && P >= 256 &&
+                            ctx->beam_size == 0;
   hipStream_t sn = side_streams ? L.aux2 : s;       // stream of the final NMS
   if (side_streams) {
     HIPCHK(hipEventRecord(L.ev_fork2, s));
@@ -479,7 +560,8 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int img_on_device, b
   }
   // ---- language model (reference order: all P proposals, DenseCapModel.lua:127-162) -----------------
   if (!features_only && !survivors_only) {
-    if (side_streams) DCCHK(lm_sample_two_streams(ctx, L, L.codes, P, L.seq));
+    if (ctx->beam_size > 0) DCCHK(lm_beamsearch(ctx, L, L.codes, P, L.seq, s));
+    else if (side_streams) DCCHK(lm_sample_two_streams(ctx, L, L.codes, P, L.seq));
     else DCCHK(lm_sample(ctx, L, L.codes, P, nullptr, L.seq));
   }
   HIPCHK(hipEventRecord(L.ev[7], s));
@@ -505,7 +587,8 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int img_on_device, b
   } else if (survivors_only) {
     // identical outputs, less work: LSTM rows are independent, so decode only the rows the final NMS kept
     KCHK(launch_gather_rows(L.codes, L.picks2, L.count2, P, ctx->D, L.out_feats, s));
-    DCCHK(lm_sample(ctx, L, L.out_feats, P, L.count2, L.out_tokens));
+    if (ctx->beam_size > 0) DCCHK(lm_beamsearch(ctx, L, L.out_feats, P, L.out_tokens, s));   // rows past K: zero codes, ignored
+    else DCCHK(lm_sample(ctx, L, L.out_feats, P, L.count2, L.out_tokens));
   } else {
     KCHK(launch_gather_rows_i32(L.seq, L.picks2, L.count2, P, ctx->T, L.out_tokens, s));
   }
@@ -611,6 +694,7 @@ void dc_destroy(dc_ctx* ctx) {
   for (auto& lp : ctx->lanes) {
     Lane& L = *lp;
     if (L.arena.p) hipFree(L.arena.p);
+    if (L.beam_base) hipFree(L.beam_base);
     if (L.host_stage) hipHostFree(L.host_stage);
     for (auto& ev : L.ev) if (ev) hipEventDestroy(ev);
     if (L.ev_fork) hipEventDestroy(L.ev_fork);
@@ -645,6 +729,15 @@ int dc_set_lanes(dc_ctx* ctx, int lanes) {
   // numerics depend only on this setting, never on how many images a call happens to carry: with one lane the
   // last partial round of a layer is K-split (different fp32 summation order for those rows)
   ctx->serial_mode = lanes == 1;
+  return DC_OK;
+}
+
+int dc_set_beam_size(dc_ctx* ctx, int beam_size) {
+  if (!ctx) return DC_E_INVALID;
+  if (beam_size < 0 || beam_size > 32) return ctx->fail(DC_E_UNSUPPORTED, "dc_set_beam_size: beam_size must be in [0,32] (got %d)", beam_size);
+  if (beam_size > 0 && ctx->have_weights && ((size_t)(ctx->V + 1) * 4 > 150 * 1024 || beam_size > ctx->V + 1))
+    return ctx->fail(DC_E_UNSUPPORTED, "dc_set_beam_size: vocabulary of %d words does not fit the top-k kernel's LDS row", ctx->V);
+  ctx->beam_size = beam_size;
   return DC_OK;
 }
 
@@ -1068,7 +1161,7 @@ int dc_op_lm_sample(dc_ctx* ctx, const float* codes, int n, int32_t* tokens) {
   L.cstate = (float*)p; p += al((size_t)n * Hd * 4);
   L.logits = (float*)p; p += al((size_t)n * V1 * 4);
   L.tok = (int32_t*)p;
-  int rc = lm_sample(ctx, L, codes, n, nullptr, tokens);
+  int rc = ctx->beam_size > 0 ? lm_beamsearch(ctx, L, codes, n, tokens, s) : lm_sample(ctx, L, codes, n, nullptr, tokens);
   hipError_t e2 = hipStreamSynchronize(s);
   L.enc = sv.enc; L.gates = sv.gates; L.hstate = sv.h; L.cstate = sv.c; L.logits = sv.logits; L.tok = sv.tok;
   hipFree(base);

@@ -6,9 +6,9 @@ after the final NMS, no LSTM decode), boxes converted to xywh, the first `-boxes
 
     python -m densecap_amd.extract_features -input_txt paths.txt -output_h5 feats.h5 -checkpoint model.t7
 
-Output: datasets `/feats` (N, M, 4096) and `/boxes` (N, M, 4), fp32.  The reference writes them with
-torch-hdf5; this image has no HDF5 library, so when `h5py` cannot be imported the same two arrays go to
-`<output_h5>.npz` (keys `feats`, `boxes`) and a note is printed.
+Output: an HDF5 file with datasets `/feats` (N, M, 4096) and `/boxes` (N, M, 4), fp32, as the reference writes
+with torch-hdf5 (extract_features.lua:92-96); written by densecap_amd/hdf5_min.py (this image has no h5py) in the
+classic contiguous layout, readable by libhdf5 / h5py.
 """
 from __future__ import annotations
 
@@ -40,17 +40,10 @@ def build_parser():
 
 
 def write_datasets(path, feats, boxes):
-    try:
-        import h5py
-    except ImportError:
-        out = path + ".npz"
-        np.savez(out, feats=feats, boxes=boxes)
-        print("h5py is not installed: wrote datasets feats%s, boxes%s to %s" % (feats.shape, boxes.shape, out))
-        return out
-    with h5py.File(path, "w") as f:
-        f.create_dataset("feats", data=feats)
-        f.create_dataset("boxes", data=boxes)
-    return path
+    """extract_features.lua:92-96: `/feats` and `/boxes` in one HDF5 file (contiguous fp32 datasets)."""
+    from .hdf5_min import write_hdf5
+    return write_hdf5(path, {"feats": np.ascontiguousarray(feats, np.float32),
+                             "boxes": np.ascontiguousarray(boxes, np.float32)})
 
 
 def main(argv=None):

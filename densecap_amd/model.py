@@ -130,6 +130,11 @@ class DenseCapModel:
         check(self.ctx.h, self.lib.dc_set_caption_order(self.ctx.h, int(bool(after_final_nms))), "dc_set_caption_order")
         return self
 
+    def setBeamSize(self, beam_size):
+        """language_model.beam_size (LanguageModel.lua:129-131): None/0 = greedy sample, n = beam search with n beams."""
+        check(self.ctx.h, self.lib.dc_set_beam_size(self.ctx.h, int(beam_size or 0)), "dc_set_beam_size")
+        return self
+
     def convert(self, dtype=None, use_cudnn=None):
         """model:convert(dtype, use_cudnn): the HIP path is always fp32 on the ctx's device."""
         return self

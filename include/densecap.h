@@ -133,6 +133,10 @@ int dc_set_lanes(dc_ctx* ctx, int lanes);
  * first and decode only the K surviving rows: LSTM rows are independent, so boxes, scores and tokens
  * are bit-identical, with ~K/num_proposals of the decode work. */
 int dc_set_caption_order(dc_ctx* ctx, int after_final_nms);
+/* LanguageModel.beam_size (LanguageModel.lua:129-131): 0 (default) = greedy LM:sample; 1..32 = LM:beamsearch
+ * (LanguageModel.lua:170-290) with that many beams.  Ties in torch.topk (unspecified in the reference; they occur for
+ * finished beams, whose next-word log-probabilities are zeroed) resolve to the lower index. */
+int dc_set_beam_size(dc_ctx* ctx, int beam_size);
 /* DenseCapModel:extractFeatures (DenseCapModel.lua:285-304): boxes (K,4) and fc7
  * codes (K,fc_dim) after the final NMS; the LSTM decode is skipped. Host outputs. */
 int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_device,
@@ -238,7 +242,7 @@ int dc_op_nms(dc_ctx* ctx, const float* boxes, const float* scores, const uint8_
 int dc_op_bilinear_roi_pool(dc_ctx* ctx, const float* feat_hwc, int h, int w, int C, const float* boxes,
                             int B, int img_h, int img_w, int HH, int WW, float* out, int out_layout);
 /* LanguageModel:sample, greedy (LanguageModel.lua:293-348) with the ctx's loaded language
- * model: codes (n,fc_dim) -> tokens (n,T) int32 1-based. */
+ * model: codes (n,fc_dim) -> tokens (n,T) int32 1-based.  With dc_set_beam_size > 0: LanguageModel:beamsearch. */
 int dc_op_lm_sample(dc_ctx* ctx, const float* codes, int n, int32_t* tokens);
 
 #ifdef __cplusplus

@@ -448,6 +448,80 @@ def lm_sample(codes, Wt, T, return_logits=False):
     return seq.numpy()
 
 
+def _log_softmax_thnn(x):
+    """nn.LogSoftMax on a FloatTensor row (THNN generic/LogSoftMax.c, CPU): exp and the running sum in double
+    (accreal), logsum = max + log(sum), output = float(x - logsum)."""
+    x = np.asarray(x, F32)
+    mx = x.max(axis=-1, keepdims=True)
+    logsum = mx.astype(np.float64) + np.log(np.exp((x - mx).astype(np.float64)).sum(axis=-1, keepdims=True))
+    return (x.astype(np.float64) - logsum).astype(F32)
+
+
+def _topk_sorted(v, k):
+    """torch.topk(v, k, dim, true) over the last axis, sorted descending; ties (unspecified in the reference): lower index first."""
+    order = np.argsort(-np.asarray(v, np.float64), axis=-1, kind="stable")[..., :k]
+    return np.take_along_axis(v, order, -1), order
+
+
+def _topk_margin(v, k):
+    """Smallest gap between neighbours among the k+1 largest DISTINCT-position values of each row (how close the
+    selection or its order is to changing); exact ties (gap 0, resolved by index on both sides) do not count."""
+    sv = -np.sort(-np.asarray(v, np.float64), axis=-1)[..., :k + 1]
+    gaps = np.abs(np.diff(sv, axis=-1))
+    gaps = np.where(gaps == 0, np.inf, gaps)
+    return float(gaps.min()) if gaps.size else np.inf
+
+
+def lm_beamsearch(codes, Wt, T, beam_size, return_margins=False):
+    """LM:beamsearch (LanguageModel.lua:170-290), one proposal at a time with the beams as the minibatch, exactly as
+    written -- including the zeroed next-word log-probabilities of finished beams (:243-247), beams initialised with
+    fill(1) (:209), and seq[i] = beams[argmax beam_logprobs] (:281-282).  Returns int64 (N,T), 1-based ids."""
+    import torch
+    N = codes.shape[0]
+    Hd = Wt["lstm_w"].shape[1] // 4
+    D = Wt["lstm_w"].shape[0] - Hd
+    Wx = Wt["lstm_w"][:D]; Wh = Wt["lstm_w"][D:]
+    V1 = Wt["lm_out_w"].shape[0]
+    END = V1
+    seq = np.zeros((N, T), np.int64)
+    margins = np.full((N,), np.inf)
+    for i in range(N):
+        enc = torch.relu(codes[i:i + 1] @ Wt["lm_enc_w"].t() + Wt["lm_enc_b"])
+        h = torch.zeros(1, Hd); c = torch.zeros(1, Hd)
+        h, c = lstm_step(Wt["lstm_b"] + enc @ Wx, h, c, Wh)                              # image step
+        start = torch.full((1,), V1, dtype=torch.int64)
+        h, c = lstm_step(Wt["lstm_b"] + Wt["lm_emb"][start - 1] @ Wx, h, c, Wh)          # START step
+        scores = (h @ Wt["lm_out_w"].t() + Wt["lm_out_b"]).numpy()
+        beams = np.ones((beam_size, T), np.int64)
+        lp0 = _log_softmax_thnn(scores)[0]
+        beam_logprobs, idx = _topk_sorted(lp0, beam_size)
+        margins[i] = min(margins[i], _topk_margin(lp0, beam_size))
+        beams[:, 0] = idx + 1
+        h = h.expand(beam_size, Hd).clone(); c = c.expand(beam_size, Hd).clone()
+        for t in range(1, T):
+            words = torch.from_numpy(beams[:, t - 1])
+            h, c = lstm_step(Wt["lstm_b"] + Wt["lm_emb"][words - 1] @ Wx, h, c, Wh)
+            lp = _log_softmax_thnn((h @ Wt["lm_out_w"].t() + Wt["lm_out_b"]).numpy())
+            end_mask = ((beams == END).sum(1) == 0).astype(F32)
+            lp = lp * end_mask[:, None]
+            top_lp, word_idx = _topk_sorted(lp, beam_size)                               # (beam, beam)
+            all_next = (top_lp.reshape(-1) + np.repeat(beam_logprobs, beam_size)).astype(F32)
+            live = end_mask > 0
+            if live.any():
+                margins[i] = min(margins[i], _topk_margin(lp[live], beam_size))
+            margins[i] = min(margins[i], _topk_margin(all_next, beam_size))
+            beam_logprobs, flat = _topk_sorted(all_next, beam_size)
+            all_next_beams = np.repeat(beams, beam_size, axis=0)
+            all_next_beams[:, t] = word_idx.reshape(-1) + 1
+            beams = all_next_beams[flat]
+            parent = torch.from_numpy(flat // beam_size)
+            h = h[parent]; c = c[parent]
+        seq[i] = beams[int(np.argmax(beam_logprobs))]
+    if return_margins:
+        return seq, margins
+    return seq
+
+
 def decode_sequence(seq, idx_to_token, vocab_size):
     """LM:decodeSequence (LanguageModel.lua:86-103): stop at END(=V+1) or 0."""
     caps = []
@@ -526,7 +600,7 @@ def preprocess(img_rgb01_chw, image_size):
 
 
 def forward_test(img, Wt, rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=1000,
-                 T=15, stages=None):
+                 T=15, stages=None, beam_size=None):
     """DenseCapModel:forward_test numerics (DenseCapModel.lua:242-275,319-327 via
     LocalizationLayer.lua:250-363).  img: numpy/torch (3,H,W) BGR mean-subtracted.
     Returns (boxes_xcycwh (K,4), scores (K,), tokens (K,T) int64 1-based).
@@ -557,7 +631,10 @@ def forward_test(img, Wt, rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposal
     trans = (codes @ Wt["boxreg_w"].t() + Wt["boxreg_b"]).numpy()
     final_boxes = apply_box_transform(roi_boxes, trans)
     st["obj"] = obj; st["final_trans"] = trans; st["final_boxes_pre_nms"] = final_boxes
-    seq = lm_sample(codes, Wt, T)
+    if beam_size:                                   # LM:updateOutput dispatch (LanguageModel.lua:129-131)
+        seq, st["beam_margins"] = lm_beamsearch(codes, Wt, T, beam_size, return_margins=True)
+    else:
+        seq = lm_sample(codes, Wt, T)
     st["seq_pre_nms"] = seq
     if final_nms_thresh > 0:
         b5 = np.concatenate([xcycwh_to_x1y1x2y2(final_boxes), obj[:, None]], 1)
