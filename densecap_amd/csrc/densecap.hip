@@ -85,6 +85,7 @@ struct dc_ctx {
   float rpn_nms_thresh = 0.7f, final_nms_thresh = 0.3f;
   int max_lanes = 3;
   bool captions_after_final_nms = false;
+  int arena_allocs = 0;      // lane workspace (re)allocations so far (dc_debug_fetch "arena_allocs")
   int beam_size = 0;         // 0 = greedy LM:sample; > 0 = LM:beamsearch (LanguageModel.lua:129-131)
   bool serial_mode = false;  // lanes == 1: idle CUs in a layer's last round are worth a tail split-K (dc_set_lanes)
   int num_proposals = 300;  // LocalizationLayer default (LocalizationLayer.lua:237); run_model sets 1000
@@ -258,11 +259,6 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P) {
     HIPCHK(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
   }
   if (L.H == H && L.W == W && L.P == P && L.arena.p) return DC_OK;
-  if (L.arena.p) {
-    HIPCHK(hipStreamSynchronize(L.stream));
-    HIPCHK(hipFree(L.arena.p));
-    L.arena = DevBuf();
-  }
   int fh = H, fw = W;
   for (int i = 0; i < DC_NUM_VGG_CONVS; ++i)
     if (kVgg[i].pool_after) { fh = (fh + 1) / 2; fw = (fw + 1) / 2; }
@@ -309,8 +305,18 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P) {
   };
   size_t total = 0;
   for (auto& c : cv) total += al(c.bytes);
-  HIPCHK(hipMalloc(&L.arena.p, total));
-  L.arena.bytes = total;
+  // The arena only grows: a directory of mixed sizes (720x480, 720x540, 480x720 ... the normal case for
+  // run_model -input_dir) re-carves the existing allocation instead of a free + malloc of ~0.5 GB per image.
+  if (L.arena.p == nullptr || total > L.arena.bytes) {
+    if (L.arena.p) {
+      HIPCHK(hipStreamSynchronize(L.stream));
+      HIPCHK(hipFree(L.arena.p));
+      L.arena = DevBuf();
+    }
+    HIPCHK(hipMalloc(&L.arena.p, total));
+    L.arena.bytes = total;
+    ctx->arena_allocs += 1;
+  }
   char* p = static_cast<char*>(L.arena.p);
   for (auto& c : cv) { *c.p = p; p += al(c.bytes); }
   nms_workspace_bind(L.nms, L.nms_base, nms_n);
@@ -993,6 +999,11 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
       {"final_nms_idx", L.picks2, (int64_t)P, 4},
       {"final_nms_count", L.count2, 1, 4},
   };
+  if (strcmp(name, "arena_allocs") == 0) {
+    if (capacity_bytes < 4) return ctx->fail(DC_E_INVALID, "dc_debug_fetch: buffer too small");
+    *static_cast<int32_t*>(host_buf) = ctx->arena_allocs;
+    return 1;
+  }
   for (const Ent& e : tab) {
     if (strcmp(e.n, name) == 0) {
       const int64_t bytes = e.elems * e.esize;

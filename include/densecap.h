@@ -154,7 +154,8 @@ int dc_mfma_profile(dc_ctx* ctx, int reset, int64_t* launches, double* total_ms,
 /* Copy an intermediate of the most recent forward to the host for stage-wise parity:
  * name in {"feat_hwc","rpn_heads","rpn_boxes","rpn_x1y1x2y2","rpn_p","rpn_valid",
  * "rpn_nms_idx","rpn_nms_count","roi_boxes","roi_feats","codes","obj","final_trans","final_boxes",
- * "seq","final_nms_idx","final_nms_count"} (lane 0; "seq" is only filled in the reference caption order).
+ * "seq","final_nms_idx","final_nms_count"} (lane 0; "seq" is only filled in the reference caption order), or
+ * "arena_allocs" (int32: how many times a lane workspace has been (re)allocated -- it only grows).
  * Returns the number of elements copied (or <0). */
 int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t capacity_bytes);
 
