@@ -24,6 +24,11 @@ struct GemmDesc {
   int relu = 0;
   // conv3x3 implicit GEMM (mode 1): M = nimg*H*Wd, K = 9*Cin
   int conv = 0, H = 0, Wd = 0, Cin = 0;
+  // conv + fused 2x2/2 ceil-mode max-pool (one image): the M index walks POOL WINDOWS -- m = 4*window + 2*dy + dx with
+  // window = wy*ceil(Wd/2) + wx in raster order of the pooled map, pixel (2wy+dy, 2wx+dx) -- so that the four pixels of
+  // a window are four consecutive accumulator registers of one lane; M = 4*ceil(H/2)*ceil(Wd/2); slots outside the
+  // image (odd H or Wd) read zeros and are left out of the max.  C is the POOLED map: C[window*ldc + n].
+  int pool = 0;
   // optional gathered row term (LSTM input gates): C[m][n] += rowterm[rowidx[m]*rowterm_ld + n]
   const float* rowterm = nullptr;
   const int32_t* rowidx = nullptr;   // values are 1-based token ids -> row = id-1
@@ -52,6 +57,13 @@ struct GemmDesc {
 // C = act(sum_s ws[s] + bias): fixed summation order s = 0..S-1
 hipError_t launch_splitk_reduce(const float* ws, int S, const float* bias, float* C, int M, int N, int ldc, int relu,
                                 hipStream_t s);
+// same for a pooled conv (GemmDesc::pool): ws rows are window-ordered slots [m_begin, m_begin+M); C_pooled is the base
+// of the whole pooled map
+hipError_t launch_splitk_reduce_pool(const float* ws, int S, const float* bias, float* C_pooled, int m_begin, int M, int N,
+                                     int ldc, int H, int Wd, int relu, hipStream_t s);
+// can this conv problem take GemmDesc::pool (the LDS-DMA kernels can; the register-staged v1 fallback cannot)?
+bool mfma_gemm_can_pool(const GemmDesc& d);
+bool mfma_gemm_pool_fusion_enabled();   // false with DENSECAP_NO_POOL_FUSION / DENSECAP_GEMM_V1 (A/B runs)
 // split factor launch_mfma_gemm would like for this problem (1 = none)
 int mfma_gemm_splitk(const GemmDesc& d);
 // Tail plan for problems whose 128x128 tile count is not a multiple of the 256 CUs: rows [0, m_split) run as

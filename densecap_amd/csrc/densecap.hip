@@ -39,7 +39,7 @@ struct Lane {
   int H = 0, W = 0, P = 0;  // sizes the workspace is built for
   int fh = 0, fw = 0, A = 0;
   DevBuf arena;               // one allocation, carved below
-  float *img = nullptr, *act[2] = {nullptr, nullptr}, *feat = nullptr, *rpn_hidden = nullptr, *heads = nullptr;
+  float *img = nullptr, *act[3] = {nullptr, nullptr, nullptr}, *feat = nullptr, *rpn_hidden = nullptr, *heads = nullptr;
   float *rpn_boxes = nullptr, *rpn_xyxy = nullptr, *rpn_p = nullptr;
   uint8_t* rpn_valid = nullptr;
   NmsWorkspace nms;
@@ -136,6 +136,12 @@ namespace {
     if (_r != DC_OK) return _r; \
   } while (0)
 
+#define KCHK(expr)                                                                                      \
+  do {                                                                                                  \
+    hipError_t _e = (expr);                                                                             \
+    if (_e != hipSuccess) return ctx->fail(DC_E_HIP, "%s: %s", #expr, hipGetErrorString(_e));           \
+  } while (0)
+
 int dev_alloc(dc_ctx* ctx, void** p, size_t bytes) {
   HIPCHK(hipMalloc(p, bytes ? bytes : 16));
   ctx->owned.push_back(*p);
@@ -177,7 +183,9 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, float* ws = nullp
     // few tiles, long K: every tile is shared by `sp` workgroups
     d.splitk = sp; d.splitk_ws = ws;
     e = launch_mfma_gemm(d, s);
-    if (e == hipSuccess) e = launch_splitk_reduce(ws, sp, d.bias, d.C, d.M, d.N, d.ldc, d.relu, s);
+    if (e == hipSuccess)
+      e = d.pool ? launch_splitk_reduce_pool(ws, sp, d.bias, d.C, 0, d.M, d.N, d.ldc, d.H, d.Wd, d.relu, s)
+                 : launch_splitk_reduce(ws, sp, d.bias, d.C, d.M, d.N, d.ldc, d.relu, s);
   } else if (ws_ok && ctx->serial_mode && mfma_gemm_tail_plan(d, &m_split, &tail_sp) &&
              (size_t)tail_sp * (d.M - m_split) * d.N <= ws_floats) {
     // tile count not a multiple of the CU count: whole tiles for the full rounds, K-split for the last one
@@ -191,7 +199,8 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, float* ws = nullp
       b.m_begin = m_split; b.a_rows = d.M; b.splitk = tail_sp; b.splitk_ws = ws;
       e = launch_mfma_gemm_ks(b, s);
       if (e == hipSuccess)
-        e = launch_splitk_reduce(ws, tail_sp, d.bias, d.C + (size_t)m_split * d.ldc, d.M - m_split, d.N, d.ldc, d.relu, s);
+        e = d.pool ? launch_splitk_reduce_pool(ws, tail_sp, d.bias, d.C, m_split, d.M - m_split, d.N, d.ldc, d.H, d.Wd, d.relu, s)
+                   : launch_splitk_reduce(ws, tail_sp, d.bias, d.C + (size_t)m_split * d.ldc, d.M - m_split, d.N, d.ldc, d.relu, s);
     }
   } else {
     e = launch_mfma_gemm(d, s);
@@ -232,6 +241,21 @@ int conv3x3(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, const f
   d.relu = relu; d.conv = 1; d.H = H; d.Wd = W; d.Cin = Cin;
   return run_gemm(ctx, d, s, ws, ws_floats);
 }
+// conv3x3 + ReLU + nn.SpatialMaxPooling(2,2,2,2):ceil() (VGG layers conv1_2, conv2_2, conv3_3, conv4_3,
+// DenseCapModel.lua:61-76): the pool rides in the conv's epilogue -- the full-resolution activation never reaches HBM
+// (conv1_2: 110 MB store -> 28 MB) and four launches disappear.  out: (ceil(H/2), ceil(W/2), Cout); `tmp` (H,W,Cout) is
+// only used when the problem has to take the unfused route.
+int conv3x3_pool(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, const float* b, float* out, float* tmp,
+                 int H, int W, int Cin, int Cout, int relu, float* ws, size_t ws_floats) {
+  GemmDesc d;
+  d.A = in; d.W = w; d.bias = b; d.C = out; d.M = 4 * ((H + 1) / 2) * ((W + 1) / 2); d.N = Cout; d.K = 9 * Cin;
+  d.ldc = Cout; d.relu = relu; d.conv = 1; d.H = H; d.Wd = W; d.Cin = Cin; d.pool = 1;
+  if (mfma_gemm_can_pool(d)) return run_gemm(ctx, d, s, ws, ws_floats);
+  if (tmp == nullptr) return ctx->fail(DC_E_UNSUPPORTED, "conv3x3_pool: unfused route needs a scratch buffer");
+  DCCHK(conv3x3(ctx, s, in, w, b, tmp, 1, H, W, Cin, Cout, relu, ws, ws_floats));
+  KCHK(launch_maxpool2x2_ceil(tmp, out, 1, H, W, Cout, s));
+  return DC_OK;
+}
 
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 // num_proposals = -1 (LocalizationLayer.lua:322-324: uncapped RPN NMS): capacity = every anchor of this image size
@@ -271,6 +295,7 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P) {
       {(void**)&L.img, (size_t)3 * H * W * 4},
       {(void**)&L.act[0], act_bytes},
       {(void**)&L.act[1], act_bytes},
+      {(void**)&L.act[2], mfma_gemm_pool_fusion_enabled() ? 256 : act_bytes},
       {(void**)&L.rpn_hidden, (size_t)fh * fw * ctx->R * 4},
       {(void**)&L.heads, (size_t)fh * fw * 6 * ctx->k * 4},
       {(void**)&L.rpn_boxes, (size_t)A * 16},
@@ -330,11 +355,6 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P) {
   return DC_OK;
 }
 
-#define KCHK(expr)                                                                                      \
-  do {                                                                                                  \
-    hipError_t _e = (expr);                                                                             \
-    if (_e != hipSuccess) return ctx->fail(DC_E_HIP, "%s: %s", #expr, hipGetErrorString(_e));           \
-  } while (0)
 
 // One contiguous block of decode rows and the stream it runs on.  LSTM rows are independent, so a batch may be cut
 // into blocks that advance on different streams: every row sees exactly the same arithmetic (the K order of a GEMM
@@ -518,12 +538,15 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int img_on_device, b
   int h = H, w = W, cur = 0;
   KCHK(launch_conv3x3_c3(L.img, ctx->conv_w[0], ctx->conv_b[0], L.act[0], H, W, 64, 1, s));
   for (int i = 1; i < DC_NUM_VGG_CONVS; ++i) {
-    if (kVgg[i - 1].pool_after) {
-      KCHK(launch_maxpool2x2_ceil(L.act[cur], L.act[cur ^ 1], 1, h, w, kVgg[i - 1].cout, s));
-      h = (h + 1) / 2; w = (w + 1) / 2; cur ^= 1;
+    if (kVgg[i].pool_after) {
+      // conv + ReLU + ceil-mode 2x2 pool in one launch; act[2] is scratch for the (rare) unfused route
+      DCCHK(conv3x3_pool(ctx, s, L.act[cur], ctx->conv_w[i], ctx->conv_b[i], L.act[cur ^ 1], L.act[2], h, w, kVgg[i].cin,
+                         kVgg[i].cout, 1, L.splitk_ws, kSplitkWsFloats));
+      h = (h + 1) / 2; w = (w + 1) / 2;
+    } else {
+      DCCHK(conv3x3(ctx, s, L.act[cur], ctx->conv_w[i], ctx->conv_b[i], L.act[cur ^ 1], 1, h, w, kVgg[i].cin,
+                    kVgg[i].cout, 1, L.splitk_ws, kSplitkWsFloats));
     }
-    DCCHK(conv3x3(ctx, s, L.act[cur], ctx->conv_w[i], ctx->conv_b[i], L.act[cur ^ 1], 1, h, w, kVgg[i].cin,
-                  kVgg[i].cout, 1, L.splitk_ws, kSplitkWsFloats));
     cur ^= 1;
   }
   L.feat = L.act[cur];
@@ -1079,6 +1102,26 @@ int dc_op_conv3x3(dc_ctx* ctx, const float* in, const float* w, const float* b, 
   prof_collect(ctx);
   if (rc != DC_OK) return rc;
   if (e2 != hipSuccess) return ctx->fail(DC_E_HIP, "dc_op_conv3x3 sync: %s", hipGetErrorString(e2));
+  return DC_OK;
+}
+int dc_op_conv3x3_relu_pool(dc_ctx* ctx, const float* in, const float* w, const float* b, float* out, int H, int W,
+                            int Cin, int Cout) {
+  OP_PROLOGUE();
+  if (Cin % 32 || Cout % 4 || H <= 0 || W <= 0 || Cout <= 0)
+    return ctx->fail(DC_E_INVALID, "dc_op_conv3x3_relu_pool: need Cin %% 32 == 0, Cout %% 4 == 0 and positive sizes");
+  float *ws = nullptr, *tmp = nullptr;
+  HIPCHK(hipMalloc((void**)&ws, kSplitkWsFloats * 4));
+  if (!mfma_gemm_pool_fusion_enabled() && hipMalloc((void**)&tmp, (size_t)H * W * Cout * 4) != hipSuccess) {
+    (void)hipFree(ws);
+    return ctx->fail(DC_E_NOMEM, "dc_op_conv3x3_relu_pool: scratch allocation failed");
+  }
+  int rc = conv3x3_pool(ctx, s, in, w, b, out, tmp, H, W, Cin, Cout, 1, ws, kSplitkWsFloats);
+  hipError_t e2 = hipStreamSynchronize(s);
+  (void)hipFree(ws);
+  if (tmp) (void)hipFree(tmp);
+  prof_collect(ctx);
+  if (rc != DC_OK) return rc;
+  if (e2 != hipSuccess) return ctx->fail(DC_E_HIP, "dc_op_conv3x3_relu_pool sync: %s", hipGetErrorString(e2));
   return DC_OK;
 }
 int dc_op_conv3x3_c3(dc_ctx* ctx, const float* in, const float* w, const float* b, float* out, int H, int W, int Cout,

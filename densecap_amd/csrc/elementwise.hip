@@ -55,57 +55,68 @@ __global__ void permute_fc6_kernel(const float* __restrict__ in, float* __restri
   }
 }
 
-// ---- conv1_1: Cin=3 direct convolution (VALU), CHW in -> HWC out --------------------------
-// One thread = one pixel x 16 output channels; the 27 taps stay in registers, weights are
-// broadcast from LDS.  4 consecutive lanes write one pixel's 256 contiguous bytes.
+// ---- conv1_1: Cin = 3 (K = 27), CHW boundary image in -> HWC out, on the matrix cores -------------------------------
+// 1.49 GFLOP against 110 MB of output: HBM-store-bound (~14 us at 8 TB/s) once the arithmetic leaves the VALU
+// (the scalar version was VALU-bound at 65 us).  A workgroup owns 4 image rows x 32 columns; the (3, 6, 34) input
+// patch is staged in LDS once (zero padding outside the image); wave w computes row w: M = 32 pixels, N = 64 channels
+// (two 32x32 accumulator blocks), K = 28 = 14 x v_mfma_f32_32x32x2_f32 with k = c*9 + kh*3 + kw (k = 27: zero weight).
+// A fragments are single ds_read_b32 from the patch (lane = pixel, lane half = k parity), B fragments (the weights)
+// live in 28 registers for the whole kernel.  Each store instruction writes two pixels x 128 contiguous bytes.
 template <int COUT>
 __global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          int H, int W, int relu) {
-  __shared__ float ws[27 * COUT];  // [k][o], k = c*9 + kh*3 + kw  (k-order c, kh, kw as im2col does)
-  __shared__ float bs[COUT];
-  for (int i = threadIdx.x; i < 27 * COUT; i += 256) {
-    const int o = i % COUT, k = i / COUT;
-    ws[i] = w[o * 27 + k];
+  static_assert(COUT == 64, "two 32-channel accumulator blocks");
+  constexpr int TR = 4, TC = 32, PR = TR + 2, PC = TC + 2, KP = 28;
+  __shared__ float patch[3 * PR * PC];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, hsel = lane >> 5;
+  const int x0 = blockIdx.x * TC, y0 = blockIdx.y * TR;
+  for (int i = tid; i < 3 * PR * PC; i += 256) {
+    const int c = i / (PR * PC), rem = i - c * (PR * PC), py = rem / PC, px = rem - py * PC;
+    const int y = y0 + py - 1, x = x0 + px - 1;
+    patch[i] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? in[((size_t)c * H + y) * W + x] : 0.f;
   }
-  for (int i = threadIdx.x; i < COUT; i += 256) bs[i] = bias[i];
-  __syncthreads();
-  constexpr int G = COUT / 16;  // channel groups per pixel
-  const size_t npix = (size_t)H * W;
-  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t pix = gid / G;
-  const int grp = (int)(gid % G);
-  if (pix >= npix) return;
-  const int y = (int)(pix / W), x = (int)(pix % W);
-  float v[27];
+  // weights: lane (n = r, half hsel) holds W[n + 32 j][k = 2 s + hsel]
+  float bw[2][KP / 2];
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int yy = y + kh - 1, xx = x + kw - 1;
-        const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-        v[c * 9 + kh * 3 + kw] = ok ? in[((size_t)c * H + yy) * W + xx] : 0.f;
-      }
-  float acc[16];
-#pragma unroll
-  for (int o = 0; o < 16; ++o) acc[o] = 0.f;
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-#pragma unroll
-    for (int o = 0; o < 16; ++o) acc[o] = fmaf(v[k], ws[k * COUT + grp * 16 + o], acc[o]);
-  }
-  float* op = out + pix * COUT + grp * 16;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    f32x4 r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float t = acc[q * 4 + e] + bs[grp * 16 + q * 4 + e];
-      r[e] = (relu && t < 0.f) ? 0.f : t;
+    for (int st = 0; st < KP / 2; ++st) {
+      const int k = 2 * st + hsel;
+      bw[j][st] = k < 27 ? w[(r + 32 * j) * 27 + k] : 0.f;
     }
-    *reinterpret_cast<f32x4*>(op + q * 4) = r;
+  __syncthreads();
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  const float* prow = patch + wid * PC + r;       // pixel (row wid, column r) of the tile; tap (kh, kw) at +kh*PC + kw
+#pragma unroll
+  for (int st = 0; st < KP / 2; ++st) {
+    const int k0 = 2 * st, k1 = k0 + 1 < 27 ? k0 + 1 : 26;               // k = 27 meets a zero weight: any finite input does
+    const int o0 = (k0 / 9) * (PR * PC) + ((k0 % 9) / 3) * PC + (k0 % 3);
+    const int o1 = (k1 / 9) * (PR * PC) + ((k1 % 9) / 3) * PC + (k1 % 3);
+    const float a = prow[hsel ? o1 : o0];
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[0][st], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[1][st], acc[1], 0, 0, 0);
+  }
+  // C/D map of the 32x32 MFMA: col (channel) = lane&31, row (pixel) = (e&3) + 8*(e>>2) + 4*hsel
+  const int y = y0 + wid;
+  if (y >= H) return;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float bv = bias[r + 32 * j];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int x = x0 + (e & 3) + 8 * (e >> 2) + 4 * hsel;
+      if (x < W) {
+        float v = acc[j][e] + bv;
+        if (relu) v = v > 0.f ? v : 0.f;
+        out[((size_t)y * W + x) * COUT + r + 32 * j] = v;
+      }
+    }
   }
 }
 
@@ -326,6 +337,42 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, const 
   }
 }
 
+// split-K finish of a pooled conv (GemmDesc::pool): slots 4*wl .. 4*wl+3 of the workspace are one pool window
+__global__ void splitk_reduce_pool_kernel(const float* __restrict__ ws, int S, const float* __restrict__ bias,
+                                          float* __restrict__ C, int m_begin, int M, int N, int ldc, int H, int Wd,
+                                          int relu) {
+  const int N4 = N >> 2, Wo = (Wd + 1) >> 1;
+  const size_t total = (size_t)(M >> 2) * N4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t wl = i / N4;
+    const int n = (int)(i - wl * N4) * 4;
+    const int win = (m_begin >> 2) + (int)wl, wy = win / Wo, wx = win - wy * Wo;
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (bias) b = *reinterpret_cast<const f32x4*>(bias + n);
+    f32x4 best = {0.f, 0.f, 0.f, 0.f};
+    bool have = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (2 * wy + (c >> 1) >= H || 2 * wx + (c & 1) >= Wd) continue;
+      const size_t m = wl * 4 + c;
+      f32x4 acc = *reinterpret_cast<const f32x4*>(ws + m * N + n);
+      for (int s = 1; s < S; ++s) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ws + ((size_t)s * M + m) * N + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = acc[e] + v[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = acc[e] + b[e];
+        if (relu) t = t > 0.f ? t : 0.f;
+        best[e] = (!have || t > best[e]) ? t : best[e];
+      }
+      have = true;
+    }
+    *reinterpret_cast<f32x4*>(C + (size_t)win * ldc + n) = best;
+  }
+}
+
 __global__ void iota_count_kernel(int32_t* idx, int32_t* count_out, const int32_t* count_in, int cap) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < cap) idx[i] = i;
@@ -401,9 +448,8 @@ hipError_t launch_permute_fc6(const float* in, float* out, int N, int C, int HW,
 hipError_t launch_conv3x3_c3(const float* in, const float* w, const float* bias, float* out, int H, int W, int Cout,
                              int relu, hipStream_t s) {
   if (Cout != 64) return hipErrorInvalidValue;
-  const size_t threads = (size_t)H * W * (Cout / 16);
-  hipLaunchKernelGGL((conv3x3_c3_kernel<64>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, in, w, bias,
-                     out, H, W, relu);
+  hipLaunchKernelGGL((conv3x3_c3_kernel<64>), dim3((W + 31) / 32, (H + 3) / 4), dim3(256), 0, s, in, w, bias, out, H, W,
+                     relu);
   return hipGetLastError();
 }
 hipError_t launch_maxpool2x2_ceil(const float* in, float* out, int nimg, int H, int W, int C, hipStream_t s) {
@@ -443,6 +489,13 @@ hipError_t launch_splitk_reduce(const float* ws, int S, const float* bias, float
   if (N % 4 || ldc % 4) return hipErrorInvalidValue;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)M * (N / 4))), dim3(256), 0, s, ws, S, bias, C, M, N, ldc,
                      relu);
+  return hipGetLastError();
+}
+hipError_t launch_splitk_reduce_pool(const float* ws, int S, const float* bias, float* C_pooled, int m_begin, int M, int N,
+                                     int ldc, int H, int Wd, int relu, hipStream_t s) {
+  if (N % 4 || ldc % 4 || M % 4 || m_begin % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(splitk_reduce_pool_kernel, dim3(grid_for((size_t)(M / 4) * (N / 4))), dim3(256), 0, s, ws, S, bias,
+                     C_pooled, m_begin, M, N, ldc, H, Wd, relu);
   return hipGetLastError();
 }
 hipError_t launch_iota_count(int32_t* idx, int32_t* count_out, const int32_t* count_in, int cap, hipStream_t s) {

@@ -37,6 +37,40 @@ constexpr int BK = 32;
 constexpr unsigned CV_PAD = 0xffffe000u;   // conv padding marker: voffset (+ up to 8 KiB of channel offset) past any descriptor range
 constexpr int LDS_LD = BK + 4;  // floats per LDS row
 
+// Implicit-GEMM row m -> input pixel (y, x) and its byte offset in the channels-last activation.  Plain convs walk the
+// pixels in raster order; pooled convs (GemmDesc::pool) walk pool windows, four consecutive m per window.
+__device__ __forceinline__ void conv_pixel(const GemmDesc& d, int m, int hw, int& y, int& x, bool& ok, unsigned& off) {
+  if (d.pool) {
+    const int Wo = (d.Wd + 1) >> 1;
+    const int win = m >> 2, wy = win / Wo, wx = win - wy * Wo;
+    y = 2 * wy + ((m >> 1) & 1);
+    x = 2 * wx + (m & 1);
+    ok = ok && y < d.H && x < d.Wd;
+    off = ok ? (unsigned)(y * d.Wd + x) * (unsigned)d.Cin * 4u : 0u;
+  } else {
+    const int img = m / hw, rem = m - img * hw;
+    y = rem / d.Wd;
+    x = rem - y * d.Wd;
+    off = (unsigned)m * (unsigned)d.Cin * 4u;
+  }
+}
+// Pooled epilogue of one lane's four consecutive rows (one pool window): max over the window's in-image pixels of
+// act(v + bias).  win = first row >> 2.
+__device__ __forceinline__ float pool_window(const GemmDesc& d, int win, float v0, float v1, float v2, float v3, float bv) {
+  const int Wo = (d.Wd + 1) >> 1;
+  const int wy = win / Wo, wx = win - wy * Wo;
+  const bool hx = 2 * wx + 1 < d.Wd, hy = 2 * wy + 1 < d.H;
+  float t0 = v0 + bv, t1 = v1 + bv, t2 = v2 + bv, t3 = v3 + bv;
+  if (d.relu) {
+    t0 = t0 > 0.f ? t0 : 0.f; t1 = t1 > 0.f ? t1 : 0.f; t2 = t2 > 0.f ? t2 : 0.f; t3 = t3 > 0.f ? t3 : 0.f;
+  }
+  float best = t0;
+  if (hx) best = t1 > best ? t1 : best;
+  if (hy) best = t2 > best ? t2 : best;
+  if (hx && hy) best = t3 > best ? t3 : best;
+  return best;
+}
+
 template <int TM, int TN, bool CONV>
 __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -248,7 +282,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
   int a_y[PA], a_x[PA];
   bool a_ok[PA];
   if constexpr (CONV) {
-    const size_t bytes = (size_t)Meff * d.Cin * 4;
+    const size_t bytes = (size_t)(d.pool ? d.H * d.Wd : Meff) * d.Cin * 4;
     rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : bytes), 0x00020000);
     const int hw = d.H * d.Wd;
 #pragma unroll
@@ -256,10 +290,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
       int m = m0 + lrow + 32 * i;
       a_ok[i] = m < Meff;
       if (m >= Meff) m = Meff - 1;
-      const int img = m / hw, rem = m - img * hw;
-      a_y[i] = rem / d.Wd;
-      a_x[i] = rem - a_y[i] * d.Wd;
-      a_off[i] = (unsigned)m * (unsigned)d.Cin * 4u + (unsigned)lchunk * 16u;
+      conv_pixel(d, m, hw, a_y[i], a_x[i], a_ok[i], a_off[i]);
+      a_off[i] += (unsigned)lchunk * 16u;
     }
   } else {
     const float* baseA = d.A + (size_t)m0 * d.K;
@@ -504,6 +536,29 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
     }
     return;
   }
+  if constexpr (CONV) {
+    if (d.pool) {
+      // ---- fused 2x2/2 ceil-mode max-pool: registers 4q..4q+3 of a lane are the four pixels of pool window (mb+8q)>>2
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * 32 * TN + j * 32 + r;
+        const bool n_ok = n < d.N;
+        const float bv = (d.bias != nullptr && n_ok) ? d.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int mb = m0 + wm * 32 * TM + i * 32 + 4 * hsel;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int mrow = mb + 8 * q;
+            if (n_ok && mrow < Meff)
+              d.C[(size_t)(mrow >> 2) * d.ldc + n] = pool_window(d, mrow >> 2, acc[i][j][4 * q], acc[i][j][4 * q + 1],
+                                                                  acc[i][j][4 * q + 2], acc[i][j][4 * q + 3], bv);
+          }
+        }
+      }
+      return;
+    }
+  }
   // ---- epilogue: bias (+ gathered row term) + ReLU, channels-last store -------------------
   // C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #pragma unroll
@@ -578,7 +633,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
   int a_y[PA], a_x[PA];
   bool a_ok[PA];
   if constexpr (CONV) {
-    const size_t bytes = (size_t)(d.a_rows ? d.a_rows : d.M) * d.Cin * 4;
+    const size_t bytes = (size_t)(d.pool ? d.H * d.Wd : (d.a_rows ? d.a_rows : d.M)) * d.Cin * 4;
     rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : bytes), 0x00020000);
     const int hw = d.H * d.Wd;
 #pragma unroll
@@ -586,10 +641,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
       int m = m0 + lrow + 32 * i;
       a_ok[i] = m < Meff;
       if (m >= Meff) m = Meff - 1;
-      const int img = m / hw, rem = m - img * hw;
-      a_y[i] = rem / d.Wd;
-      a_x[i] = rem - a_y[i] * d.Wd;
-      a_off[i] = (unsigned)m * (unsigned)d.Cin * 4u + (unsigned)lchunk * 16u;
+      conv_pixel(d, m, hw, a_y[i], a_x[i], a_ok[i], a_off[i]);
+      a_off[i] += (unsigned)lchunk * 16u;
     }
   } else {
     const float* baseA = d.A + (size_t)m0 * d.K;
@@ -766,6 +819,14 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
         const int n = n0 + col_l;
         const bool n_ok = n < d.N;
         const float bv = (d.bias != nullptr && n_ok) ? d.bias[n] : 0.f;
+        if constexpr (CONV) {
+          if (d.pool && d.splitk == 1) {       // the four summed rows are one pool window: store its max in the pooled map
+            const int mrow = m0 + (qi + i) * 32 + 8 * wid + 4 * hsel;
+            if (n_ok && mrow < Meff)
+              d.C[(size_t)(mrow >> 2) * d.ldc + n] = pool_window(d, mrow >> 2, s0[0], s0[1], s0[2], s0[3], bv);
+            continue;
+          }
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int row_l = (qi + i) * 32 + c + 8 * wid + 4 * hsel;
@@ -862,7 +923,7 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
                        m_fastest);
     return hipGetLastError();
   }
-  if (d.amax_val != nullptr || d.m_dev != nullptr || d.splitk > 1) return hipErrorInvalidValue;  // v2/ks-only features
+  if (d.amax_val != nullptr || d.m_dev != nullptr || d.splitk > 1 || d.pool) return hipErrorInvalidValue;  // v2/ks-only features
   const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
   const void* fn = reinterpret_cast<const void*>(&mfma_gemm_kernel<TM, TN, CONV>);
   if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
@@ -971,10 +1032,21 @@ hipError_t launch_mfma_gemm_ks(const GemmDesc& d, hipStream_t stream) {
   return launch_cfg<2, 2, false>(d, stream);
 }
 
-// algorithmic FLOPs (the zero rows that pad the arg-max prefix to a tile boundary do not count)
+// algorithmic FLOPs (zero rows that pad the arg-max prefix to a tile boundary and pool-window slots outside the image
+// do not count)
 double gemm_flops(const GemmDesc& d) {
   const double n = d.amax_cols > 0 ? (double)d.amax_n + (double)(d.N - d.amax_cols) : (double)d.N;
-  return 2.0 * (double)d.M * n * (double)d.K;
+  const double m = d.pool ? (double)d.H * (double)d.Wd : (double)d.M;
+  return 2.0 * m * n * (double)d.K;
+}
+
+bool mfma_gemm_pool_fusion_enabled() {
+  static const bool off = getenv("DENSECAP_GEMM_V1") != nullptr || getenv("DENSECAP_NO_POOL_FUSION") != nullptr;
+  return !off;
+}
+bool mfma_gemm_can_pool(const GemmDesc& d) {
+  return mfma_gemm_pool_fusion_enabled() && d.conv && (size_t)d.M * d.Cin * 4 < CV_PAD && d.Cin <= 2048 && (size_t)128 * d.K * 4 < 0xfffffff0ull &&
+         d.N % 4 == 0 && d.ldc % 4 == 0;
 }
 
 hipError_t launch_mfma_gemm(const GemmDesc& d, hipStream_t stream) {

@@ -119,6 +119,20 @@ def conv3x3(ctx, x_nchw, w_oihw, bias, relu=True):
     return np.ascontiguousarray(o.numpy().transpose(0, 3, 1, 2))
 
 
+def conv3x3_relu_pool(ctx, x_chw, w_oihw, bias):
+    """conv3x3 + ReLU + ceil-mode 2x2 max-pool in one launch: (Cin,H,W) -> (Cout, ceil(H/2), ceil(W/2))."""
+    x = _f32(x_chw); w = _f32(w_oihw)
+    Cin, H, W = x.shape
+    Cout = w.shape[0]
+    xh = ctx.to_device(np.ascontiguousarray(x.transpose(1, 2, 0)))
+    wd = ctx.to_device(w); wp = ctx.empty((Cout, 9 * Cin)); bd = ctx.to_device(_f32(bias))
+    check(ctx.h, ctx.lib.dc_op_pack_conv3x3_weights(ctx.h, wd.ptr, wp.ptr, Cout, Cin), "pack")
+    o = ctx.empty(((H + 1) // 2, (W + 1) // 2, Cout))
+    check(ctx.h, ctx.lib.dc_op_conv3x3_relu_pool(ctx.h, xh.ptr, wp.ptr, bd.ptr, o.ptr, H, W, Cin, Cout),
+          "dc_op_conv3x3_relu_pool")
+    return np.ascontiguousarray(o.numpy().transpose(2, 0, 1))
+
+
 def maxpool2x2_ceil(ctx, x_nchw):
     x = _f32(x_nchw)
     N, C_, H, W = x.shape

@@ -200,6 +200,11 @@ int dc_op_pack_conv3x3_weights(dc_ctx* ctx, const float* w_oihw, float* w_packed
  * dc_op_pack_conv3x3_weights; out (n_img,H,W,Cout). */
 int dc_op_conv3x3(dc_ctx* ctx, const float* in_hwc, const float* w_packed, const float* bias,
                   float* out_hwc, int n_img, int H, int W, int Cin, int Cout, int relu);
+/* The same conv + ReLU followed by nn.SpatialMaxPooling(2,2,2,2):ceil() (VGG conv1_2, conv2_2, conv3_3, conv4_3 ->
+ * pool1..4, DenseCapModel.lua:61-76) in ONE launch: the pool is taken in the conv's epilogue, the full-resolution
+ * activation never reaches HBM.  out (ceil(H/2), ceil(W/2), Cout); bit-identical to dc_op_conv3x3 + dc_op_maxpool2x2_ceil. */
+int dc_op_conv3x3_relu_pool(dc_ctx* ctx, const float* in_hwc, const float* w_packed, const float* bias,
+                            float* out_hwc, int H, int W, int Cin, int Cout);
 /* conv1_1: Cin = 3, reads the (3,H,W) CHW boundary image, writes (H,W,Cout) HWC. */
 int dc_op_conv3x3_c3(dc_ctx* ctx, const float* in_chw, const float* w_oihw, const float* bias,
                      float* out_hwc, int H, int W, int Cout, int relu);

@@ -118,6 +118,39 @@ def test_conv_splitk_and_tail_plans_single_lane(case):
         c.close()
 
 
+@pytest.mark.parametrize("case", [(64, 150, 180, 64, 3), (64, 37, 53, 64, 3), (128, 75, 90, 128, 3), (32, 9, 11, 32, 3),
+                                  (64, 301, 203, 64, 3),            # conv1_2-like, odd sizes: ceil-mode windows at both borders
+                                  (128, 300, 360, 128, 1),          # conv2_2 at 720x600: tail plan (single-lane mode)
+                                  (256, 150, 180, 256, 1),          # conv3_3: tail plan
+                                  (512, 75, 90, 512, 1),            # conv4_3: 212 tiles, odd height
+                                  (512, 19, 23, 512, 1)])           # few tiles: split-K + pooled reduce
+def test_conv_relu_pool_fused_equals_conv_then_pool(case):
+    """The pool taken in the conv epilogue (pool-window-ordered implicit GEMM rows) must be bit-identical to the conv
+    followed by the stand-alone ceil-mode pool: same K order per pixel, max and ReLU commute exactly."""
+    import torch
+    from densecap_amd import ops
+    from densecap_amd._lib import check
+    Cin, H, W, Cout, lanes = case
+    c = ops.Context(0)
+    try:
+        check(c.h, c.lib.dc_set_lanes(c.h, lanes), "dc_set_lanes")
+        g = torch.Generator().manual_seed(Cin + H + W)
+        x = torch.randn(Cin, H, W, generator=g).numpy()
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).numpy()
+        b = torch.randn(Cout, generator=g).numpy()
+        fused = ops.conv3x3_relu_pool(c, x, w, b)
+        full = ops.conv3x3(c, x[None], w, b, relu=True)
+        np.testing.assert_array_equal(fused, ops.maxpool2x2_ceil(c, full)[0])
+        assert fused.shape == (Cout, (H + 1) // 2, (W + 1) // 2)
+        # and the full-resolution conv itself against fp64 (the pooled values inherit its accuracy)
+        ref = torch.relu(torch.nn.functional.conv2d(torch.from_numpy(x)[None].double(), torch.from_numpy(w).double(),
+                                                    torch.from_numpy(b).double(), padding=1))
+        refp = torch.nn.functional.max_pool2d(ref, 2, 2, ceil_mode=True)[0].float().numpy()
+        _close(fused, refp, rel=2e-5)
+    finally:
+        c.close()
+
+
 def test_lm_encoder_splitk_single_lane():
     """image_encoder Linear(4096,512) at M=1000 (32 tiles, K=4096 -> split-K in single-image mode)."""
     from densecap_amd import ops
