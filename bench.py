@@ -325,7 +325,7 @@ def main():
             # PMC passes of this same command with --lanes 1 (tools/collect_profiles.sh + tools/pmc_summary.py)
             try:
                 pm = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
-                fam = [v for k, v in pm.items() if k.startswith("mfma_gemm") and "avg_hbm_bytes_per_launch" in v]
+                fam = [v for k, v in pm.items() if k.startswith("mfma_gemm") and isinstance(v, dict) and "avg_hbm_bytes_per_launch" in v]
                 calls = sum(v["calls"] for v in fam)
                 roof["traffic_from_profile"] = {
                     "hbm_bytes_per_launch": sum(v["avg_hbm_bytes_per_launch"] * v["calls"] for v in fam) / calls,

@@ -126,7 +126,8 @@ def test_conv_splitk_and_tail_plans_single_lane(case):
                                   (512, 19, 23, 512, 1)])           # few tiles: split-K + pooled reduce
 def test_conv_relu_pool_fused_equals_conv_then_pool(case):
     """The pool taken in the conv epilogue (pool-window-ordered implicit GEMM rows) must be bit-identical to the conv
-    followed by the stand-alone ceil-mode pool: same K order per pixel, max and ReLU commute exactly."""
+    followed by the stand-alone ceil-mode pool (same K order per pixel; max and ReLU commute exactly) whenever every row
+    takes the same kernel route, i.e. in the multi-lane mode; in single-image mode it agrees to fp32 rounding."""
     import torch
     from densecap_amd import ops
     from densecap_amd._lib import check
@@ -140,8 +141,14 @@ def test_conv_relu_pool_fused_equals_conv_then_pool(case):
         b = torch.randn(Cout, generator=g).numpy()
         fused = ops.conv3x3_relu_pool(c, x, w, b)
         full = ops.conv3x3(c, x[None], w, b, relu=True)
-        np.testing.assert_array_equal(fused, ops.maxpool2x2_ceil(c, full)[0])
+        unfused = ops.maxpool2x2_ceil(c, full)[0]
         assert fused.shape == (Cout, (H + 1) // 2, (W + 1) // 2)
+        if lanes != 1:
+            np.testing.assert_array_equal(fused, unfused)
+        else:
+            # single-image mode K-splits the LAST partial round of tiles (another fixed fp32 summation order for those
+            # rows); the fused conv walks pool windows, the plain one raster rows, so different pixels fall in that round
+            _close(fused, unfused, rel=1e-5)
         # and the full-resolution conv itself against fp64 (the pooled values inherit its accuracy)
         ref = torch.relu(torch.nn.functional.conv2d(torch.from_numpy(x)[None].double(), torch.from_numpy(w).double(),
                                                     torch.from_numpy(b).double(), padding=1))

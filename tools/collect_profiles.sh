@@ -18,12 +18,20 @@ run() {  # name, bench args, rocprof args...
   timeout 600 rocprofv3 "$@" --output-format csv -d /tmp/rp_$name -o $name -- $BENCH $args > /tmp/rp_$name.json 2> /tmp/rp_$name.err
   find /tmp/rp_$name -name "${name}_*.csv" -exec cp {} "$OUT"/ \;
 }
-run lanes1 "--steps 10 --warmup 3" --kernel-trace --stats
+run lanes1 "--steps 10 --warmup 3 --repeats 1" --kernel-trace --stats
 grep '^{' /tmp/rp_lanes1.json > "$OUT/bench_lanes1.json"
-run fetch "--steps 3 --warmup 1" --kernel-trace --pmc FETCH_SIZE
-run write "--steps 3 --warmup 1" --kernel-trace --pmc WRITE_SIZE
-run mfma "--steps 3 --warmup 1" --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT
-cd "$REPO"
+run fetch "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc FETCH_SIZE
+run write "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc WRITE_SIZE
+run mfma "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT
+# the DEFAULT (multi-lane) schedule -- the one the headline number comes from -- under the kernel trace as well
+# (rocprofv3 serialises dispatches, so the overlap itself is not visible; per-kernel durations and counts are)
 unset DENSECAP_NO_DECODE_SPLIT
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-alt-pass"
+run default "--steps 10 --warmup 3 --repeats 2" --kernel-trace --stats
+grep '^{' /tmp/rp_default.json > "$OUT/bench_default_under_rocprof.json"
+cd "$REPO"
 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+python bench.py --height 320 --width 480 --proposals 50 --lanes 1 --steps 30 --no-cpu-baseline --no-alt-pass > "$OUT/bench_webcam_480_p50.json" 2>/dev/null
+python bench.py --proposals 300 --steps 32 --no-cpu-baseline > "$OUT/bench_config3_p300.json" 2>/dev/null
+python bench.py --height 720 --width 1080 --proposals 2000 --steps 12 --warmup 2 --no-cpu-baseline > "$OUT/bench_config5.json" 2>/dev/null
 ls -la "$OUT"

@@ -73,9 +73,18 @@ def main():
             summ[f]["clock_ghz"] = gui / c["_dur_us"] / 1e3
             summ[f]["mfma_tflops_counted"] = c["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512 / (c["_dur_us"] * 1e-6) / 1e12
             summ[f]["lds_bank_conflict_cycles"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0)
+    try:
+        import subprocess
+        summ["_commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"]).decode().strip()
+    except Exception:
+        summ["_commit"] = None
     json.dump(summ, open(prefix + "_pmc_summary.json", "w"), indent=1)
+    for extra in ("default_kernel_stats.csv", "bench_default_under_rocprof.json", "bench_default.json",
+                  "bench_webcam_480_p50.json", "bench_config3_p300.json", "bench_config5.json"):
+        if os.path.exists(os.path.join(d, extra)):
+            shutil.copy(os.path.join(d, extra), prefix + "_" + extra.replace("default_kernel_stats", "kernel_stats_default_lanes"))
     for f, e in summ.items():
-        if e["total_us"] > 50:
+        if isinstance(e, dict) and e["total_us"] > 50:
             print("%-44s calls=%4d avg_us=%9.1f %s" % (f[:44], e["calls"], e["avg_us"],
                   " ".join("%s=%.3g" % (k, v) for k, v in e.items() if k not in ("calls", "total_us", "avg_us"))))
 
