@@ -60,8 +60,8 @@ __global__ void permute_fc6_kernel(const float* __restrict__ in, float* __restri
 // (the scalar version was VALU-bound at 65 us).  A workgroup owns 4 image rows x 32 columns; the (3, 6, 34) input
 // patch is staged in LDS once (zero padding outside the image); wave w computes row w: M = 32 pixels, N = 64 channels
 // (two 32x32 accumulator blocks), K = 28 = 14 x v_mfma_f32_32x32x2_f32 with k = c*9 + kh*3 + kw (k = 27: zero weight).
-// A fragments are single ds_read_b32 from the patch (lane = pixel, lane half = k parity), B fragments (the weights)
-// live in 28 registers for the whole kernel.  Each store instruction writes two pixels x 128 contiguous bytes.
+// A fragments are single ds_read_b32 from the patch (lane = pixel, lane half = k parity), B fragments (the weights,
+// staged through LDS) live in 28 registers.  Each store instruction writes two pixels x 128 contiguous bytes.
 template <int COUT>
 __global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ out,
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float* __restrict
   static_assert(COUT == 64, "two 32-channel accumulator blocks");
   constexpr int TR = 4, TC = 32, PR = TR + 2, PC = TC + 2, KP = 28;
   __shared__ float patch[3 * PR * PC];
+  __shared__ float wsm[COUT * 27];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, hsel = lane >> 5;
   const int x0 = blockIdx.x * TC, y0 = blockIdx.y * TR;
@@ -77,16 +78,19 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float* __restrict
     const int y = y0 + py - 1, x = x0 + px - 1;
     patch[i] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? in[((size_t)c * H + y) * W + x] : 0.f;
   }
-  // weights: lane (n = r, half hsel) holds W[n + 32 j][k = 2 s + hsel]
+  // weights (64 x 27, 6.9 KB): one coalesced pass into LDS (a per-lane gather from global costs 28 scattered loads per
+  // thread -- measured 2x the whole kernel), then lane (n = r, half hsel) takes W[n + 32 j][k = 2 s + hsel]; the odd row
+  // stride 27 keeps the LDS reads conflict-free
+  for (int i = tid; i < COUT * 27; i += 256) wsm[i] = w[i];
+  __syncthreads();
   float bw[2][KP / 2];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int st = 0; st < KP / 2; ++st) {
       const int k = 2 * st + hsel;
-      bw[j][st] = k < 27 ? w[(r + 32 * j) * 27 + k] : 0.f;
+      bw[j][st] = k < 27 ? wsm[(r + 32 * j) * 27 + k] : 0.f;
     }
-  __syncthreads();
   f32x16 acc[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void argmax_finalize_kernel(const float* __res
   }
 }
 
-// ---- decode step tail: arg-max finalize + LSTM point-wise, one workgroup (256 threads) per row ---------------------
+// ---- decode step tail: arg-max finalize + LSTM point-wise, one wave per row ------------------------------------------
 // Replaces argmax_finalize + the gate row-term epilogue + lstm_pointwise of one step (3 launches and an 8 MB gate
 // round trip) by one launch: the token a row just produced selects its xg row here, so the h.Wh product of the NEXT
 // step's gates can run inside the same GEMM launch as the vocabulary projection (both only need h_t).
@@ -232,32 +236,25 @@ __global__ __launch_bounds__(256) void lstm_step_tail_kernel(const float* __rest
                                                              float* __restrict__ c, float* __restrict__ h, int n,
                                                              const int32_t* __restrict__ n_dev, int Hd, int zero_c,
                                                              int32_t* __restrict__ seq, int T, int t) {
+  // one WAVE per row (four rows per workgroup): no barrier anywhere; a lane owns 4 consecutive hidden units per pass
   if (n_dev) n = min(n, *n_dev);
-  const int m = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= n) return;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  __shared__ float sv[4];
-  __shared__ int si[4];
-  // the token-independent operands are requested first: they travel while the arg-max is being reduced
-  constexpr int UPT = 2;                            // hidden units per thread and pass (Hd = 512: one pass)
-  float gpre[UPT][4], cprev[UPT];
   const float* g = gates_pre ? gates_pre + (size_t)m * 4 * Hd : nullptr;
-  if (g != nullptr) {
+  // the token-independent operands of the first pass are requested before the arg-max is reduced
+  f32x4 gp[4] = {}, cp = {0.f, 0.f, 0.f, 0.f};
+  const int j0 = lane * 4;
+  if (g != nullptr && j0 < Hd) {
 #pragma unroll
-    for (int u = 0; u < UPT; ++u) {
-      const int j = tid + u * 256;
-      if (j < Hd) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) gpre[u][q] = g[q * Hd + j];
-        cprev[u] = zero_c ? 0.f : c[(size_t)m * Hd + j];
-      }
-    }
+    for (int q = 0; q < 4; ++q) gp[q] = *reinterpret_cast<const f32x4*>(g + q * Hd + j0);
+    if (!zero_c) cp = *reinterpret_cast<const f32x4*>(c + (size_t)m * Hd + j0);
   }
   int tok = fixed_tok;
   if (pval != nullptr) {
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int j = tid; j < ntiles; j += 256) {
+    for (int j = lane; j < ntiles; j += 64) {
       const float v = pval[(size_t)m * ld + j];
       const int i = pidx[(size_t)m * ld + j];
       if (bi == 0x7fffffff || v > best) { best = v; bi = i; }      // ascending j = ascending column: first max stays
@@ -268,45 +265,34 @@ __global__ __launch_bounds__(256) void lstm_step_tail_kernel(const float* __rest
       const int oi = __shfl_xor(bi, o, 64);
       if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
     }
-    if (lane == 0) { sv[wid] = best; si[wid] = bi; }
-    __syncthreads();
-    best = sv[0]; bi = si[0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      const float ov = sv[w];
-      const int oi = si[w];
-      if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
-    }
     tok = bi + 1;
-    if (tid == 0) seq[(size_t)m * T + t] = tok;
+    if (lane == 0) seq[(size_t)m * T + t] = tok;
   }
   if (g == nullptr) return;
   const float* x = tok > 0 ? xg + (size_t)(tok - 1) * 4 * Hd : nullptr;
-  for (int j0 = 0; j0 < Hd; j0 += 256 * UPT) {
-    if (j0 > 0) {                                   // Hd > 512: further passes load in place
+  for (int j = j0; j < Hd; j += 256) {
+    if (j != j0) {                                    // Hd > 256: later passes load in place
 #pragma unroll
-      for (int u = 0; u < UPT; ++u) {
-        const int j = j0 + tid + u * 256;
-        if (j < Hd) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) gpre[u][q] = g[q * Hd + j];
-          cprev[u] = zero_c ? 0.f : c[(size_t)m * Hd + j];
-        }
-      }
+      for (int q = 0; q < 4; ++q) gp[q] = *reinterpret_cast<const f32x4*>(g + q * Hd + j);
+      cp = zero_c ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(c + (size_t)m * Hd + j);
     }
+    f32x4 xv[4] = {};
+    if (x != nullptr) {
 #pragma unroll
-    for (int u = 0; u < UPT; ++u) {
-      const int j = j0 + tid + u * 256;
-      if (j >= Hd) continue;
-      float gi = gpre[u][0], gf = gpre[u][1], go = gpre[u][2], gg = gpre[u][3];
-      if (x != nullptr) { gi = x[j] + gi; gf = x[Hd + j] + gf; go = x[2 * Hd + j] + go; gg = x[3 * Hd + j] + gg; }
+      for (int q = 0; q < 4; ++q) xv[q] = *reinterpret_cast<const f32x4*>(x + q * Hd + j);
+    }
+    f32x4 cn, hn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gi = gp[0][e], gf = gp[1][e], go = gp[2][e], gg = gp[3][e];
+      if (x != nullptr) { gi = xv[0][e] + gi; gf = xv[1][e] + gf; go = xv[2][e] + go; gg = xv[3][e] + gg; }
       const float ig = sigmoidf_(gi), fg = sigmoidf_(gf), og = sigmoidf_(go);
       const float gt = tanhf(gg);
-      const size_t i = (size_t)m * Hd + j;
-      const float cn = fg * cprev[u] + ig * gt;
-      c[i] = cn;
-      h[i] = og * tanhf(cn);
+      cn[e] = fg * cp[e] + ig * gt;
+      hn[e] = og * tanhf(cn[e]);
     }
+    *reinterpret_cast<f32x4*>(c + (size_t)m * Hd + j) = cn;
+    *reinterpret_cast<f32x4*>(h + (size_t)m * Hd + j) = hn;
   }
 }
 
@@ -480,8 +466,9 @@ hipError_t launch_lstm_step_tail(const float* pval, const int32_t* pidx, int nti
                                  const float* xg, const float* gates_pre, float* c, float* h, int n,
                                  const int32_t* n_dev, int Hd, int zero_c, int32_t* seq, int T, int t, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(lstm_step_tail_kernel, dim3(n), dim3(256), 0, s, pval, pidx, ntiles, ld, fixed_tok, xg, gates_pre,
-                     c, h, n, n_dev, Hd, zero_c, seq, T, t);
+  if (Hd % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(lstm_step_tail_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pval, pidx, ntiles, ld, fixed_tok, xg,
+                     gates_pre, c, h, n, n_dev, Hd, zero_c, seq, T, t);
   return hipGetLastError();
 }
 hipError_t launch_splitk_reduce(const float* ws, int S, const float* bias, float* C, int M, int N, int ldc, int relu,

@@ -883,7 +883,8 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
       static const bool no_ks = getenv("DENSECAP_GEMM_NOKS") != nullptr;
       const bool forced = d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0;
       if (d.amax_val != nullptr) return hipErrorInvalidValue;    // the arg-max epilogue lives in the 64-column v2 variant
-      if (!no_ks && (d.K % (2 * BK * d.splitk)) == 0 && (forced || d.K >= 32 * BK)) {   // short K loops do not amortise the 4-phase reduction
+      static const int ks_min_ktiles = getenv("DENSECAP_KS_MINK") ? atoi(getenv("DENSECAP_KS_MINK")) : 32;   // A/B switch
+      if (!no_ks && (d.K % (2 * BK * d.splitk)) == 0 && (forced || d.K >= ks_min_ktiles * BK)) {   // short K loops do not amortise the 4-phase reduction
         // 64 KiB operand ring, reused as the 4 x 16 KiB reduction slots; leaves 96 KiB of the CU's LDS to co-resident workgroups
         const size_t lds_ks = (size_t)2 * (BM + BN) * BK * sizeof(float);
         const void* fn = reinterpret_cast<const void*>(&mfma_gemm_ks_kernel<CONV>);

@@ -33,6 +33,8 @@ def build_parser():
     a("-num_proposals", type=int, default=1000)
     a("-gpu", type=int, default=0)
     a("-synthetic_weights", type=int, default=0)
+    a("-beam_size", type=int, default=0,
+      help="language_model.beam_size (LanguageModel.lua:129-131): 0 = greedy sampling, n = beam search")
     a("-max_polls", type=int, default=-1, help="stop after this many directory polls (-1 = forever)")
     return p
 
@@ -96,6 +98,7 @@ def main(argv=None):
     model.evaluate()
     model.setTestArgs(num_proposals=opt.num_proposals, rpn_nms_thresh=opt.rpn_nms_thresh,
                       final_nms_thresh=opt.final_nms_thresh)
+    model.setBeamSize(opt.beam_size)
     serve(model, opt)
     return 0
 

@@ -498,3 +498,35 @@ def test_mixed_image_sizes_reuse_the_lane_workspace(model, weights):
         first[key] = out
     a1, _ = model.debug_fetch("arena_allocs", (1,), np.int32)
     assert a1[0] == a0[0], "lane workspace was re-allocated %d times for smaller images" % (a1[0] - a0[0])
+
+
+def test_webcam_daemon_with_the_hip_model(tmp_path):
+    """webcam/daemon.lua:55-102 end to end with the real model (small vocabulary): a 640x480 frame dropped into the input
+    directory is consumed, <id>.json carries boxes rescaled to the ORIGINAL frame, and the result equals what
+    forward_test gives on the same preprocessed frame (webcam settings: 480 px, 50 proposals, single_machine_demo.lua:25-26)."""
+    import json
+    from PIL import Image
+    from densecap_amd import DenseCapModel, daemon as D
+    from densecap_amd.run_model import load_image_caffe, xcycwh_to_xywh
+    from densecap_amd.weights import make_synthetic_weights
+    W = make_synthetic_weights(seed=1234, vocab_size=300, seq_length=8)
+    m = DenseCapModel(W, device=0)
+    try:
+        m.setLanes(1)
+        m.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=50)
+        ind, outd = tmp_path / "in", tmp_path / "out"
+        ind.mkdir()
+        frame = np.random.default_rng(9).uniform(0, 255, (960, 1280, 3)).astype(np.uint8)
+        Image.fromarray(frame).save(ind / "frame3.jpg", quality=95)
+        x, _ = load_image_caffe(str(ind / "frame3.jpg"), 480)
+        assert x.shape == (1, 3, 360, 480)
+        eb, es, ecaps = m.forward_test(x)
+        opt = D.build_parser().parse_args(["-input_dir", str(ind), "-output_dir", str(outd), "-max_polls", "1",
+                                           "-max_image_size", "480", "-num_proposals", "50"])
+        D.serve(m, opt)
+        out = json.load(open(outd / "frame3.json"))
+        assert not (ind / "frame3.jpg").exists()
+        assert out["height"] == 960 and out["width"] == 1280 and out["captions"] == ecaps and len(ecaps) > 0
+        np.testing.assert_allclose(out["boxes"], D.scale_boxes_xywh(xcycwh_to_xywh(eb), 960.0 / 360.0), rtol=1e-6)
+    finally:
+        m.ctx.close()

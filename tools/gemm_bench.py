@@ -8,6 +8,7 @@ from densecap_amd.ops import Context
 from densecap_amd._lib import check
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+CUSTOM = [tuple(int(v) for v in a.split(",")) for a in sys.argv[2:] if a.count(",") == 2]     # extra "M,N,K" shapes only
 ctx = Context(0)
 lib = ctx.lib
 
@@ -27,6 +28,9 @@ LIN = [("fc6", 1000, 4096, 25088), ("fc7", 1000, 4096, 4096), ("lm_enc", 1000, 5
 CONV = [("conv1_2", 600, 720, 64, 64), ("conv2_1", 300, 360, 64, 128), ("conv2_2", 300, 360, 128, 128),
         ("conv3_1", 150, 180, 128, 256), ("conv3_2", 150, 180, 256, 256), ("conv4_1", 75, 90, 256, 512),
         ("conv4_2", 75, 90, 512, 512), ("conv5_1", 38, 45, 512, 512), ("rpn_conv", 38, 45, 512, 256)]
+if CUSTOM:
+    LIN = [("%dx%dx%d" % c,) + c for c in CUSTOM]
+    CONV = []
 print("%-10s %10s %10s %8s" % ("op", "GFLOP", "us", "TF"))
 for item in LIN:
     if item is None: continue
