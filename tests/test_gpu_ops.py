@@ -254,8 +254,10 @@ def test_box_iou_conventions_exact(ctx, conv):
     got = ops.box_iou(ctx, b1, b2, code)
     np.testing.assert_array_equal(got, O.box_iou(b1, b2, name))
     assert got.min() >= 0 and got.max() <= 1
-    if name != "boxiou_module":
-        assert (np.diag(got[:20, :20]) == 1).all()
+    if name == "nms_plus1":
+        assert (np.diag(got[:20, :20]) == 1).all()             # intersection and both areas are the same fp32 expression
+    elif name == "legacy_half_w":
+        np.testing.assert_allclose(np.diag(got[:20, :20]), 1.0, rtol=1e-5)   # (xc + w/2) - (xc - w/2) rounds, w*h does not
     else:
         # the live module mixes (w-1) extents in the intersection with w*h areas: IoU(b, b) = (w-1)(h-1) / (2wh - (w-1)(h-1)) < 1
         assert (np.diag(got[:20, :20]) < 1).all()
