@@ -253,7 +253,7 @@ def test_box_iou_conventions_exact(ctx, conv):
     b2[:20] = b1[:20]                                            # identical boxes
     got = ops.box_iou(ctx, b1, b2, code)
     np.testing.assert_array_equal(got, O.box_iou(b1, b2, name))
-    assert got.min() >= 0 and got.max() <= 1
+    assert got.min() >= 0 and got.max() <= 1 + 2e-6          # legacy_half_w can round a self-IoU to 1 + 1 ulp
     if name == "nms_plus1":
         assert (np.diag(got[:20, :20]) == 1).all()             # intersection and both areas are the same fp32 expression
     elif name == "legacy_half_w":
