@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float* __restrict
   static_assert(COUT == 64, "two 32-channel accumulator blocks");
   constexpr int TR = 4, TC = 32, PR = TR + 2, PC = TC + 2, KP = 28;
   __shared__ float patch[3 * PR * PC];
-  __shared__ float wsm[COUT * 27];
+  __shared__ float wsm[4 * 32 * 68];                 // weights (64 x 27 floats) first, then the output transpose tiles
+  static_assert(4 * 32 * 68 >= COUT * 27, "weights fit in the transpose buffer");
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, hsel = lane >> 5;
   const int x0 = blockIdx.x * TC, y0 = blockIdx.y * TR;
@@ -106,20 +107,33 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float* __restrict
     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[0][st], acc[0], 0, 0, 0);
     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[1][st], acc[1], 0, 0, 0);
   }
-  // C/D map of the 32x32 MFMA: col (channel) = lane&31, row (pixel) = (e&3) + 8*(e>>2) + 4*hsel
-  const int y = y0 + wid;
-  if (y >= H) return;
+  // Epilogue.  C/D map of the 32x32 MFMA: col (channel) = lane&31, row (pixel) = (e&3) + 8*(e>>2) + 4*hsel.  The wave's
+  // result -- 32 consecutive pixels x 64 channels -- is ONE contiguous 8 KiB run of the channels-last output, so it is
+  // transposed through LDS ([pixel][64 + 4 pad] floats) and leaves as 16-byte stores, 1 KiB contiguous per instruction
+  // (dword stores in MFMA order reach ~2.5 TB/s on this 110 MB store-bound kernel).
+  __syncthreads();                                   // all waves are done with the patch / weights
+  float* ot = wsm + wid * (32 * 68);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const float bv = bias[r + 32 * j];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int x = x0 + (e & 3) + 8 * (e >> 2) + 4 * hsel;
-      if (x < W) {
-        float v = acc[j][e] + bv;
-        if (relu) v = v > 0.f ? v : 0.f;
-        out[((size_t)y * W + x) * COUT + r + 32 * j] = v;
-      }
+      float v = acc[j][e] + bv;
+      if (relu) v = v > 0.f ? v : 0.f;
+      ot[((e & 3) + 8 * (e >> 2) + 4 * hsel) * 68 + r + 32 * j] = v;
+    }
+  }
+  // (same wave reads what it wrote: no barrier needed, the LDS ops of a wave complete in order)
+  const int y = y0 + wid;
+  if (y >= H) return;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int idx = it * 64 + lane;                  // float4 index inside the wave's 32 x 64 block
+    const int px = idx >> 4, c4 = idx & 15;
+    const int x = x0 + px;
+    if (x < W) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ot + px * 68 + c4 * 4);
+      *reinterpret_cast<f32x4*>(out + ((size_t)y * W + x) * COUT + c4 * 4) = v;
     }
   }
 }
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(256) void argmax_finalize_kernel(const float* __res
   }
 }
 
-// ---- decode step tail: arg-max finalize + LSTM point-wise, one wave per row ------------------------------------------
+// ---- decode step tail: arg-max finalize + LSTM point-wise, one workgroup (256 threads) per row ---------------------
 // Replaces argmax_finalize + the gate row-term epilogue + lstm_pointwise of one step (3 launches and an 8 MB gate
 // round trip) by one launch: the token a row just produced selects its xg row here, so the h.Wh product of the NEXT
 // step's gates can run inside the same GEMM launch as the vocabulary projection (both only need h_t).
@@ -236,25 +250,32 @@ __global__ __launch_bounds__(256) void lstm_step_tail_kernel(const float* __rest
                                                              float* __restrict__ c, float* __restrict__ h, int n,
                                                              const int32_t* __restrict__ n_dev, int Hd, int zero_c,
                                                              int32_t* __restrict__ seq, int T, int t) {
-  // one WAVE per row (four rows per workgroup): no barrier anywhere; a lane owns 4 consecutive hidden units per pass
   if (n_dev) n = min(n, *n_dev);
-  const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int m = blockIdx.x;
   if (m >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  // the token-independent operands are requested first: they travel while the arg-max is being reduced
+  constexpr int UPT = 2;                            // hidden units per thread and pass (Hd = 512: one pass)
+  float gpre[UPT][4], cprev[UPT];
   const float* g = gates_pre ? gates_pre + (size_t)m * 4 * Hd : nullptr;
-  // the token-independent operands of the first pass are requested before the arg-max is reduced
-  f32x4 gp[4] = {}, cp = {0.f, 0.f, 0.f, 0.f};
-  const int j0 = lane * 4;
-  if (g != nullptr && j0 < Hd) {
+  if (g != nullptr) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) gp[q] = *reinterpret_cast<const f32x4*>(g + q * Hd + j0);
-    if (!zero_c) cp = *reinterpret_cast<const f32x4*>(c + (size_t)m * Hd + j0);
+    for (int u = 0; u < UPT; ++u) {
+      const int j = tid + u * 256;
+      if (j < Hd) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gpre[u][q] = g[q * Hd + j];
+        cprev[u] = zero_c ? 0.f : c[(size_t)m * Hd + j];
+      }
+    }
   }
   int tok = fixed_tok;
   if (pval != nullptr) {
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int j = lane; j < ntiles; j += 64) {
+    for (int j = tid; j < ntiles; j += 256) {
       const float v = pval[(size_t)m * ld + j];
       const int i = pidx[(size_t)m * ld + j];
       if (bi == 0x7fffffff || v > best) { best = v; bi = i; }      // ascending j = ascending column: first max stays
@@ -265,34 +286,45 @@ __global__ __launch_bounds__(256) void lstm_step_tail_kernel(const float* __rest
       const int oi = __shfl_xor(bi, o, 64);
       if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
     }
+    if (lane == 0) { sv[wid] = best; si[wid] = bi; }
+    __syncthreads();
+    best = sv[0]; bi = si[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float ov = sv[w];
+      const int oi = si[w];
+      if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+    }
     tok = bi + 1;
-    if (lane == 0) seq[(size_t)m * T + t] = tok;
+    if (tid == 0) seq[(size_t)m * T + t] = tok;
   }
   if (g == nullptr) return;
   const float* x = tok > 0 ? xg + (size_t)(tok - 1) * 4 * Hd : nullptr;
-  for (int j = j0; j < Hd; j += 256) {
-    if (j != j0) {                                    // Hd > 256: later passes load in place
+  for (int j0 = 0; j0 < Hd; j0 += 256 * UPT) {
+    if (j0 > 0) {                                   // Hd > 512: further passes load in place
 #pragma unroll
-      for (int q = 0; q < 4; ++q) gp[q] = *reinterpret_cast<const f32x4*>(g + q * Hd + j);
-      cp = zero_c ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(c + (size_t)m * Hd + j);
+      for (int u = 0; u < UPT; ++u) {
+        const int j = j0 + tid + u * 256;
+        if (j < Hd) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gpre[u][q] = g[q * Hd + j];
+          cprev[u] = zero_c ? 0.f : c[(size_t)m * Hd + j];
+        }
+      }
     }
-    f32x4 xv[4] = {};
-    if (x != nullptr) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) xv[q] = *reinterpret_cast<const f32x4*>(x + q * Hd + j);
-    }
-    f32x4 cn, hn;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float gi = gp[0][e], gf = gp[1][e], go = gp[2][e], gg = gp[3][e];
-      if (x != nullptr) { gi = xv[0][e] + gi; gf = xv[1][e] + gf; go = xv[2][e] + go; gg = xv[3][e] + gg; }
+    for (int u = 0; u < UPT; ++u) {
+      const int j = j0 + tid + u * 256;
+      if (j >= Hd) continue;
+      float gi = gpre[u][0], gf = gpre[u][1], go = gpre[u][2], gg = gpre[u][3];
+      if (x != nullptr) { gi = x[j] + gi; gf = x[Hd + j] + gf; go = x[2 * Hd + j] + go; gg = x[3 * Hd + j] + gg; }
       const float ig = sigmoidf_(gi), fg = sigmoidf_(gf), og = sigmoidf_(go);
       const float gt = tanhf(gg);
-      cn[e] = fg * cp[e] + ig * gt;
-      hn[e] = og * tanhf(cn[e]);
+      const size_t i = (size_t)m * Hd + j;
+      const float cn = fg * cprev[u] + ig * gt;
+      c[i] = cn;
+      h[i] = og * tanhf(cn);
     }
-    *reinterpret_cast<f32x4*>(c + (size_t)m * Hd + j) = cn;
-    *reinterpret_cast<f32x4*>(h + (size_t)m * Hd + j) = hn;
   }
 }
 
@@ -466,9 +498,8 @@ hipError_t launch_lstm_step_tail(const float* pval, const int32_t* pidx, int nti
                                  const float* xg, const float* gates_pre, float* c, float* h, int n,
                                  const int32_t* n_dev, int Hd, int zero_c, int32_t* seq, int T, int t, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  if (Hd % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(lstm_step_tail_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pval, pidx, ntiles, ld, fixed_tok, xg,
-                     gates_pre, c, h, n, n_dev, Hd, zero_c, seq, T, t);
+  hipLaunchKernelGGL(lstm_step_tail_kernel, dim3(n), dim3(256), 0, s, pval, pidx, ntiles, ld, fixed_tok, xg, gates_pre,
+                     c, h, n, n_dev, Hd, zero_c, seq, T, t);
   return hipGetLastError();
 }
 hipError_t launch_splitk_reduce(const float* ws, int S, const float* bias, float* C, int M, int N, int ldc, int relu,
