@@ -175,20 +175,44 @@ def main():
 
     # ---- the path's single collective -------------------------------------------------------------------
     comm = None
+    gather_note = None
+
+    def all_ranks_ok(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=coll_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
     if dist is not None and gather_kind == "abi":
         from densecap_amd import dist as D
+        err = None
         idt = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            idt = torch.frombuffer(bytearray(D.Comm.unique_id(ctx.lib)), dtype=torch.uint8).clone()
+        try:
+            if rank == 0:
+                idt = torch.frombuffer(bytearray(D.Comm.unique_id(ctx.lib)), dtype=torch.uint8).clone()
+        except Exception as e:                               # e.g. librccl cannot be opened
+            err = e
         idt = idt.to(coll_device) if coll_device is not None else idt
         dist.broadcast(idt, src=0)                       # rendezvous id of the RCCL communicator, out of band
-        comm = D.Comm(ctx, rank, world, bytes(idt.cpu().numpy().tobytes()))
+        if all_ranks_ok(err is None):
+            try:
+                comm = D.Comm(ctx, rank, world, bytes(idt.cpu().numpy().tobytes()))
+            except Exception as e:
+                err = e
+        if not all_ranks_ok(comm is not None):
+            # The measurement must not be lost to the carrier: say so loudly and carry the same records over
+            # torch.distributed instead (the line's config.gather records which carrier ran and why).
+            if comm is not None:
+                comm.close()
+            comm = None
+            gather_note = "dc_gather_results unavailable (%s)" % (err if err is not None else "failed on another rank")
+            print("bench.py[rank %d]: WARNING: %s -- gathering with torch.distributed.gather instead" % (rank, gather_note),
+                  file=sys.stderr, flush=True)
 
     def gather(results):
         if dist is None:
             return [results]
         from densecap_amd import dist as D
-        if comm is not None:
+        if comm is not None:                 # (rebound to None below if the RCCL carrier turns out unusable)
             return comm.gather(results, P, model.seq_length)
         return D.gather_records(dist, results, P, model.seq_length, rank, world, device=coll_device)
 
@@ -210,7 +234,22 @@ def main():
     model.forward_batch_device(imgs, min(args.lanes, n_img), H, W)
     wres = model.forward_batch_device(imgs, max(Wm, 1), H, W)
     if dist is not None:
-        gather(([wres[0]] * K)[:K])      # communicator / buffer setup of the first collective is not part of a step
+        # communicator / buffer setup of the first collective is not part of a step; a carrier that fails here is replaced
+        warm = ([wres[0]] * K)[:K]
+        if comm is not None:
+            err = None
+            try:
+                gather(warm)
+            except Exception as e:
+                err = e
+            if not all_ranks_ok(err is None):
+                comm.close()
+                comm = None
+                gather_note = "dc_gather_results failed in the warm-up (%s)" % (err if err is not None else "on another rank")
+                print("bench.py[rank %d]: WARNING: %s -- gathering with torch.distributed.gather instead" % (rank, gather_note),
+                      file=sys.stderr, flush=True)
+        if comm is None:
+            gather(warm)
     sync()
     if on_gpu and args.lanes == 1:
         model.mfma_profile(reset=1)      # HIP events around every MFMA launch during the timed regions
@@ -290,7 +329,8 @@ def main():
                        "images_per_gpu": K, "parallelism": "image-sharded x%d" % world,
                        "total_output_boxes": total_boxes,
                        "gather": None if dist is None else ("dc_gather_results (RCCL send/recv)" if comm is not None
-                                                             else "torch.distributed.gather (%s)" % args.dist_backend)},
+                                                             else "torch.distributed.gather (%s)%s" % (
+                                                                 args.dist_backend, "; " + gather_note if gather_note else ""))},
             "repeats": {"n": nrep, "statistic": "median", "images_per_s": [world * K / e for e in elapsed_all]},
         }
         if on_gpu:
