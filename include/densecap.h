@@ -128,6 +128,15 @@ int dc_forward_batch(dc_ctx* ctx, const float* imgs, int n, int H, int W, int im
  * rows advance as two blocks on two streams (same arithmetic per row); per-kernel profiling (dc_mfma_profile)
  * keeps every kernel on one stream.  Results are bit-identical for a given lanes setting however images are batched. */
 int dc_set_lanes(dc_ctx* ctx, int lanes);
+/* Images per GROUP inside dc_forward_batch: with 2, the two images of a group share the launches of the dense stages
+ * (the convolutions run over both images, fc6/fc7 and the decode over both images' RoI rows: fuller tile rounds, half
+ * the launches per image) while the per-image stages (RPN decode, NMS, RoI pooling, final NMS) follow each other.
+ * 0 or 1 (default) = every image on its own.  Measured at 720x600 / 1000 proposals: on ONE lane pairs give 152.6 vs
+ * 146.0 images/s (at twice the per-image latency); with two or more lanes the lanes already fill each other's partial
+ * rounds and pairs change nothing (173 vs 175).  Every decision that changes a sum's order (kernel route, split-K
+ * factor) is planned per image, so an image's results do not depend on the group it travels in (bit-identical, like
+ * the lane count). */
+int dc_set_group(dc_ctx* ctx, int images);
 /* Caption order. 0 (default) = the reference's order: LanguageModel:sample runs on all num_proposals
  * RoIs and the final NMS then keeps K rows (DenseCapModel.lua:127-162,261-275).  1 = run the final NMS
  * first and decode only the K surviving rows: LSTM rows are independent, so boxes, scores and tokens

@@ -530,3 +530,28 @@ def test_webcam_daemon_with_the_hip_model(tmp_path):
         np.testing.assert_allclose(out["boxes"], D.scale_boxes_xywh(xcycwh_to_xywh(eb), 960.0 / 360.0), rtol=1e-6)
     finally:
         m.ctx.close()
+
+
+def test_image_groups_do_not_change_results(model, weights):
+    """dc_set_group: two images sharing the dense stages' launches (convolutions over both images, fc6/fc7 and the
+    decode over both images' RoI rows) must give each image exactly the results it gets alone -- the kernel route and the
+    split-K factor are planned per image.  Odd batch sizes leave a group of one at the end."""
+    from densecap_amd.weights import make_synthetic_image
+    try:
+        for (H, W, P, n) in [(224, 288, 100, 5), (600, 720, 1000, 3), (203, 301, 64, 4)]:
+            model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
+            imgs = np.stack([make_synthetic_image(H, W, 70 + s) for s in range(n)])
+            outs = {}
+            for group in (1, 2, 0):
+                model.setGroup(group)
+                outs[group] = model.forward_batch(imgs)
+            for i in range(n):
+                single = model.forward_raw(imgs[i])
+                for group in (1, 2, 0):
+                    for x, y in zip(outs[group][i], single):
+                        np.testing.assert_array_equal(x, y)
+                assert len(single[0]) > 0
+        with pytest.raises(Exception):
+            model.setGroup(3)
+    finally:
+        model.setGroup(0)
