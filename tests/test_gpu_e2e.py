@@ -551,7 +551,24 @@ def test_image_groups_do_not_change_results(model, weights):
                     for x, y in zip(outs[group][i], single):
                         np.testing.assert_array_equal(x, y)
                 assert len(single[0]) > 0
+        # random sizes / proposal counts / thresholds (odd sizes exercise the ceil-mode pool windows per image)
+        rng = np.random.default_rng(11)
+        for case in range(6):
+            H = int(rng.integers(40, 330)); W = int(rng.integers(40, 400))
+            P = int(rng.choice([1, 7, 50, 128, 300, -1]))
+            model.setTestArgs(rpn_nms_thresh=float(rng.choice([0.3, 0.7])), final_nms_thresh=float(rng.choice([0.0, 0.3, 0.5])),
+                              num_proposals=P)
+            model.setCaptionOrder(bool(case % 2))
+            imgs = np.stack([make_synthetic_image(H, W, 900 + 3 * case + s) for s in range(3)])
+            model.setGroup(2)
+            pair = model.forward_batch(imgs)
+            model.setGroup(1)
+            for i in range(3):
+                for x, y in zip(pair[i], model.forward_raw(imgs[i])):
+                    np.testing.assert_array_equal(x, y, err_msg="case %d (%dx%d, P=%d) image %d" % (case, W, H, P, i))
         with pytest.raises(Exception):
             model.setGroup(3)
     finally:
         model.setGroup(0)
+        model.setCaptionOrder(False)
+        model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=100)
