@@ -229,38 +229,44 @@ __global__ __launch_bounds__(256) void nms_hist_kernel(const float* __restrict__
   if (my_cnt) atomicAdd(&hist[b], my_cnt);
 }
 
-// exclusive scan of the histogram: 1024 threads x (NMS_BUCKETS/1024) bins; the 1024 per-thread sums are scanned with
-// wave shuffles (6 steps) + one pass over the 16 wave totals -- two barriers instead of twenty (19 -> 5 us)
+// exclusive scan of the histogram by one workgroup of 16 waves: wave w owns the contiguous bins [w*C, (w+1)*C),
+// C = NMS_BUCKETS/16, and walks them in coalesced 1 KiB rows (lane l takes bins 4l..4l+3 of a row); a row is scanned with
+// wave shuffles, rows chain through a running base; the 16 wave totals meet in LDS.  (One thread per 64 consecutive bins
+// made every load touch 64 cache lines: 19 us for 512 KiB of traffic.)
 __global__ __launch_bounds__(1024) void nms_bucket_scan_kernel(const int32_t* __restrict__ hist,
                                                                 int32_t* __restrict__ off) {
-  constexpr int PER = NMS_BUCKETS / 1024;
+  constexpr int C = NMS_BUCKETS / 16, ROWS = C / 256;
   __shared__ int wtot[16];
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   typedef int i32x4 __attribute__((ext_vector_type(4)));
-  i32x4 loc[PER / 4];
-  int sum = 0;
+  const int32_t* src = hist + wid * C;
+  i32x4 v[ROWS];
+  int excl[ROWS];                                    // exclusive prefix of this lane's 4 bins inside the wave's chunk
+  int run = 0;
 #pragma unroll
-  for (int q = 0; q < PER / 4; ++q) {
-    loc[q] = *reinterpret_cast<const i32x4*>(hist + t * PER + q * 4);
-    sum += loc[q][0] + loc[q][1] + loc[q][2] + loc[q][3];
-  }
-  int incl = sum;                                     // inclusive scan inside the wave
+  for (int rw = 0; rw < ROWS; ++rw) {
+    v[rw] = *reinterpret_cast<const i32x4*>(src + rw * 256 + lane * 4);
+    const int s4 = v[rw][0] + v[rw][1] + v[rw][2] + v[rw][3];
+    int incl = s4;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    excl[rw] = run + incl - s4;
+    run += __shfl(incl, 63, 64);
   }
-  if (lane == 63) wtot[wid] = incl;
+  if (lane == 0) wtot[wid] = run;
   __syncthreads();
   int base = 0;
   for (int w = 0; w < wid; ++w) base += wtot[w];
-  int run = base + incl - sum;
 #pragma unroll
-  for (int q = 0; q < PER / 4; ++q) {
+  for (int rw = 0; rw < ROWS; ++rw) {
     i32x4 o4;
+    int r = base + excl[rw];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { o4[e] = run; run += loc[q][e]; }
-    *reinterpret_cast<i32x4*>(off + t * PER + q * 4) = o4;
+    for (int e = 0; e < 4; ++e) { o4[e] = r; r += v[rw][e]; }
+    *reinterpret_cast<i32x4*>(off + wid * C + rw * 256 + lane * 4) = o4;
   }
 }
 
