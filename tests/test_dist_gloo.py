@@ -99,3 +99,24 @@ def test_bench_world2_branch_runs_under_gloo_with_stub_model():
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["data"] == "stub"
     assert d["config"]["total_output_boxes"] > 0 and len(d["repeats"]["images_per_s"]) == 3
     assert abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_line_contract_single_process_stub():
+    """The one JSON line bench.py prints carries every key of the driver's contract (checked without a GPU through the
+    --stub model; the roofline / cpu_baseline objects need the device and are checked in tests/test_gpu_dist.py)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--stub", "--steps", "3", "--warmup", "1",
+                        "--repeats", "2"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "images/s" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]

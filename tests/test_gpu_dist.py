@@ -89,6 +89,25 @@ def test_bench_world2_branch_on_one_gpu():
     assert "roofline" in d and d["roofline"]["frac"] > 0
 
 
+def test_bench_line_has_roofline_and_cpu_baseline():
+    """Default single-GPU invocation shape (small workload so the CPU leg is quick): the contract's `roofline` and
+    `cpu_baseline` objects, the per-stage fractions and the repeats are all in the one line."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--repeats", "2",
+                        "--height", "224", "--width", "288", "--proposals", "100"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "trunk_frac", "fc_frac", "decode_frac",
+              "serial_ms_per_image", "measured_on", "traffic_from_profile"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "images/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    assert d["n_gpus"] == 1 and len(d["repeats"]["images_per_s"]) == 2 and d["value"] > c["value"]
+
+
 @pytest.mark.skipif("_ngpus() < 2")
 def test_bench_world2_rccl_gather():
     """Two GPUs visible: the default carrier -- dc_gather_results over RCCL send/recv."""
