@@ -95,7 +95,13 @@ function Model.fromCheckpoint(ref, gpu)
   self.num_anchors = make_anchors.anchors:size(2)
   self.idx_to_token = lm.idx_to_token
   -- keep the reference's field layout for callers that reach into it
-  self.nets = {language_model = {decodeSequence = function(_, seq) return self:decodeSequence(seq) end}}
+  -- `model.nets.language_model.beam_size = n` (LanguageModel.lua:129-131) keeps working: the assignment reaches the library
+  local lm_proxy = setmetatable({decodeSequence = function(_, seq) return self:decodeSequence(seq) end}, {
+    __newindex = function(t, k, v)
+      if k == 'beam_size' then self:setBeamSize(v) end
+      rawset(t, k, v)
+    end})
+  self.nets = {language_model = lm_proxy}
   self:setTestArgs{}
   return self
 end
@@ -112,6 +118,10 @@ function Model:_capacity(H, W)
   if P ~= -1 then return P end
   for _ = 1, 4 do H, W = math.floor((H + 1) / 2), math.floor((W + 1) / 2) end
   return math.min(self.num_anchors * H * W, 65536)
+end
+-- language_model.beam_size: nil / 0 = greedy LM:sample, n = LM:beamsearch with n beams (1..32)
+function Model:setBeamSize(n)
+  hip.check(self.ctx, C.dc_set_beam_size(self.ctx, n or 0), 'dc_set_beam_size')
 end
 function Model:convert(dtype, use_cudnn) return self end
 function Model:evaluate() return self end
