@@ -96,10 +96,16 @@ function Model.fromCheckpoint(ref, gpu)
   self.idx_to_token = lm.idx_to_token
   -- keep the reference's field layout for callers that reach into it
   -- `model.nets.language_model.beam_size = n` (LanguageModel.lua:129-131) keeps working: the assignment reaches the library
+  local lm_state = {}           -- beam_size lives here so that EVERY assignment goes through __newindex
   local lm_proxy = setmetatable({decodeSequence = function(_, seq) return self:decodeSequence(seq) end}, {
+    __index = lm_state,
     __newindex = function(t, k, v)
-      if k == 'beam_size' then self:setBeamSize(v) end
-      rawset(t, k, v)
+      if k == 'beam_size' then
+        self:setBeamSize(v)
+        lm_state.beam_size = v
+      else
+        rawset(t, k, v)
+      end
     end})
   self.nets = {language_model = lm_proxy}
   self:setTestArgs{}
