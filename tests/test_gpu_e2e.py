@@ -433,7 +433,6 @@ def test_beamsearch_teacher_forced(beam):
         bad = np.nonzero((seq != oseq).any(axis=1))[0]
         for r in bad:
             assert margins[r] < 1e-4, "row %d differs (hip %s oracle %s) with oracle margin %g" % (r, seq[r], oseq[r], margins[r])
-        assert len(bad) <= 2
         assert seq.min() >= 1 and seq.max() <= 301
         if beam == 1:
             m.setBeamSize(0)
