@@ -571,3 +571,45 @@ def test_image_groups_do_not_change_results(model, weights):
         model.setGroup(0)
         model.setCaptionOrder(False)
         model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=100)
+
+
+def test_abi_edge_cases_report_errors_and_truncate(model, weights):
+    """C-ABI behaviour at the edges (include/densecap.h): a result capacity below K truncates to the best `capacity` rows,
+    bad arguments come back as DC_E_* codes with a message, nothing aborts."""
+    import ctypes as C
+    from densecap_amd import _lib
+    from densecap_amd._lib import DcResult, DenseCapError
+    from densecap_amd.weights import make_synthetic_image
+    lib, h = model.lib, model.ctx.h
+    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=100)
+    img = make_synthetic_image(224, 288, 3)
+    full = model.forward_raw(img)
+    K = len(full[0])
+    assert K > 5
+    cap = 5
+    b = np.zeros((cap, 4), np.float32); s_ = np.zeros(cap, np.float32); t = np.zeros((cap, 15), np.int32)
+    r = DcResult(); r.capacity = cap
+    r.boxes = b.ctypes.data_as(_lib.c_float_p); r.scores = s_.ctypes.data_as(_lib.c_float_p); r.tokens = t.ctypes.data_as(_lib.c_int32_p)
+    assert lib.dc_forward_test(h, img.ctypes.data, 224, 288, 0, C.byref(r)) == 0
+    assert r.K == cap and r.T == 15
+    np.testing.assert_array_equal(b, full[0][:cap]); np.testing.assert_array_equal(t, full[2][:cap])
+    # NULL output pointers are allowed (only K comes back)
+    r2 = DcResult(); r2.capacity = 100
+    assert lib.dc_forward_test(h, img.ctypes.data, 224, 288, 0, C.byref(r2)) == 0 and r2.K == K
+    # bad arguments
+    r3 = DcResult(); r3.capacity = 0
+    assert lib.dc_forward_test(h, img.ctypes.data, 224, 288, 0, C.byref(r3)) == -1          # DC_E_INVALID
+    assert b"capacity" in lib.dc_last_error(h)
+    assert lib.dc_forward_test(h, img.ctypes.data, 16, 16, 0, C.byref(r2)) == -1             # below 32 px
+    assert lib.dc_forward_test(h, None, 224, 288, 0, C.byref(r2)) == -1
+    assert lib.dc_set_lanes(h, 0) == -1 and lib.dc_set_lanes(h, 5) == -1
+    assert lib.dc_set_beam_size(h, -1) == -5 and lib.dc_set_group(h, 7) == -1                # DC_E_UNSUPPORTED / DC_E_INVALID
+    assert lib.dc_debug_fetch(h, b"no_such_tensor", b.ctypes.data, b.nbytes) < 0
+    # an image too large for the NMS mask (k * ceil(H/16) * ceil(W/16) > 65536 anchors) is refused, not mangled
+    big = np.zeros((3, 1300, 1300), np.float32)
+    assert lib.dc_forward_test(h, big.ctypes.data, 1300, 1300, 0, C.byref(r2)) == -5
+    assert b"65536" in lib.dc_last_error(h)
+    # and the context still works afterwards
+    again = model.forward_raw(img)
+    for x, y in zip(again, full):
+        np.testing.assert_array_equal(x, y)
