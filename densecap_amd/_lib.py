@@ -49,6 +49,8 @@ _SIGS = {
     "dc_set_group": (C.c_int, [C.c_void_p, C.c_int]),
     "dc_forward_test": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DcResult)]),
     "dc_forward_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DcResult)]),
+    "dc_forward_images": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
+                                    C.c_int, C.POINTER(DcResult)]),
     "dc_extract_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, c_int32_p]),
     "dc_stage_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), c_float_p, C.c_int]),

@@ -1008,6 +1008,30 @@ static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, i
   return DC_OK;
 }
 
+int dc_forward_images(dc_ctx* ctx, const float* const* imgs, const int* H, const int* W, int n, int on_dev, dc_result* outs) {
+  if (!ctx) return DC_E_INVALID;
+  if (!ctx->have_weights) return ctx->fail(DC_E_STATE, "dc_forward_images: weights not loaded");
+  if (!imgs || !H || !W || !outs || n <= 0) return ctx->fail(DC_E_INVALID, "dc_forward_images: bad arguments");
+  for (int i = 0; i < n; ++i) {
+    if (!imgs[i] || H[i] < 32 || W[i] < 32 || outs[i].capacity <= 0)
+      return ctx->fail(DC_E_INVALID, "dc_forward_images: image %d: null pointer, side below 32 px or capacity <= 0", i);
+    DCCHK(check_anchor_count(ctx, H[i], W[i], "dc_forward_images"));
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  const int nl = std::min(n, ctx->max_lanes);
+  while ((int)ctx->lanes.size() < nl) ctx->lanes.emplace_back(new Lane());
+  for (int i = 0; i < n; ++i) {
+    Lane& L = *ctx->lanes[i % nl];
+    DCCHK_DRAIN(harvest(ctx, L));                 // the lane's previous image leaves before its workspace is re-carved
+    DCCHK_DRAIN(lane_prepare(ctx, L, H[i], W[i], effective_proposals(ctx, H[i], W[i]), 1));
+    L.pending = &outs[i];
+    DCCHK_DRAIN(enqueue_forward(ctx, L, imgs[i], 1, on_dev, false));
+  }
+  for (int l = 0; l < nl; ++l) DCCHK_DRAIN(harvest(ctx, *ctx->lanes[l]));
+  prof_collect(ctx);
+  return DC_OK;
+}
+
 int dc_forward_test(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_device, dc_result* out) {
   return forward_common(ctx, img_chw, 1, H, W, img_on_device, out);
 }

@@ -217,6 +217,25 @@ class DenseCapModel:
         check(self.ctx.h, self.lib.dc_forward_batch(self.ctx.h, imgs.ctypes.data, n, H, W, 0, arr), "dc_forward_batch")
         return [(b[:arr[i].K].copy(), s[:arr[i].K].copy(), t[:arr[i].K].copy()) for i, (b, s, t) in enumerate(keep)]
 
+    def forward_images(self, imgs):
+        """run_model.lua's loop over a list of images of DIFFERENT sizes, pipelined over the lanes (dc_forward_images);
+        imgs: sequence of (3,H,W) / (1,3,H,W) arrays.  Returns a list of (boxes, scores, tokens)."""
+        arrs = [self._check_input(im) for im in imgs]
+        n = len(arrs)
+        if n == 0:
+            return []
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        Hs = (C.c_int * n)(*[a.shape[1] for a in arrs])
+        Ws = (C.c_int * n)(*[a.shape[2] for a in arrs])
+        res = (DcResult * n)()
+        keep = []
+        for i, a in enumerate(arrs):
+            r, b, s, t = self._new_result(self._capacity(a.shape[1], a.shape[2]))
+            res[i] = r
+            keep.append((b, s, t))
+        check(self.ctx.h, self.lib.dc_forward_images(self.ctx.h, ptrs, Hs, Ws, n, 0, res), "dc_forward_images")
+        return [(b[:res[i].K].copy(), s[:res[i].K].copy(), t[:res[i].K].copy()) for i, (b, s, t) in enumerate(keep)]
+
     def extractFeatures(self, img):
         """DenseCapModel:extractFeatures -> (boxes_xcycwh (K,4), feats (K,fc_dim))."""
         img = self._check_input(img)

@@ -39,6 +39,7 @@ def build_parser():
     a("-output_vis", type=int, default=1)
     a("-output_vis_dir", default="vis/data")
     a("-gpu", type=int, default=0)
+    a("-lanes", type=int, default=2, help="images in flight when a directory is processed (not a reference flag)")
     a("-synthetic_weights", type=int, default=0,
       help="1: random weights in checkpoint shapes (no pretrained .t7 is available offline)")
     return p
@@ -159,25 +160,31 @@ def main(argv=None):
             raise SystemExit("checkpoint %s not found (use -synthetic_weights 1 for random weights)" % opt.checkpoint)
         weights = t7.weights_from_checkpoint(t7.load(opt.checkpoint))
     model = DenseCapModel(weights, device=opt.gpu)                      # utils.setup_gpus + model:convert
-    model.setLanes(1)      # one image at a time, like the reference: single-image mode has the lowest latency
+    paths = get_input_images(opt)
+    num = min(len(paths), opt.max_images)
+    # one image: single-image mode (lowest latency, like the reference); a directory: its images -- whatever their
+    # sizes -- are pipelined over the lanes in chunks (dc_forward_images), results identical to one-by-one processing
+    model.setLanes(1 if num == 1 else opt.lanes)
     model.setTestArgs(rpn_nms_thresh=opt.rpn_nms_thresh, final_nms_thresh=opt.final_nms_thresh,
                       num_proposals=opt.num_proposals)
     model.evaluate()
-    paths = get_input_images(opt)
-    num = min(len(paths), opt.max_images)
     results = []
-    for k in range(num):
-        path = paths[k]
-        print("%d/%d processing image %s" % (k + 1, num, path))
-        img_caffe, rgb = load_image_caffe(path, opt.image_size)
-        boxes, scores, captions = model.forward_test(img_caffe)
-        rj = result_to_json(xcycwh_to_xywh(boxes), scores, captions)
-        if opt.output_vis == 1:
-            os.makedirs(opt.output_vis_dir, exist_ok=True)
-            from PIL import Image
-            Image.fromarray(rgb).save(os.path.join(opt.output_vis_dir, os.path.basename(path)))
-            rj["img_name"] = os.path.basename(path)
-            results.append(rj)
+    CHUNK = 16
+    for k0 in range(0, num, CHUNK):
+        chunk = paths[k0:min(k0 + CHUNK, num)]
+        pre = []
+        for j, path in enumerate(chunk):
+            print("%d/%d processing image %s" % (k0 + j + 1, num, path))
+            pre.append(load_image_caffe(path, opt.image_size))
+        outs = model.forward_images([p[0] for p in pre])
+        for path, (img_caffe, rgb), (boxes, scores, tokens) in zip(chunk, pre, outs):
+            rj = result_to_json(xcycwh_to_xywh(boxes), scores, model.decodeSequence(tokens))
+            if opt.output_vis == 1:
+                os.makedirs(opt.output_vis_dir, exist_ok=True)
+                from PIL import Image
+                Image.fromarray(rgb).save(os.path.join(opt.output_vis_dir, os.path.basename(path)))
+                rj["img_name"] = os.path.basename(path)
+                results.append(rj)
     if results:
         out = dict(results=results, opt={k: v for k, v in vars(opt).items()})
         with open(os.path.join(opt.output_vis_dir, "results.json"), "w") as f:

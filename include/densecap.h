@@ -122,6 +122,11 @@ int dc_forward_test(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_
  * back to back; images are software-pipelined over the ctx's lanes (streams). */
 int dc_forward_batch(dc_ctx* ctx, const float* imgs, int n, int H, int W, int imgs_on_device,
                      dc_result* outs);
+/* The same loop over images of DIFFERENT sizes (a directory of photographs: run_model.lua -input_dir): imgs[i] is
+ * image i, (3, H[i], W[i]); images are pipelined over the lanes exactly like dc_forward_batch, each lane's workspace
+ * growing to the largest size it meets.  Results are those of dc_forward_test on each image. */
+int dc_forward_images(dc_ctx* ctx, const float* const* imgs, const int* H, const int* W, int n, int imgs_on_device,
+                      dc_result* outs);
 /* Number of lanes (HIP streams with private workspaces, 1..4, default 3) dc_forward_batch
  * pipelines images over.  1 = single-image mode (lowest latency for one image at a time): a layer's last
  * partial round of tiles is K-split over the idle CUs (a different but fixed fp32 summation order) and the decode

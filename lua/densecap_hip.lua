@@ -40,6 +40,8 @@ int dc_set_beam_size(dc_ctx* ctx, int beam_size);
 int dc_set_group(dc_ctx* ctx, int images);
 int dc_forward_test(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_device, dc_result* out);
 int dc_forward_batch(dc_ctx* ctx, const float* imgs, int n, int H, int W, int imgs_on_device, dc_result* outs);
+int dc_forward_images(dc_ctx* ctx, const float* const* imgs, const int* H, const int* W, int n, int imgs_on_device,
+                      dc_result* outs);
 int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_device,
                         int capacity, float* boxes, float* feats, int32_t* K);
 int dc_stage_times(dc_ctx* ctx, const char** names, float* ms, int max_stages);

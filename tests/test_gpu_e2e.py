@@ -613,3 +613,33 @@ def test_abi_edge_cases_report_errors_and_truncate(model, weights):
     again = model.forward_raw(img)
     for x, y in zip(again, full):
         np.testing.assert_array_equal(x, y)
+
+
+def test_forward_images_of_mixed_sizes_equals_one_by_one(model, weights, tmp_path):
+    """dc_forward_images (run_model.lua -input_dir over photographs of different sizes): pipelined over the lanes, every
+    image's result is bit for bit what dc_forward_test gives it; then the run_model CLI over such a directory."""
+    import json
+    from PIL import Image
+    from densecap_amd import run_model as R
+    from densecap_amd.weights import make_synthetic_image
+    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=80)
+    sizes = [(240, 360), (360, 240), (203, 301), (240, 360), (96, 128), (330, 330), (360, 240)]
+    imgs = [make_synthetic_image(H, W, 300 + i) for i, (H, W) in enumerate(sizes)]
+    outs = model.forward_images(imgs)
+    assert len(outs) == len(imgs)
+    for img, out in zip(imgs, outs):
+        for x, y in zip(out, model.forward_raw(img)):
+            np.testing.assert_array_equal(x, y)
+    assert model.forward_images([]) == []
+    rng = np.random.default_rng(8)
+    d = tmp_path / "photos"
+    d.mkdir()
+    for i, (H, W) in enumerate([(240, 360), (360, 240), (300, 300)]):
+        Image.fromarray(rng.uniform(0, 255, (H, W, 3)).astype(np.uint8)).save(d / ("p%d.png" % i))
+    out_dir = tmp_path / "vis"
+    rc = R.main(["-input_dir", str(d), "-synthetic_weights", "1", "-num_proposals", "40", "-image_size", "360",
+                 "-output_vis_dir", str(out_dir), "-gpu", "0"])
+    assert rc == 0
+    res = json.load(open(out_dir / "results.json"))["results"]
+    assert [r["img_name"] for r in res] == ["p0.png", "p1.png", "p2.png"]
+    assert all(len(r["boxes"]) == len(r["captions"]) > 0 for r in res)
