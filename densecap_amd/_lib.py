@@ -53,6 +53,8 @@ _SIGS = {
                                     C.c_int, C.POINTER(DcResult)]),
     "dc_extract_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, c_int32_p]),
+    "dc_extract_features_images": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                             C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, c_int32_p]),
     "dc_stage_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), c_float_p, C.c_int]),
     "dc_mfma_profile": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double)]),

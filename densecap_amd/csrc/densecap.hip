@@ -1057,6 +1057,36 @@ int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img
   return DC_OK;
 }
 
+int dc_extract_features_images(dc_ctx* ctx, const float* const* imgs, const int* H, const int* W, int n, int on_dev,
+                               int capacity, float* boxes, float* feats, int32_t* K) {
+  if (!ctx) return DC_E_INVALID;
+  if (!ctx->have_weights) return ctx->fail(DC_E_STATE, "dc_extract_features_images: weights not loaded");
+  if (!imgs || !H || !W || n <= 0 || capacity <= 0 || !boxes || !feats || !K)
+    return ctx->fail(DC_E_INVALID, "dc_extract_features_images: bad arguments");
+  for (int i = 0; i < n; ++i) {
+    if (!imgs[i] || H[i] < 32 || W[i] < 32)
+      return ctx->fail(DC_E_INVALID, "dc_extract_features_images: image %d: null pointer or side below 32 px", i);
+    DCCHK(check_anchor_count(ctx, H[i], W[i], "dc_extract_features_images"));
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  const int nl = std::min(n, ctx->max_lanes);
+  while ((int)ctx->lanes.size() < nl) ctx->lanes.emplace_back(new Lane());
+  for (int i = 0; i < n; ++i) {
+    Lane& L = *ctx->lanes[i % nl];
+    DCCHK_DRAIN(harvest(ctx, L));
+    DCCHK_DRAIN(lane_prepare(ctx, L, H[i], W[i], effective_proposals(ctx, H[i], W[i]), 1));
+    L.pending = nullptr;
+    L.pending_capacity = capacity;
+    L.pending_box_dst = boxes + (size_t)i * capacity * 4;
+    L.pending_feat_dst = feats + (size_t)i * capacity * ctx->D;
+    L.pending_k_dst = K + i;
+    DCCHK_DRAIN(enqueue_forward(ctx, L, imgs[i], 1, on_dev, true));
+  }
+  for (int l = 0; l < nl; ++l) DCCHK_DRAIN(harvest(ctx, *ctx->lanes[l]));
+  prof_collect(ctx);
+  return DC_OK;
+}
+
 int dc_stage_times(dc_ctx* ctx, const char** names, float* ms, int max_stages) {
   if (!ctx) return DC_E_INVALID;
   if (ctx->lanes.empty() || !ctx->lanes[0]->have_times) return 0;

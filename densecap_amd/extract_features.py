@@ -67,24 +67,29 @@ def main(argv=None):
             raise SystemExit("checkpoint %s not found (use -synthetic_weights 1 for random weights)" % opt.checkpoint)
         weights = t7.weights_from_checkpoint(t7.load(opt.checkpoint))
     model = DenseCapModel(weights, device=opt.gpu)
-    model.setLanes(1)      # one image at a time, like the reference: single-image mode has the lowest latency
+    model.setLanes(1 if len(paths) == 1 else 2)      # a list of images is pipelined over two streams (same results per image)
     model.setTestArgs(rpn_nms_thresh=opt.rpn_nms_thresh, final_nms_thresh=opt.final_nms_thresh,
                       num_proposals=opt.num_proposals)
     model.evaluate()
     N, M = len(paths), opt.boxes_per_image
     all_boxes = np.zeros((N, M, 4), np.float32)
     all_feats = None
-    for i, path in enumerate(paths):
-        print("Processing image %d / %d" % (i + 1, N))
-        img_caffe, _ = load_image_caffe(path, opt.image_size)
-        boxes_xcycwh, feats = model.extractFeatures(img_caffe)
-        if len(boxes_xcycwh) < M:     # the reference's boxes[{{1, M}}] raises on a short result as well
-            raise SystemExit("image %s: only %d boxes survive the final NMS, -boxes_per_image is %d"
-                             % (path, len(boxes_xcycwh), M))
-        if all_feats is None:
-            all_feats = np.zeros((N, M, feats.shape[1]), np.float32)
-        all_boxes[i] = xcycwh_to_xywh(boxes_xcycwh)[:M]
-        all_feats[i] = feats[:M]
+    CHUNK = 16
+    for k0 in range(0, N, CHUNK):
+        chunk = paths[k0:k0 + CHUNK]
+        pre = []
+        for j, path in enumerate(chunk):
+            print("Processing image %d / %d" % (k0 + j + 1, N))
+            pre.append(load_image_caffe(path, opt.image_size)[0])
+        for j, (boxes_xcycwh, feats) in enumerate(model.extractFeatures_images(pre)):
+            i = k0 + j
+            if len(boxes_xcycwh) < M:     # the reference's boxes[{{1, M}}] raises on a short result as well
+                raise SystemExit("image %s: only %d boxes survive the final NMS, -boxes_per_image is %d"
+                                 % (chunk[j], len(boxes_xcycwh), M))
+            if all_feats is None:
+                all_feats = np.zeros((N, M, feats.shape[1]), np.float32)
+            all_boxes[i] = xcycwh_to_xywh(boxes_xcycwh)[:M]
+            all_feats[i] = feats[:M]
     if all_feats is None:
         all_feats = np.zeros((0, M, 4096), np.float32)
     write_datasets(opt.output_h5, all_feats, all_boxes)

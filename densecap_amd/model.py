@@ -247,6 +247,23 @@ class DenseCapModel:
               "dc_extract_features")
         return boxes[:K.value].copy(), feats[:K.value].copy()
 
+    def extractFeatures_images(self, imgs):
+        """extract_features.lua's loop over images (any sizes), pipelined over the lanes: list of (boxes, feats)."""
+        arrs = [self._check_input(im) for im in imgs]
+        n = len(arrs)
+        if n == 0:
+            return []
+        cap = max(self._capacity(a.shape[1], a.shape[2]) for a in arrs)
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        Hs = (C.c_int * n)(*[a.shape[1] for a in arrs])
+        Ws = (C.c_int * n)(*[a.shape[2] for a in arrs])
+        boxes = np.zeros((n, cap, 4), np.float32); feats = np.zeros((n, cap, self.fc_dim), np.float32)
+        K = np.zeros((n,), np.int32)
+        check(self.ctx.h, self.lib.dc_extract_features_images(self.ctx.h, ptrs, Hs, Ws, n, 0, cap, boxes.ctypes.data,
+                                                              feats.ctypes.data, K.ctypes.data_as(_lib.c_int32_p)),
+              "dc_extract_features_images")
+        return [(boxes[i, :K[i]].copy(), feats[i, :K[i]].copy()) for i in range(n)]
+
     def decodeSequence(self, seq):
         """LanguageModel:decodeSequence (LanguageModel.lua:86-103)."""
         return decode_sequence(seq, self.idx_to_token, self.vocab_size)

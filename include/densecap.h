@@ -156,6 +156,11 @@ int dc_set_beam_size(dc_ctx* ctx, int beam_size);
 int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_device,
                         int capacity, float* boxes, float* feats, int32_t* K);
 
+/* extract_features.lua's loop (extract_features.lua:79-91) over n images of possibly different sizes, pipelined over
+ * the lanes like dc_forward_images: image i writes K[i] rows to boxes + i*capacity*4 and feats + i*capacity*fc_dim. */
+int dc_extract_features_images(dc_ctx* ctx, const float* const* imgs, const int* H, const int* W, int n,
+                               int imgs_on_device, int capacity, float* boxes, float* feats, int32_t* K);
+
 /* Per-stage GPU time of the most recent dc_forward_test on this ctx, measured with
  * HIP events on the ctx's stream (replaces LocalizationLayer:timeit,
  * LocalizationLayer.lua:219-230).  names[i] are static strings.  Returns the

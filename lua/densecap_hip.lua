@@ -44,6 +44,8 @@ int dc_forward_images(dc_ctx* ctx, const float* const* imgs, const int* H, const
                       dc_result* outs);
 int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img_on_device,
                         int capacity, float* boxes, float* feats, int32_t* K);
+int dc_extract_features_images(dc_ctx* ctx, const float* const* imgs, const int* H, const int* W, int n,
+                               int imgs_on_device, int capacity, float* boxes, float* feats, int32_t* K);
 int dc_stage_times(dc_ctx* ctx, const char** names, float* ms, int max_stages);
 typedef struct dc_comm dc_comm;
 int dc_comm_unique_id(void* id_out);

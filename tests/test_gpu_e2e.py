@@ -631,6 +631,11 @@ def test_forward_images_of_mixed_sizes_equals_one_by_one(model, weights, tmp_pat
         for x, y in zip(out, model.forward_raw(img)):
             np.testing.assert_array_equal(x, y)
     assert model.forward_images([]) == []
+    # the same for extractFeatures (extract_features.lua's loop)
+    feats = model.extractFeatures_images(imgs[:4])
+    for img, (fb, ff) in zip(imgs[:4], feats):
+        sb, sf = model.extractFeatures(img)
+        np.testing.assert_array_equal(fb, sb); np.testing.assert_array_equal(ff, sf)
     rng = np.random.default_rng(8)
     d = tmp_path / "photos"
     d.mkdir()
