@@ -167,11 +167,20 @@ __global__ void beam_best_kernel(const int32_t* __restrict__ beams, int nprop, i
 
 }  // namespace
 
+// The top-k kernel keeps one vocabulary row in dynamic LDS: V+1 floats must fit what the CURRENT device grants a
+// workgroup (160 KiB on gfx950; the static reduction scratch of the kernel takes a few hundred bytes of it).
+size_t beam_topk_max_vocab() {
+  int dev = 0, lds = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return 0;
+  return lds > 1024 ? (size_t)(lds - 1024) / sizeof(float) : 0;
+}
+
 hipError_t launch_beam_logsoftmax_topk(const float* logits, int rows, int V1, int ld, const uint8_t* finished, int k,
                                        float* top_lp, int32_t* top_idx, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
   const size_t lds = (size_t)V1 * sizeof(float);
-  if (lds > 150 * 1024 || k < 1 || k > V1) return hipErrorInvalidValue;
+  if ((size_t)V1 > beam_topk_max_vocab() || k < 1 || k > V1) return hipErrorInvalidValue;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&beam_logsoftmax_topk_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -13,6 +13,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
 #include <mutex>
 
 #include "common.h"
@@ -61,17 +65,133 @@ RcclApi* rccl() {
 
 thread_local std::string g_comm_error;
 
+// ---- transports -------------------------------------------------------------------------------------------------------
+// dc_gather_results is written against this four-call point-to-point interface (the grouped send/recv subset of RCCL).
+// Two carriers implement it: RCCL itself, and an in-process LOOPBACK hub used by the unit tests to drive the whole
+// gather -- shape handshake, per-peer offsets, device staging -- at world > 1 on a single GPU (RCCL refuses two ranks
+// on one device).  A loopback communicator is made by handing dc_comm_create an id that starts with "dc-loopback:"
+// (the rest of the 128 bytes names the hub); its ranks are threads of one process.
+struct Transport {
+  virtual ~Transport() {}
+  virtual const char* name() const = 0;
+  virtual int group_start(std::string& err) = 0;
+  virtual int send(const void* dev, size_t bytes, int peer, hipStream_t s, std::string& err) = 0;
+  virtual int recv(void* dev, size_t bytes, int peer, hipStream_t s, std::string& err) = 0;
+  virtual int group_end(hipStream_t s, std::string& err) = 0;    // returns with the group's traffic enqueued on s
+};
+
+struct RcclTransport : Transport {
+  ncclComm_t comm = nullptr;
+  ~RcclTransport() override { if (comm) rccl()->CommDestroy(comm); }
+  const char* name() const override { return "rccl"; }
+  int chk(ncclResult_t e, const char* what, std::string& err) {
+    if (e == ncclSuccess) return DC_OK;
+    err = std::string(what) + ": " + rccl()->GetErrorString(e);
+    return DC_E_HIP;
+  }
+  int group_start(std::string& err) override { return chk(rccl()->GroupStart(), "ncclGroupStart", err); }
+  int send(const void* dev, size_t bytes, int peer, hipStream_t s, std::string& err) override {
+    return chk(rccl()->Send(dev, bytes, ncclInt8, peer, comm, s), "ncclSend", err);
+  }
+  int recv(void* dev, size_t bytes, int peer, hipStream_t s, std::string& err) override {
+    return chk(rccl()->Recv(dev, bytes, ncclInt8, peer, comm, s), "ncclRecv", err);
+  }
+  int group_end(hipStream_t, std::string& err) override { return chk(rccl()->GroupEnd(), "ncclGroupEnd", err); }
+};
+
+// In-process hub: one mailbox per (src, dst) pair, filled by send (device -> host copy), drained by the matching recv
+// at group_end (host -> device copy).  Messages between a pair keep their order, like RCCL's.
+struct LoopHub {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::map<std::pair<int, int>, std::deque<std::vector<char>>> box;
+  int refs = 0;
+};
+std::mutex g_hub_mu;
+std::map<std::string, LoopHub*> g_hubs;
+
+struct LoopbackTransport : Transport {
+  std::string key;
+  LoopHub* hub = nullptr;
+  int rank = 0;
+  struct Pending { void* dev; size_t bytes; int peer; };
+  std::vector<Pending> recvs;
+  std::vector<std::vector<char>> landed;     // host copies stay alive until the stream has consumed them
+  LoopbackTransport(const std::string& k, int r) : key(k), rank(r) {
+    std::lock_guard<std::mutex> l(g_hub_mu);
+    LoopHub*& h = g_hubs[key];
+    if (!h) h = new LoopHub();
+    h->refs += 1;
+    hub = h;
+  }
+  ~LoopbackTransport() override {
+    std::lock_guard<std::mutex> l(g_hub_mu);
+    if (--hub->refs == 0) { g_hubs.erase(key); delete hub; }
+  }
+  const char* name() const override { return "loopback"; }
+  int group_start(std::string&) override { recvs.clear(); return DC_OK; }
+  int send(const void* dev, size_t bytes, int peer, hipStream_t s, std::string& err) override {
+    std::vector<char> msg(bytes);
+    hipError_t e = hipStreamSynchronize(s);              // the payload was staged on this stream
+    if (e == hipSuccess) e = hipMemcpy(msg.data(), dev, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { err = std::string("loopback send: ") + hipGetErrorString(e); return DC_E_HIP; }
+    {
+      std::lock_guard<std::mutex> l(hub->mu);
+      hub->box[{rank, peer}].push_back(std::move(msg));
+    }
+    hub->cv.notify_all();
+    return DC_OK;
+  }
+  int recv(void* dev, size_t bytes, int peer, hipStream_t, std::string&) override {
+    recvs.push_back({dev, bytes, peer});
+    return DC_OK;
+  }
+  int group_end(hipStream_t s, std::string& err) override {
+    landed.clear();
+    landed.reserve(recvs.size());
+    for (const Pending& p : recvs) {
+      std::vector<char> msg;
+      {
+        std::unique_lock<std::mutex> l(hub->mu);
+        auto& q = hub->box[{p.peer, rank}];
+        if (!hub->cv.wait_for(l, std::chrono::seconds(60), [&] { return !q.empty(); })) {
+          err = "loopback recv: peer " + std::to_string(p.peer) + " sent nothing within 60 s";
+          return DC_E_STATE;
+        }
+        msg = std::move(q.front());
+        q.pop_front();
+      }
+      if (msg.size() != p.bytes) {           // RCCL would hang or corrupt here; the loopback hub can tell
+        err = "loopback recv: peer " + std::to_string(p.peer) + " sent " + std::to_string(msg.size()) + " bytes, " +
+              std::to_string(p.bytes) + " expected";
+        return DC_E_STATE;
+      }
+      landed.push_back(std::move(msg));
+      hipError_t e = hipMemcpyAsync(p.dev, landed.back().data(), p.bytes, hipMemcpyHostToDevice, s);
+      if (e != hipSuccess) { err = std::string("loopback recv: ") + hipGetErrorString(e); return DC_E_HIP; }
+    }
+    recvs.clear();
+    hipError_t e = hipStreamSynchronize(s);
+    landed.clear();
+    if (e != hipSuccess) { err = std::string("loopback recv: ") + hipGetErrorString(e); return DC_E_HIP; }
+    return DC_OK;
+  }
+};
+
+const char kLoopbackPrefix[] = "dc-loopback:";
+
 }  // namespace
 
 struct dc_comm {
   dc_ctx* ctx = nullptr;
   int device = 0, rank = 0, world = 1;
-  ncclComm_t comm = nullptr;
+  Transport* tp = nullptr;     // null when world == 1
   hipStream_t stream = nullptr;
-  void* dev_buf = nullptr;     // rank 0: world records blocks; others: one
+  void* dev_buf = nullptr;     // rank 0: world record blocks; others: one (world > 1 only)
   size_t dev_bytes = 0;
   void* host_buf = nullptr;    // pinned staging, same size
   size_t host_bytes = 0;
+  int32_t* dev_hdr = nullptr;  // (world, 4) int32: the shape handshake before the payload
   std::string err;
   int fail(int code, const std::string& msg) {
     err = msg;
@@ -84,6 +204,57 @@ struct dc_comm {
 // One image's record: {int32 K, int32 T, int32 capacity, int32 0; float boxes[cap][4]; float scores[cap];
 // int32 tokens[cap][T]} -- typed fields at fixed offsets, K inside the record (one message per rank).
 static size_t record_bytes(int capacity, int T) { return 16 + (size_t)capacity * (16 + 4 + 4 * (size_t)T); }
+
+#define HCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return c->fail(DC_E_HIP, std::string(#x ": ") + hipGetErrorString(_e)); } while (0)
+#define TCHK(x) do { int _r = (x); if (_r != DC_OK) return c->fail(_r, std::string(c->tp->name()) + " " + err); } while (0)
+
+// Shape handshake before the payload: every rank must bring the same (n_local, capacity, T) -- a mismatch would post
+// sends and receives of different byte counts, which hangs or corrupts under RCCL.  Peers send their 16-byte shape to
+// rank 0, rank 0 answers every peer with its verdict {ok, n_local, capacity, T of rank 0}; only then does the payload
+// move.  Two tiny messages per peer, once per gather.
+static int shape_handshake(dc_comm* c, int n_local, int cap, int T) {
+  std::string err;
+  int32_t mine[4] = {n_local, cap, T, 0x44434752};            // 'DCGR'
+  if (c->rank != 0) {
+    HCHK(hipMemcpyAsync(c->dev_hdr, mine, 16, hipMemcpyHostToDevice, c->stream));
+    TCHK(c->tp->group_start(err));
+    TCHK(c->tp->send(c->dev_hdr, 16, 0, c->stream, err));
+    TCHK(c->tp->group_end(c->stream, err));
+    TCHK(c->tp->group_start(err));
+    TCHK(c->tp->recv(c->dev_hdr + 4, 16, 0, c->stream, err));
+    TCHK(c->tp->group_end(c->stream, err));
+    int32_t verdict[4];
+    HCHK(hipMemcpyAsync(verdict, c->dev_hdr + 4, 16, hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    if (verdict[0] != 1)
+      return c->fail(DC_E_STATE, "dc_gather_results: ranks disagree on (n_local, capacity, T): rank 0 has (" +
+                                     std::to_string(verdict[1]) + ", " + std::to_string(verdict[2]) + ", " +
+                                     std::to_string(verdict[3]) + "), rank " + std::to_string(c->rank) + " has (" +
+                                     std::to_string(n_local) + ", " + std::to_string(cap) + ", " + std::to_string(T) + ")");
+    return DC_OK;
+  }
+  TCHK(c->tp->group_start(err));
+  for (int peer = 1; peer < c->world; ++peer) TCHK(c->tp->recv(c->dev_hdr + 4 * peer, 16, peer, c->stream, err));
+  TCHK(c->tp->group_end(c->stream, err));
+  std::vector<int32_t> all((size_t)c->world * 4);
+  HCHK(hipMemcpyAsync(all.data() + 4, c->dev_hdr + 4, (size_t)(c->world - 1) * 16, hipMemcpyDeviceToHost, c->stream));
+  HCHK(hipStreamSynchronize(c->stream));
+  int bad = -1;
+  for (int peer = 1; peer < c->world && bad < 0; ++peer)
+    if (all[4 * peer] != n_local || all[4 * peer + 1] != cap || all[4 * peer + 2] != T || all[4 * peer + 3] != mine[3]) bad = peer;
+  int32_t verdict[4] = {bad < 0 ? 1 : 0, n_local, cap, T};
+  HCHK(hipMemcpyAsync(c->dev_hdr, verdict, 16, hipMemcpyHostToDevice, c->stream));
+  TCHK(c->tp->group_start(err));
+  for (int peer = 1; peer < c->world; ++peer) TCHK(c->tp->send(c->dev_hdr, 16, peer, c->stream, err));
+  TCHK(c->tp->group_end(c->stream, err));
+  HCHK(hipStreamSynchronize(c->stream));
+  if (bad >= 0)
+    return c->fail(DC_E_STATE, "dc_gather_results: rank " + std::to_string(bad) + " brought (n_local, capacity, T) = (" +
+                                   std::to_string(all[4 * bad]) + ", " + std::to_string(all[4 * bad + 1]) + ", " +
+                                   std::to_string(all[4 * bad + 2]) + "), rank 0 has (" + std::to_string(n_local) + ", " +
+                                   std::to_string(cap) + ", " + std::to_string(T) + "): every rank must pass equal shards");
+  return DC_OK;
+}
 
 extern "C" {
 
@@ -116,16 +287,32 @@ int dc_comm_create(dc_comm** out, dc_ctx* ctx, const void* id, int rank, int wor
     return DC_E_HIP;
   }
   if (world > 1) {
-    RcclApi* r = rccl();
-    if (!r->err.empty()) { g_comm_error = r->err; hipStreamDestroy(c->stream); delete c; return DC_E_UNSUPPORTED; }
-    ncclUniqueId uid;
-    memcpy(&uid, id, sizeof uid);
-    ncclResult_t e = r->CommInitRank(&c->comm, world, uid, rank);
-    if (e != ncclSuccess) {
-      g_comm_error = std::string("ncclCommInitRank: ") + r->GetErrorString(e);
+    if (memcmp(id, kLoopbackPrefix, sizeof(kLoopbackPrefix) - 1) == 0) {
+      const char* p = static_cast<const char*>(id);
+      c->tp = new LoopbackTransport(std::string(p, strnlen(p, DC_COMM_ID_BYTES)), rank);
+    } else {
+      RcclApi* r = rccl();
+      if (!r->err.empty()) { g_comm_error = r->err; hipStreamDestroy(c->stream); delete c; return DC_E_UNSUPPORTED; }
+      ncclUniqueId uid;
+      memcpy(&uid, id, sizeof uid);
+      RcclTransport* t = new RcclTransport();
+      ncclResult_t e = r->CommInitRank(&t->comm, world, uid, rank);
+      if (e != ncclSuccess) {
+        g_comm_error = std::string("ncclCommInitRank: ") + r->GetErrorString(e);
+        t->comm = nullptr;
+        delete t;
+        hipStreamDestroy(c->stream);
+        delete c;
+        return DC_E_HIP;
+      }
+      c->tp = t;
+    }
+    if (hipMalloc(reinterpret_cast<void**>(&c->dev_hdr), (size_t)world * 16) != hipSuccess) {
+      g_comm_error = "dc_comm_create: hipMalloc failed";
+      delete c->tp;
       hipStreamDestroy(c->stream);
       delete c;
-      return DC_E_HIP;
+      return DC_E_NOMEM;
     }
   }
   *out = c;
@@ -136,8 +323,9 @@ void dc_comm_destroy(dc_comm* c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
-  if (c->comm) rccl()->CommDestroy(c->comm);
+  delete c->tp;
   if (c->dev_buf) hipFree(c->dev_buf);
+  if (c->dev_hdr) hipFree(c->dev_hdr);
   if (c->host_buf) hipHostFree(c->host_buf);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -159,15 +347,24 @@ int dc_gather_results(dc_comm* c, const dc_result* local, int n_local, dc_result
       if (gathered[i].capacity < cap || !gathered[i].boxes || !gathered[i].scores || !gathered[i].tokens)
         return c->fail(DC_E_INVALID, "dc_gather_results: gathered[] entries need capacity >= the senders' capacity");
   if (hipSetDevice(c->device) != hipSuccess) return c->fail(DC_E_HIP, "hipSetDevice failed");
+  if (c->world > 1) {
+    const int rc = shape_handshake(c, n_local, cap, T);
+    if (rc != DC_OK) return rc;
+  }
   const size_t rb = record_bytes(cap, T), block = rb * (size_t)n_local;
   const size_t need = c->rank == 0 ? block * (size_t)c->world : block;
-  if (c->dev_bytes < need) {
+  if (c->host_bytes < need) {
+    if (c->stream) (void)hipStreamSynchronize(c->stream);        // nothing may still read the buffers being replaced
     if (c->dev_buf) hipFree(c->dev_buf);
     if (c->host_buf) hipHostFree(c->host_buf);
     c->dev_buf = c->host_buf = nullptr; c->dev_bytes = c->host_bytes = 0;
-    if (hipMalloc(&c->dev_buf, need) != hipSuccess || hipHostMalloc(&c->host_buf, need, hipHostMallocDefault) != hipSuccess)
-      return c->fail(DC_E_NOMEM, "dc_gather_results: buffer allocation failed");
-    c->dev_bytes = c->host_bytes = need;
+    if (hipHostMalloc(&c->host_buf, need, hipHostMallocDefault) != hipSuccess)
+      return c->fail(DC_E_NOMEM, "dc_gather_results: host staging allocation failed");
+    c->host_bytes = need;
+    if (c->world > 1) {                                           // world == 1 is a host-side copy: no device buffer
+      if (hipMalloc(&c->dev_buf, need) != hipSuccess) return c->fail(DC_E_NOMEM, "dc_gather_results: device buffer allocation failed");
+      c->dev_bytes = need;
+    }
   }
   // pack this rank's records (rank 0: into slot 0 of the gathered layout)
   char* hb = static_cast<char*>(c->host_buf);
@@ -181,26 +378,23 @@ int dc_gather_results(dc_comm* c, const dc_result* local, int n_local, dc_result
     memcpy(p + 16 + (size_t)cap * 20, local[i].tokens, K * 4 * (size_t)T);
   }
   if (c->world > 1) {
-    RcclApi* r = rccl();
-#define HCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return c->fail(DC_E_HIP, std::string(#x ": ") + hipGetErrorString(_e)); } while (0)
-#define NCHK(x) do { ncclResult_t _e = (x); if (_e != ncclSuccess) return c->fail(DC_E_HIP, std::string(#x ": ") + r->GetErrorString(_e)); } while (0)
+    std::string err;
     if (c->rank != 0) {
       HCHK(hipMemcpyAsync(c->dev_buf, hb, block, hipMemcpyHostToDevice, c->stream));
-      NCHK(r->GroupStart());
-      NCHK(r->Send(c->dev_buf, block, ncclInt8, 0, c->comm, c->stream));
-      NCHK(r->GroupEnd());
+      TCHK(c->tp->group_start(err));
+      TCHK(c->tp->send(c->dev_buf, block, 0, c->stream, err));
+      TCHK(c->tp->group_end(c->stream, err));
       HCHK(hipStreamSynchronize(c->stream));
       return DC_OK;
     }
-    NCHK(r->GroupStart());
+    // ONE group: world-1 receives, peer p's block lands at offset block*p (each peer rides its own xGMI link to rank 0)
+    TCHK(c->tp->group_start(err));
     for (int peer = 1; peer < c->world; ++peer)
-      NCHK(r->Recv(static_cast<char*>(c->dev_buf) + block * (size_t)peer, block, ncclInt8, peer, c->comm, c->stream));
-    NCHK(r->GroupEnd());
+      TCHK(c->tp->recv(static_cast<char*>(c->dev_buf) + block * (size_t)peer, block, peer, c->stream, err));
+    TCHK(c->tp->group_end(c->stream, err));
     HCHK(hipMemcpyAsync(hb + block, static_cast<char*>(c->dev_buf) + block, block * (size_t)(c->world - 1),
                         hipMemcpyDeviceToHost, c->stream));
     HCHK(hipStreamSynchronize(c->stream));
-#undef HCHK
-#undef NCHK
   }
   // rank 0: unpack world * n_local records
   for (int i = 0; i < c->world * n_local; ++i) {

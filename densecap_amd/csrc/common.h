@@ -65,9 +65,8 @@ hipError_t launch_splitk_reduce(const float* ws, int S, const float* bias, float
 // of the whole pooled map
 hipError_t launch_splitk_reduce_pool(const float* ws, int S, const float* bias, float* C_pooled, int m_begin, int M, int N,
                                      int ldc, int H, int Wd, int relu, hipStream_t s);
-// can this conv problem take GemmDesc::pool (the LDS-DMA kernels can; the register-staged v1 fallback cannot)?
+// can this conv problem take GemmDesc::pool (operands within the kernels' 32-bit buffer offsets)?
 bool mfma_gemm_can_pool(const GemmDesc& d);
-bool mfma_gemm_pool_fusion_enabled();   // false with DENSECAP_NO_POOL_FUSION / DENSECAP_GEMM_V1 (A/B runs)
 // split factor launch_mfma_gemm would like for this problem (1 = none)
 int mfma_gemm_splitk(const GemmDesc& d);
 // Tail plan for problems whose 128x128 tile count is not a multiple of the 256 CUs: rows [0, m_split) run as
@@ -95,15 +94,9 @@ hipError_t launch_permute_fc6(const float* in, float* out, int N, int C, int HW,
 // LSTM pointwise: gates (n,4Hd) [i f o g], c (n,Hd) in/out, h (n,Hd) out
 hipError_t launch_lstm_pointwise(const float* gates, float* c, float* h, int n, const int32_t* n_dev, int Hd,
                                   int zero_c, hipStream_t s);
-// row argmax (first max on ties) -> tok (n) 1-based, also seq[m*T + t]
-hipError_t launch_row_argmax(const float* logits, int n, int N, int ld, int32_t* tok, int32_t* seq, int T, int t,
-                             hipStream_t s);
 hipError_t launch_fill_i32(int32_t* p, int32_t v, int n, hipStream_t s);
 // idx[i] = i for i < cap, *count_out = *count_in
 hipError_t launch_iota_count(int32_t* idx, int32_t* count_out, const int32_t* count_in, int cap, hipStream_t s);
-// reduce the per-N-tile arg-max partials of the fused vocab epilogue: tok[m] = seq[m*T+t] = 1 + argmax
-hipError_t launch_argmax_finalize(const float* pval, const int32_t* pidx, int n, const int32_t* n_dev, int ntiles,
-                                  int ld, int32_t* tok, int32_t* seq, int T, int t, hipStream_t s);
 // One decode step's row-wise tail (LanguageModel.lua:316-335 between two GEMMs), one workgroup per row
 // (a wave per row was measured slower: 11.4 vs 8.3 us -- the row's 2048 gate values want 256 lanes in flight):
 //   pval != null: tok = 1 + argmax over the row's `ntiles` partials (first max on ties), seq[m*T+t] = tok;
@@ -119,6 +112,7 @@ hipError_t launch_recog_heads(const float* codes, const float* w5 /*(5,D): obj, 
                               hipStream_t s);
 
 // ---- beam search row kernels (beam.hip; LanguageModel.lua:170-290) --------------------------
+size_t beam_topk_max_vocab();     // largest V+1 whose row fits the top-k kernel's LDS on the current device
 hipError_t launch_beam_logsoftmax_topk(const float* logits, int rows, int V1, int ld, const uint8_t* finished, int k,
                                        float* top_lp, int32_t* top_idx, hipStream_t s);
 hipError_t launch_beam_init(const float* top_lp, const int32_t* top_idx, int nprop, int beam, int T, int END,

@@ -41,7 +41,7 @@ struct Lane {
   int g = 1;                // images of the group in flight
   int fh = 0, fw = 0, A = 0;
   DevBuf arena;               // one allocation, carved below
-  float *img = nullptr, *act[3] = {nullptr, nullptr, nullptr}, *feat = nullptr, *rpn_hidden = nullptr, *heads = nullptr;
+  float *img = nullptr, *act[2] = {nullptr, nullptr}, *feat = nullptr, *rpn_hidden = nullptr, *heads = nullptr;
   float *rpn_boxes = nullptr, *rpn_xyxy = nullptr, *rpn_p = nullptr;
   uint8_t* rpn_valid = nullptr;
   NmsWorkspace nms;
@@ -64,7 +64,7 @@ struct Lane {
   int pending_capacity = 0;
   float stage_ms[ST_COUNT] = {};
   bool have_times = false;
-  // beam search scratch (allocated on first use; kBeamChunk proposals x beam rows at a time)
+  // beam search scratch (allocated on first use; beam_chunk() proposals x beam rows at a time)
   void* beam_base = nullptr;
   int beam_rows = 0;
   float *bm_enc = nullptr, *bm_gates = nullptr, *bm_h[2] = {nullptr, nullptr}, *bm_c[2] = {nullptr, nullptr};
@@ -89,7 +89,10 @@ struct dc_ctx {
   bool captions_after_final_nms = false;
   int group = 0;             // images per lane group (dc_set_group): 0 = default (1), 1, 2
   int arena_allocs = 0;      // lane workspace (re)allocations so far (dc_debug_fetch "arena_allocs")
+  double host_enqueue_ms = 0;  // host ms per image spent enqueueing in the last dc_forward_batch
   int beam_size = 0;         // 0 = greedy LM:sample; > 0 = LM:beamsearch (LanguageModel.lua:129-131)
+  int64_t beam_chunk_floats = (int64_t)1 << 28;   // cap of the beam search's full-logits buffer (dc_debug_set)
+  int decode_route = 0;      // 0 auto, 1 GEMM decode, 2 persistent LDS-resident decode (dc_debug_set)
   bool serial_mode = false;  // lanes == 1: idle CUs in a layer's last round are worth a tail split-K (dc_set_lanes)
   int num_proposals = 300;  // LocalizationLayer default (LocalizationLayer.lua:237); run_model sets 1000
   // dims
@@ -246,19 +249,16 @@ int conv3x3(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, const f
 }
 // conv3x3 + ReLU + nn.SpatialMaxPooling(2,2,2,2):ceil() (VGG layers conv1_2, conv2_2, conv3_3, conv4_3,
 // DenseCapModel.lua:61-76): the pool rides in the conv's epilogue -- the full-resolution activation never reaches HBM
-// (conv1_2: 110 MB store -> 28 MB) and four launches disappear.  out: (ceil(H/2), ceil(W/2), Cout); `tmp` (H,W,Cout) is
-// only used when the problem has to take the unfused route.
-int conv3x3_pool(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, const float* b, float* out, float* tmp,
-                 int nimg, int H, int W, int Cin, int Cout, int relu, float* ws, size_t ws_floats) {
+// (conv1_2: 110 MB store -> 28 MB) and four launches disappear.  out: (ceil(H/2), ceil(W/2), Cout).
+int conv3x3_pool(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, const float* b, float* out, int nimg, int H,
+                 int W, int Cin, int Cout, int relu, float* ws, size_t ws_floats) {
   GemmDesc d;
   const int slots = 4 * ((H + 1) / 2) * ((W + 1) / 2);          // window slots of one image
   d.A = in; d.W = w; d.bias = b; d.C = out; d.M = nimg * slots; d.N = Cout; d.K = 9 * Cin; d.plan_M = slots;
   d.ldc = Cout; d.relu = relu; d.conv = 1; d.H = H; d.Wd = W; d.Cin = Cin; d.pool = 1;
-  if (mfma_gemm_can_pool(d)) return run_gemm(ctx, d, s, ws, ws_floats);
-  if (tmp == nullptr) return ctx->fail(DC_E_UNSUPPORTED, "conv3x3_pool: unfused route needs a scratch buffer");
-  DCCHK(conv3x3(ctx, s, in, w, b, tmp, nimg, H, W, Cin, Cout, relu, ws, ws_floats));
-  KCHK(launch_maxpool2x2_ceil(tmp, out, nimg, H, W, Cout, s));
-  return DC_OK;
+  if (!mfma_gemm_can_pool(d))
+    return ctx->fail(DC_E_UNSUPPORTED, "conv3x3_pool: %dx%dx%d activation exceeds the kernels' 32-bit operand offsets", H, W, Cin);
+  return run_gemm(ctx, d, s, ws, ws_floats);
 }
 
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -305,7 +305,6 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P, int G) {
       {(void**)&L.img, (size_t)G * 3 * H * W * 4},
       {(void**)&L.act[0], act_bytes},
       {(void**)&L.act[1], act_bytes},
-      {(void**)&L.act[2], mfma_gemm_pool_fusion_enabled() ? 256 : act_bytes},
       {(void**)&L.rpn_hidden, (size_t)G * fh * fw * ctx->R * 4},
       {(void**)&L.heads, (size_t)G * fh * fw * 6 * ctx->k * 4},
       {(void**)&L.rpn_boxes, (size_t)G * A * 16},
@@ -457,18 +456,23 @@ int lm_sample_rows(dc_ctx* ctx, Lane& L, const float* codes, int r0, int n, cons
 
 // LanguageModel:beamsearch (LanguageModel.lua:170-290), dispatched by LM:updateOutput when self.beam_size is set
 // (:129-131; no reference script sets it).  The reference walks the proposals one by one with the beams in the
-// minibatch dimension; here kBeamChunk proposals advance together (rows = proposals x beams), row for row the same
+// minibatch dimension; here ALL proposals advance together (rows = proposals x beams; beam_chunk), row for row the same
 // arithmetic: LSTM step (MFMA GEMM + point-wise), vocabulary projection (full logits this time), LogSoftMax + top-k per
 // beam, beam x beam merge, states re-indexed by parent.  Ties: lower index first (docs/SEMANTICS.md).
-constexpr int kBeamChunk = 64;
-int beam_prepare(dc_ctx* ctx, Lane& L) {
-  const int beam = ctx->beam_size, rows = kBeamChunk * beam;
+// Proposals that advance together: all of them (rows = P x beam, one GEMM per step over every proposal) unless the
+// full-logits buffer rows x (V+1) would pass 2^28 floats (1 GiB) -- e.g. 5,114 proposals at beam 5 / V = 10,497.
+int beam_chunk(const dc_ctx* ctx, int n) {
+  const long cap = (long)(ctx->beam_chunk_floats / ((int64_t)ctx->beam_size * (ctx->V + 1)));
+  return (int)std::max<long>(1, std::min<long>(n, std::max<long>(64, cap)));
+}
+int beam_prepare(dc_ctx* ctx, Lane& L, int chunk) {
+  const int beam = ctx->beam_size, rows = chunk * beam;
   if (L.beam_base && L.beam_rows >= rows) return DC_OK;
   if (L.beam_base) { HIPCHK(hipStreamSynchronize(L.stream)); HIPCHK(hipFree(L.beam_base)); L.beam_base = nullptr; }
   const int E = ctx->E, Hd = ctx->Hd, V1 = ctx->V + 1, T = ctx->T;
   struct Carve { void** p; size_t bytes; };
   std::vector<Carve> cv = {
-      {(void**)&L.bm_enc, (size_t)kBeamChunk * E * 4}, {(void**)&L.bm_gates, (size_t)rows * 4 * Hd * 4},
+      {(void**)&L.bm_enc, (size_t)chunk * E * 4},      {(void**)&L.bm_gates, (size_t)rows * 4 * Hd * 4},
       {(void**)&L.bm_h[0], (size_t)rows * Hd * 4},     {(void**)&L.bm_h[1], (size_t)rows * Hd * 4},
       {(void**)&L.bm_c[0], (size_t)rows * Hd * 4},     {(void**)&L.bm_c[1], (size_t)rows * Hd * 4},
       {(void**)&L.bm_logits, (size_t)rows * V1 * 4},   {(void**)&L.bm_top_lp, (size_t)rows * beam * 4},
@@ -487,7 +491,8 @@ int beam_prepare(dc_ctx* ctx, Lane& L) {
 }
 
 int lm_beamsearch(dc_ctx* ctx, Lane& L, const float* codes, int n, int32_t* seq_out, hipStream_t s) {
-  DCCHK(beam_prepare(ctx, L));
+  const int kBeamChunk = beam_chunk(ctx, n);
+  DCCHK(beam_prepare(ctx, L, kBeamChunk));
   const int beam = ctx->beam_size, E = ctx->E, Hd = ctx->Hd, V1 = ctx->V + 1, T = ctx->T, D = ctx->D;
   auto step = [&](float* h, float* c, int rows) -> int {        // one LSTM step on the words in bm_tok, in place
     GemmDesc d;
@@ -509,7 +514,10 @@ int lm_beamsearch(dc_ctx* ctx, Lane& L, const float* codes, int n, int32_t* seq_
     KCHK(launch_beam_logsoftmax_topk(L.bm_logits, c, V1, V1, nullptr, beam, L.bm_top_lp, L.bm_top_idx, s));
     KCHK(launch_beam_init(L.bm_top_lp, L.bm_top_idx, c, beam, T, V1, L.bm_lp[0], L.bm_beams[0], L.bm_parent, L.bm_tok,
                           L.bm_fin, s));
-    KCHK(launch_beam_gather_state(L.bm_h[0], L.bm_c[0], L.bm_parent, c * beam, beam, 1, Hd, L.bm_h[1], L.bm_c[1], s));
+    // LanguageModel.lua:221-226 duplicates the states for the beams with `layer.output = layer.cell:expand(...):clone()`:
+    // BOTH the cell and the hidden state of every beam start from the CELL state of the START step (torch-rnn's
+    // nn.LSTM with remember_states reads h0 from self.output).  Replicated as written: h rows := c rows.
+    KCHK(launch_beam_gather_state(L.bm_c[0], L.bm_c[0], L.bm_parent, c * beam, beam, 1, Hd, L.bm_h[1], L.bm_c[1], s));
     int cur = 1, bcur = 0;
     const int rows = c * beam;
     for (int t = 1; t < T; ++t) {
@@ -563,8 +571,8 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
   KCHK(launch_conv3x3_c3(L.img, ctx->conv_w[0], ctx->conv_b[0], L.act[0], g, H, W, 64, 1, s));
   for (int i = 1; i < DC_NUM_VGG_CONVS; ++i) {
     if (kVgg[i].pool_after) {
-      // conv + ReLU + ceil-mode 2x2 pool in one launch; act[2] is scratch for the (rare) unfused route
-      DCCHK(conv3x3_pool(ctx, s, L.act[cur], ctx->conv_w[i], ctx->conv_b[i], L.act[cur ^ 1], L.act[2], g, h, w, kVgg[i].cin,
+      // conv + ReLU + ceil-mode 2x2 pool in one launch
+      DCCHK(conv3x3_pool(ctx, s, L.act[cur], ctx->conv_w[i], ctx->conv_b[i], L.act[cur ^ 1], g, h, w, kVgg[i].cin,
                          kVgg[i].cout, 1, L.splitk_ws, kSplitkWsFloats));
       h = (h + 1) / 2; w = (w + 1) / 2;
     } else {
@@ -610,11 +618,10 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
                           ctx->D, s));
   HIPCHK(hipEventRecord(L.ev[6], s));
   const bool survivors_only = ctx->captions_after_final_nms && !features_only;
-  static const bool no_split = getenv("DENSECAP_NO_DECODE_SPLIT") != nullptr;
   // single-image mode, reference order: decode (two row blocks on two streams) and final NMS (a third stream) are
   // independent consumers of the heads' outputs.  Per-launch HIP-event profiling wants kernels that do not overlap:
   // everything stays on one stream while it is on.
-  const bool side_streams = ctx->serial_mode && !ctx->prof && !no_split && !features_only && !survivors_only && R >= 256 &&
+  const bool side_streams = ctx->serial_mode && !ctx->prof && !features_only && !survivors_only && R >= 256 &&
                             ctx->beam_size == 0;
   hipStream_t sn = side_streams ? L.aux2 : s;       // stream of the final NMS
   if (side_streams) {
@@ -816,11 +823,23 @@ int dc_set_group(dc_ctx* ctx, int images) {
   return DC_OK;
 }
 
+// beam search needs one vocabulary row in the top-k kernel's LDS and at least `beam` words to choose from
+static int check_beam_fits(dc_ctx* ctx, int beam_size) {
+  if (beam_size <= 0 || !ctx->have_weights) return DC_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(DC_E_HIP, "hipSetDevice failed");
+  const size_t vmax = beam_topk_max_vocab();
+  if ((size_t)(ctx->V + 1) > vmax)
+    return ctx->fail(DC_E_UNSUPPORTED, "beam search: a vocabulary of %d words does not fit the top-k kernel's LDS row on this device (max %zu)",
+                     ctx->V, vmax > 0 ? vmax - 1 : 0);
+  if (beam_size > ctx->V + 1)
+    return ctx->fail(DC_E_UNSUPPORTED, "beam search: beam_size %d exceeds the %d output words", beam_size, ctx->V + 1);
+  return DC_OK;
+}
+
 int dc_set_beam_size(dc_ctx* ctx, int beam_size) {
   if (!ctx) return DC_E_INVALID;
   if (beam_size < 0 || beam_size > 32) return ctx->fail(DC_E_UNSUPPORTED, "dc_set_beam_size: beam_size must be in [0,32] (got %d)", beam_size);
-  if (beam_size > 0 && ctx->have_weights && ((size_t)(ctx->V + 1) * 4 > 150 * 1024 || beam_size > ctx->V + 1))
-    return ctx->fail(DC_E_UNSUPPORTED, "dc_set_beam_size: vocabulary of %d words does not fit the top-k kernel's LDS row", ctx->V);
+  DCCHK(check_beam_fits(ctx, beam_size));          // before dc_load_weights the check runs there instead
   ctx->beam_size = beam_size;
   return DC_OK;
 }
@@ -938,6 +957,10 @@ int dc_load_weights(dc_ctx* ctx, const dc_weights* w) {
   HIPCHK(hipStreamSynchronize(s));
   prof_collect(ctx);
   ctx->have_weights = true;
+  if (int rc = check_beam_fits(ctx, ctx->beam_size); rc != DC_OK) {   // dc_set_beam_size came first: validate it now
+    ctx->beam_size = 0;
+    return rc;
+  }
   return DC_OK;
 }
 
@@ -991,7 +1014,6 @@ static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, i
   while ((int)ctx->lanes.size() < nl) ctx->lanes.emplace_back(new Lane());
   for (int l = 0; l < nl; ++l) DCCHK(lane_prepare(ctx, *ctx->lanes[l], H, W, P, G));
   const size_t img_elems = (size_t)3 * H * W;
-  static const bool host_timing = getenv("DENSECAP_HOST_TIMING") != nullptr;   // stderr: host ms spent enqueueing
   double enq_ms = 0;
   for (int gi = 0; gi < ngroups; ++gi) {
     const int i = gi * G, g = std::min(G, n - i);
@@ -1003,7 +1025,7 @@ static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, i
     enq_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
   for (int l = 0; l < nl; ++l) DCCHK_DRAIN(harvest(ctx, *ctx->lanes[l]));
-  if (host_timing) fprintf(stderr, "[densecap] %d images: host enqueue %.3f ms/image\n", n, enq_ms / n);
+  ctx->host_enqueue_ms = enq_ms / n;       // host time spent enqueueing, per image (dc_debug_fetch "host_enqueue_us")
   prof_collect(ctx);
   return DC_OK;
 }
@@ -1135,6 +1157,11 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
       {"final_nms_idx", L.picks2, (int64_t)P, 4},
       {"final_nms_count", L.count2, 1, 4},
   };
+  if (strcmp(name, "host_enqueue_us") == 0) {
+    if (capacity_bytes < 4) return ctx->fail(DC_E_INVALID, "dc_debug_fetch: buffer too small");
+    *static_cast<int32_t*>(host_buf) = (int32_t)(ctx->host_enqueue_ms * 1000.0);
+    return 1;
+  }
   if (strcmp(name, "arena_allocs") == 0) {
     if (capacity_bytes < 4) return ctx->fail(DC_E_INVALID, "dc_debug_fetch: buffer too small");
     *static_cast<int32_t*>(host_buf) = ctx->arena_allocs;
@@ -1151,6 +1178,21 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
     }
   }
   return ctx->fail(DC_E_INVALID, "dc_debug_fetch: unknown name '%s'", name);
+}
+
+int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value) {
+  if (!ctx || !name) return DC_E_INVALID;
+  if (strcmp(name, "beam_chunk_floats") == 0) {
+    if (value < 1) return ctx->fail(DC_E_INVALID, "dc_debug_set: beam_chunk_floats must be >= 1");
+    ctx->beam_chunk_floats = value;
+    return DC_OK;
+  }
+  if (strcmp(name, "decode_route") == 0) {
+    if (value < 0 || value > 2) return ctx->fail(DC_E_INVALID, "dc_debug_set: decode_route must be 0, 1 or 2");
+    ctx->decode_route = (int)value;
+    return DC_OK;
+  }
+  return ctx->fail(DC_E_INVALID, "dc_debug_set: unknown name '%s'", name);
 }
 
 // ---- memory helpers ----------------------------------------------------------------------
@@ -1222,16 +1264,11 @@ int dc_op_conv3x3_relu_pool(dc_ctx* ctx, const float* in, const float* w, const 
   OP_PROLOGUE();
   if (Cin % 32 || Cout % 4 || H <= 0 || W <= 0 || Cout <= 0)
     return ctx->fail(DC_E_INVALID, "dc_op_conv3x3_relu_pool: need Cin %% 32 == 0, Cout %% 4 == 0 and positive sizes");
-  float *ws = nullptr, *tmp = nullptr;
+  float* ws = nullptr;
   HIPCHK(hipMalloc((void**)&ws, kSplitkWsFloats * 4));
-  if (!mfma_gemm_pool_fusion_enabled() && hipMalloc((void**)&tmp, (size_t)H * W * Cout * 4) != hipSuccess) {
-    (void)hipFree(ws);
-    return ctx->fail(DC_E_NOMEM, "dc_op_conv3x3_relu_pool: scratch allocation failed");
-  }
-  int rc = conv3x3_pool(ctx, s, in, w, b, out, tmp, 1, H, W, Cin, Cout, 1, ws, kSplitkWsFloats);
+  int rc = conv3x3_pool(ctx, s, in, w, b, out, 1, H, W, Cin, Cout, 1, ws, kSplitkWsFloats);
   hipError_t e2 = hipStreamSynchronize(s);
   (void)hipFree(ws);
-  if (tmp) (void)hipFree(tmp);
   prof_collect(ctx);
   if (rc != DC_OK) return rc;
   if (e2 != hipSuccess) return ctx->fail(DC_E_HIP, "dc_op_conv3x3_relu_pool sync: %s", hipGetErrorString(e2));

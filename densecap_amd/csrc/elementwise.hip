@@ -185,62 +185,6 @@ __global__ void lstm_pointwise_kernel(const float* __restrict__ gates, float* __
   }
 }
 
-// ---- row arg-max: one wave per row, first max on ties (torch.max semantics) --------------------
-__global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict__ logits, int n, int N, int ld,
-                                                         int32_t* __restrict__ tok, int32_t* __restrict__ seq,
-                                                         int T, int t) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= n) return;
-  const float* p = logits + (size_t)row * ld;
-  float best = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int j = lane; j < N; j += 64) {
-    const float v = p[j];
-    if (v > best || (bi == 0x7fffffff)) { best = v; bi = j; }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(bi, o, 64);
-    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-  }
-  if (lane == 0) {
-    tok[row] = bi + 1;
-    seq[(size_t)row * T + t] = bi + 1;
-  }
-}
-
-// reduce per-N-tile arg-max partials: one wave per row, coalesced read of the row's partials; on equal
-// values the lower column wins (first max), which is also the lower tile
-__global__ __launch_bounds__(256) void argmax_finalize_kernel(const float* __restrict__ pval,
-                                                              const int32_t* __restrict__ pidx, int n,
-                                                              const int32_t* __restrict__ n_dev, int ntiles,
-                                                              int ld, int32_t* __restrict__ tok,
-                                                              int32_t* __restrict__ seq, int T, int t) {
-  if (n_dev) n = min(n, *n_dev);
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (m >= n) return;
-  float best = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int j = lane; j < ntiles; j += 64) {
-    const float v = pval[(size_t)m * ld + j];
-    const int i = pidx[(size_t)m * ld + j];
-    if (bi == 0x7fffffff || v > best) { best = v; bi = i; }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(bi, o, 64);
-    if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
-  }
-  if (lane == 0) {
-    tok[m] = bi + 1;
-    seq[(size_t)m * T + t] = bi + 1;
-  }
-}
-
 // ---- decode step tail: arg-max finalize + LSTM point-wise, one workgroup (256 threads) per row ---------------------
 // Replaces argmax_finalize + the gate row-term epilogue + lstm_pointwise of one step (3 launches and an 8 MB gate
 // round trip) by one launch: the token a row just produced selects its xg row here, so the h.Wh product of the NEXT
@@ -483,17 +427,6 @@ hipError_t launch_lstm_pointwise(const float* gates, float* c, float* h, int n, 
                                   int zero_c, hipStream_t s) {
   hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(grid_for((size_t)n * Hd)), dim3(256), 0, s, gates, c, h, n, n_dev, Hd,
                      zero_c);
-  return hipGetLastError();
-}
-hipError_t launch_row_argmax(const float* logits, int n, int N, int ld, int32_t* tok, int32_t* seq, int T, int t,
-                             hipStream_t s) {
-  hipLaunchKernelGGL(row_argmax_kernel, dim3((n + 3) / 4), dim3(256), 0, s, logits, n, N, ld, tok, seq, T, t);
-  return hipGetLastError();
-}
-hipError_t launch_argmax_finalize(const float* pval, const int32_t* pidx, int n, const int32_t* n_dev, int ntiles,
-                                  int ld, int32_t* tok, int32_t* seq, int T, int t, hipStream_t s) {
-  hipLaunchKernelGGL(argmax_finalize_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pval, pidx, n, n_dev, ntiles, ld, tok,
-                     seq, T, t);
   return hipGetLastError();
 }
 hipError_t launch_lstm_step_tail(const float* pval, const int32_t* pidx, int ntiles, int ld, int fixed_tok,

@@ -10,7 +10,7 @@
 //     (LanguageModel.lua:27-61) and the fused 1x1 RPN heads.
 //
 // Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain, 64 cycles/SIMD, 157 TF chip peak).
-// Three kernels share the interface (GemmDesc) and the K order of every output element:
+// Two kernels share the interface (GemmDesc) and the K order of every output element:
 //   * mfma_gemm_v2_kernel<TM,TN,CONV,NS[,AMAX]>  -- the workhorse: 2x2 waves, wave tile (32*TM)x(32*TN), operands
 //     HBM/L2 -> LDS by LDS-DMA (buffer_load ... lds) into an NS-stage ring of unpadded, XOR-swizzled 128-byte rows,
 //     one barrier per K-tile in the middle of the tile's MFMAs.  AMAX = fused row arg-max epilogue (vocabulary
@@ -18,12 +18,12 @@
 //     next decode step's gates in the same launch;
 //   * mfma_gemm_ks_kernel<CONV>                  -- 128x128 tile, the four waves split K instead of the tile (half the
 //     LDS->VGPR traffic), cross-wave reduction through LDS at the end; optional split-K over workgroups and row
-//     windows (tail plans);
-//   * mfma_gemm_kernel<TM,TN,CONV> (v1)          -- register-staged, padded LDS rows [BK+4], double buffer: kept for A/B
-//     runs (DENSECAP_GEMM_V1=1) and for operands beyond 32-bit buffer offsets.
+//     windows (tail plans).
+// Both address their operands through 32-bit buffer offsets: an operand tile set beyond 4 GiB (an image of more than
+// ~16 Mpx) is refused with an error, not routed elsewhere.
 // Each lane fetches 4 consecutive k with ONE ds_read_b128 and feeds 4 MFMAs: lane-half h=lane>>5 supplies
 // k = 8g+4h+j to the j-th MFMA of group g, so the hardware's k-pair is (8g+j, 8g+4+j) -- a fixed permutation of the
-// summation order, identical for A and B and for all three kernels.
+// summation order, identical for A and B and for both kernels.
 #include <stdlib.h>
 
 #include <mutex>
@@ -34,8 +34,8 @@
 namespace {
 
 constexpr int BK = 32;
+constexpr int KS_MIN_KTILES = 32;     // K-tiles from which the K-split 128x128 kernel pays (its cross-wave reduction must be amortised)
 constexpr unsigned CV_PAD = 0xffffe000u;   // conv padding marker: voffset (+ up to 8 KiB of channel offset) past any descriptor range
-constexpr int LDS_LD = BK + 4;  // floats per LDS row
 
 // Implicit-GEMM row m -> input pixel (y, x) and its byte offset in the channels-last activation.  Plain convs walk the
 // pixels in raster order; pooled convs (GemmDesc::pool) walk pool windows, four consecutive m per window.
@@ -79,160 +79,6 @@ __device__ __forceinline__ float pool_window(const GemmDesc& d, int win, float v
   if (hx && hy) best = t3 > best ? t3 : best;
   return best;
 }
-
-template <int TM, int TN, bool CONV>
-__global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
-  constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int PA = BM / 32, PB = BN / 32;  // load passes (32 rows x 8 float4 per pass)
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                         // [2][BM][LDS_LD]
-  float* Bs = smem + 2 * BM * LDS_LD;       // [2][BN][LDS_LD]
-
-  // ---- XCD-aware tile mapping: blocks b, b+8, b+16.. share an XCD (b % 8); give each XCD a
-  // contiguous run of logical tile ids so neighbours in the fast dimension share its L2.
-  const int nblk = ntm * ntn;
-  int bid = blockIdx.x;
-  {
-    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, o = bid >> 3;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
-  }
-  int tile_m, tile_n;
-  if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
-  else           { tile_n = bid % ntn; tile_m = bid / ntn; }
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
-  const int lrow = tid >> 3, lchunk = tid & 7;
-
-  // ---- per-thread load descriptors -------------------------------------------------
-  const float* a_ptr[PA];
-  int a_y[PA], a_x[PA];
-  bool a_ok[PA];
-#pragma unroll
-  for (int i = 0; i < PA; ++i) {
-    int m = m0 + lrow + 32 * i;
-    a_ok[i] = m < d.M;
-    if (m >= d.M) m = d.M - 1;
-    if constexpr (CONV) {
-      const int hw = d.H * d.Wd;
-      const int img = m / hw, rem = m - img * hw;
-      a_y[i] = rem / d.Wd;
-      a_x[i] = rem - a_y[i] * d.Wd;
-      a_ptr[i] = d.A + (size_t)m * d.Cin + lchunk * 4;
-    } else {
-      a_y[i] = a_x[i] = 0;
-      a_ptr[i] = d.A + (size_t)m * d.K + lchunk * 4;
-    }
-  }
-  const float* b_ptr[PB];
-#pragma unroll
-  for (int i = 0; i < PB; ++i) {
-    int n = n0 + lrow + 32 * i;
-    if (n >= d.N) n = d.N - 1;
-    b_ptr[i] = d.W + (size_t)n * d.K + lchunk * 4;
-  }
-
-  f32x4 ra[PA], rb[PB];
-  // conv K-walk state: tap (dy,dx) and channel offset
-  int tap = 0, c0 = 0;
-
-  auto load_tile = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < PB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_ptr[i] + (size_t)kt * BK);
-    if constexpr (CONV) {
-      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-      const int off = (dy * d.Wd + dx) * d.Cin + c0;
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        const bool ok = a_ok[i] && (unsigned)(a_y[i] + dy) < (unsigned)d.H && (unsigned)(a_x[i] + dx) < (unsigned)d.Wd;
-        const float* p = ok ? a_ptr[i] + off : a_ptr[i];
-        f32x4 v = *reinterpret_cast<const f32x4*>(p);
-        ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      c0 += BK;
-      if (c0 >= d.Cin) { c0 = 0; ++tap; }
-    } else {
-#pragma unroll
-      for (int i = 0; i < PA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + (size_t)kt * BK);
-    }
-  };
-  auto store_tile = [&](int buf) {
-    float* as = As + buf * BM * LDS_LD;
-    float* bs = Bs + buf * BN * LDS_LD;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(as + (lrow + 32 * i) * LDS_LD + lchunk * 4) = ra[i];
-#pragma unroll
-    for (int i = 0; i < PB; ++i) *reinterpret_cast<f32x4*>(bs + (lrow + 32 * i) * LDS_LD + lchunk * 4) = rb[i];
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int nkt = d.K / BK;
-  const int r = lane & 31, hsel = lane >> 5;
-  const int a_frag_off = (wm * 32 * TM + r) * LDS_LD + hsel * 4;
-  const int b_frag_off = (wn * 32 * TN + r) * LDS_LD + hsel * 4;
-
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) load_tile(kt + 1);
-    const float* as = As + buf * BM * LDS_LD + a_frag_off;
-    const float* bs = Bs + buf * BN * LDS_LD + b_frag_off;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDS_LD + g * 8);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDS_LD + g * 8);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nkt) store_tile(buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue: bias (+ gathered row term) + ReLU, channels-last store -------------------
-  // C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * 32 * TN + j * 32 + r;
-    const bool n_ok = n < d.N;
-    const float bv = (d.bias != nullptr && n_ok) ? d.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mb = m0 + wm * 32 * TM + i * 32 + 4 * hsel;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = mb + (e & 3) + 8 * (e >> 2);
-        if (n_ok && m < d.M) {
-          float v;
-          if (d.rowterm != nullptr) v = d.rowterm[(size_t)(d.rowidx[m] - 1) * d.rowterm_ld + n] + acc[i][j][e];
-          else v = acc[i][j][e] + bv;
-          if (d.relu) v = v > 0.f ? v : 0.f;
-          d.C[(size_t)m * d.ldc + n] = v;
-        }
-      }
-    }
-  }
-}
-
 
 // =========================================================================================
 // v2: LDS-DMA (buffer_load ... lds) 3-stage ring, fragment double-buffering, ONE barrier per
@@ -884,60 +730,40 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   const int ntm = (d.M - d.m_begin + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
   const int m_fastest = ntm <= ntn ? 1 : 0;
-  static const bool use_v1 = getenv("DENSECAP_GEMM_V1") != nullptr;
-  // v2 addresses operands through 32-bit buffer offsets
+  // operands are addressed through 32-bit buffer offsets
   const bool fits = CONV ? ((size_t)(d.a_rows > d.M ? d.a_rows : d.M) * d.Cin * 4 < CV_PAD && d.Cin <= 2048) : ((size_t)BM * d.K * 4 < 0xfffffff0ull);
-  if ((!use_v1 || d.amax_val != nullptr || d.m_dev != nullptr) && fits && (size_t)BN * d.K * 4 < 0xfffffff0ull) {
-    if constexpr (TM == 2 && TN == 2) {
-      static const bool no_ks = getenv("DENSECAP_GEMM_NOKS") != nullptr;
-      const bool forced = d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0;
-      if (d.amax_val != nullptr) return hipErrorInvalidValue;    // the arg-max epilogue lives in the 64-column v2 variant
-      static const int ks_min_ktiles = getenv("DENSECAP_KS_MINK") ? atoi(getenv("DENSECAP_KS_MINK")) : 32;   // A/B switch
-      if (!no_ks && (d.K % (2 * BK * d.splitk)) == 0 && (forced || d.K >= ks_min_ktiles * BK)) {   // short K loops do not amortise the 4-phase reduction
-        // 64 KiB operand ring, reused as the 4 x 16 KiB reduction slots; leaves 96 KiB of the CU's LDS to co-resident workgroups
-        const size_t lds_ks = (size_t)2 * (BM + BN) * BK * sizeof(float);
-        const void* fn = reinterpret_cast<const void*>(&mfma_gemm_ks_kernel<CONV>);
-        if (hipError_t e = ensure_dyn_lds(fn, lds_ks); e != hipSuccess) return e;
-        hipLaunchKernelGGL((mfma_gemm_ks_kernel<CONV>), dim3(ntm * ntn * d.splitk), dim3(256), lds_ks, stream, d, ntm, ntn,
-                           m_fastest);
-        return hipGetLastError();
-      }
-    }
-    if (d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0) return hipErrorInvalidValue;   // K-split kernel features
-    if constexpr (!CONV && TN == 1) {
-      if (d.amax_val != nullptr) {
-        if (d.amax_cols % BN != 0 || (d.amax_cols > 0 && (d.C == nullptr || d.amax_n > d.amax_cols || d.amax_cols > d.N)))
-          return hipErrorInvalidValue;
-        const size_t lds3 = (size_t)3 * (BM + BN) * BK * sizeof(float);
-        const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, false, 3, true>);
-        if (hipError_t e = ensure_dyn_lds(fn, lds3); e != hipSuccess) return e;
-        hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, false, 3, true>), dim3(ntm * ntn), dim3(256), lds3, stream, d, ntm,
-                           ntn, m_fastest);
-        return hipGetLastError();
-      }
-    }
-    if (d.amax_val != nullptr) return hipErrorInvalidValue;
-    static const int ns_env = getenv("DENSECAP_GEMM_STAGES") ? atoi(getenv("DENSECAP_GEMM_STAGES")) : 0;
-    const int ns = ns_env == 4 ? 4 : 3;
-    const size_t lds = (size_t)ns * (BM + BN) * BK * sizeof(float);
-    if (ns == 4) {
-      const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, CONV, 4>);
-      if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
-      hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, CONV, 4>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn,
+  if (!fits || (size_t)BN * d.K * 4 >= 0xfffffff0ull) return hipErrorInvalidValue;
+  if constexpr (TM == 2 && TN == 2) {
+    const bool forced = d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0;
+    if (d.amax_val != nullptr) return hipErrorInvalidValue;    // the arg-max epilogue lives in the 64-column v2 variant
+    if ((d.K % (2 * BK * d.splitk)) == 0 && (forced || d.K >= KS_MIN_KTILES * BK)) {   // short K loops do not amortise the 4-phase reduction
+      // 64 KiB operand ring, reused as the 4 x 16 KiB reduction slots; leaves 96 KiB of the CU's LDS to co-resident workgroups
+      const size_t lds_ks = (size_t)2 * (BM + BN) * BK * sizeof(float);
+      const void* fn = reinterpret_cast<const void*>(&mfma_gemm_ks_kernel<CONV>);
+      if (hipError_t e = ensure_dyn_lds(fn, lds_ks); e != hipSuccess) return e;
+      hipLaunchKernelGGL((mfma_gemm_ks_kernel<CONV>), dim3(ntm * ntn * d.splitk), dim3(256), lds_ks, stream, d, ntm, ntn,
                          m_fastest);
       return hipGetLastError();
     }
-    const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, CONV, 3>);
-    if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, CONV, 3>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn,
-                       m_fastest);
-    return hipGetLastError();
   }
-  if (d.amax_val != nullptr || d.m_dev != nullptr || d.splitk > 1 || d.pool) return hipErrorInvalidValue;  // v2/ks-only features
-  const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
-  const void* fn = reinterpret_cast<const void*>(&mfma_gemm_kernel<TM, TN, CONV>);
+  if (d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0) return hipErrorInvalidValue;   // K-split kernel features
+  if constexpr (!CONV && TN == 1) {
+    if (d.amax_val != nullptr) {
+      if (d.amax_cols % BN != 0 || (d.amax_cols > 0 && (d.C == nullptr || d.amax_n > d.amax_cols || d.amax_cols > d.N)))
+        return hipErrorInvalidValue;
+      const size_t lds3 = (size_t)3 * (BM + BN) * BK * sizeof(float);
+      const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, false, 3, true>);
+      if (hipError_t e = ensure_dyn_lds(fn, lds3); e != hipSuccess) return e;
+      hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, false, 3, true>), dim3(ntm * ntn), dim3(256), lds3, stream, d, ntm,
+                         ntn, m_fastest);
+      return hipGetLastError();
+    }
+  }
+  if (d.amax_val != nullptr) return hipErrorInvalidValue;
+  const size_t lds = (size_t)3 * (BM + BN) * BK * sizeof(float);
+  const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, CONV, 3>);
   if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL((mfma_gemm_kernel<TM, TN, CONV>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn,
+  hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, CONV, 3>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn,
                      m_fastest);
   return hipGetLastError();
 }
@@ -945,9 +771,6 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
 template <bool CONV>
 hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
   if (d.splitk > 1) return launch_cfg<2, 2, CONV>(d, stream);
-  static const int tile_env = getenv("DENSECAP_GEMM_TILE") ? atoi(getenv("DENSECAP_GEMM_TILE")) : 0;
-  if (tile_env == 22 && d.N > 64 && d.amax_val == nullptr) return launch_cfg<2, 2, CONV>(d, stream);
-  if (tile_env == 21 && d.amax_val == nullptr) return launch_cfg<2, 1, CONV>(d, stream);
   // Tile choice: largest tile that still yields >= ~1.5 workgroups per CU (256 CUs) -- for ONE image of a group (plan_M)
   const int pm = d.plan_M > 0 ? d.plan_M : d.M;
   auto blocks = [&](int bm, int bn) { return (long)((pm + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
@@ -983,10 +806,8 @@ int mfma_gemm_ntiles_n(const GemmDesc& d) {
 // Few 128x128 tiles and a long K: split K so that ~224-256 workgroups exist (one round on 256 CUs).  Every slice
 // keeps an even number (>= 16) of K-tiles for the K-split kernel.
 int mfma_gemm_splitk(const GemmDesc& d) {
-  static const bool off = getenv("DENSECAP_GEMM_NOSPLITK") != nullptr || getenv("DENSECAP_GEMM_NOKS") != nullptr ||
-                          getenv("DENSECAP_GEMM_V1") != nullptr || getenv("DENSECAP_GEMM_TILE") != nullptr;
   if ((size_t)128 * d.K * 4 >= 0xfffffff0ull || (d.conv && (size_t)d.M * d.Cin * 4 >= CV_PAD)) return 1;
-  if (off || d.amax_val != nullptr || d.rowterm != nullptr || d.m_dev != nullptr) return 1;
+  if (d.amax_val != nullptr || d.rowterm != nullptr || d.m_dev != nullptr) return 1;
   const int pm = d.plan_M > 0 ? d.plan_M : d.M;       // one image's tiles: the split factor fixes the summation order
   const long tiles = (long)((pm + 127) / 128) * ((d.N + 127) / 128);
   if (tiles >= 128 || d.N < 128) return 1;
@@ -1005,10 +826,7 @@ int mfma_gemm_splitk(const GemmDesc& d) {
 // 4096 cycles per K-tile at ~2.1 GHz: the unit of the tail cost model below
 static const double kUsPerKtile = 1.95;
 bool mfma_gemm_tail_plan(const GemmDesc& d, int* m_split, int* tail_splitk) {
-  static const bool off = getenv("DENSECAP_GEMM_NOTAIL") != nullptr || getenv("DENSECAP_GEMM_NOSPLITK") != nullptr ||
-                          getenv("DENSECAP_GEMM_NOKS") != nullptr || getenv("DENSECAP_GEMM_V1") != nullptr ||
-                          getenv("DENSECAP_GEMM_TILE") != nullptr || getenv("DENSECAP_GEMM_V2") != nullptr;
-  if (off || d.amax_val != nullptr || d.rowterm != nullptr || d.m_dev != nullptr || d.N < 128 || d.N % 4) return false;
+  if (d.amax_val != nullptr || d.rowterm != nullptr || d.m_dev != nullptr || d.N < 128 || d.N % 4) return false;
   if (d.plan_M > 0 && d.plan_M != d.M) return false;      // groups of images: the doubled tile count quantises better as it is
   if ((size_t)128 * d.K * 4 >= 0xfffffff0ull || (d.conv && (size_t)d.M * d.Cin * 4 >= CV_PAD)) return false;
   const int ntm = (d.M + 127) / 128, ntn = (d.N + 127) / 128, nkt = d.K / BK;
@@ -1054,12 +872,8 @@ double gemm_flops(const GemmDesc& d) {
   return 2.0 * m * n * (double)d.K;
 }
 
-bool mfma_gemm_pool_fusion_enabled() {
-  static const bool off = getenv("DENSECAP_GEMM_V1") != nullptr || getenv("DENSECAP_NO_POOL_FUSION") != nullptr;
-  return !off;
-}
 bool mfma_gemm_can_pool(const GemmDesc& d) {
-  return mfma_gemm_pool_fusion_enabled() && d.conv && (size_t)d.M * d.Cin * 4 < CV_PAD && d.Cin <= 2048 && (size_t)128 * d.K * 4 < 0xfffffff0ull &&
+  return d.conv && (size_t)d.M * d.Cin * 4 < CV_PAD && d.Cin <= 2048 && (size_t)128 * d.K * 4 < 0xfffffff0ull &&
          d.N % 4 == 0 && d.ldc % 4 == 0;
 }
 

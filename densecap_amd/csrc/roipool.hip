@@ -112,10 +112,6 @@ hipError_t launch_bilinear_roi_pool(const float* feat_hwc, int h, int w, int C, 
   if (C % 4 || B <= 0 || HH * WW > ROI_MAX_PTS) return hipErrorInvalidValue;
   int split = (4096 + B / 2) / B;             // ~4096 workgroups (16 per CU) measured best for B = 300 .. 2000
   split = split < 1 ? 1 : (split > 8 ? 8 : split);
-  if (const char* e = getenv("DENSECAP_ROI_SPLIT")) {          // tuning override; anything outside [1,8] is ignored
-    const int v = atoi(e);
-    if (v >= 1 && v <= 8) split = v;
-  }
   const long want = (long)B * split;
   const int grid = want < 256 * 16 ? (int)want : 256 * 16;
   hipLaunchKernelGGL(bilinear_roi_pool_kernel, dim3((unsigned)grid), dim3(256), 0, s, feat_hwc, h, w, C, boxes, B,

@@ -153,17 +153,22 @@ class T7Reader:
             obj.fields = self.read_object()     # default torch class read(): one table of fields
             return obj
         if t in (TYPE_FUNCTION, TYPE_RECUR_FUNCTION, TYPE_LEGACY_RECUR_FUNCTION):
-            # File.lua: [index][int size][string.dump bytecode][upvalue table].  Closures carry no weights: the bytecode
-            # is skipped; the upvalue table is still parsed so that object indices stay in step for later back-references.
-            idx = self.read_int()
-            if idx in self.memo:
-                return self.memo[idx]
+            # File.lua: RECUR_FUNCTION (8) / LEGACY_RECUR_FUNCTION (7) are memoised objects: [index][int size][string.dump
+            # bytecode][upvalue table]; the pre-2015 TYPE_FUNCTION (6) is [int size][bytecode][upvalue table] with NO
+            # index and no memo entry.  Closures carry no weights: the bytecode is skipped; the upvalue table is still
+            # parsed so that object indices stay in step for later back-references.
+            idx = None
+            if t != TYPE_FUNCTION:
+                idx = self.read_int()
+                if idx in self.memo:
+                    return self.memo[idx]
             size = self.read_int()
             code = self.f.read(size)
             if len(code) != size:
                 raise EOFError("truncated t7 file (function body)")
             fn = LuaFunction(size)
-            self.memo[idx] = fn
+            if idx is not None:
+                self.memo[idx] = fn
             fn.upvalues = self.read_object()
             return fn
         raise ValueError("t7: unknown type tag %d" % t)

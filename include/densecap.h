@@ -174,9 +174,17 @@ int dc_mfma_profile(dc_ctx* ctx, int reset, int64_t* launches, double* total_ms,
  * name in {"feat_hwc","rpn_heads","rpn_boxes","rpn_x1y1x2y2","rpn_p","rpn_valid",
  * "rpn_nms_idx","rpn_nms_count","roi_boxes","roi_feats","codes","obj","final_trans","final_boxes",
  * "seq","final_nms_idx","final_nms_count"} (lane 0; "seq" is only filled in the reference caption order), or
- * "arena_allocs" (int32: how many times a lane workspace has been (re)allocated -- it only grows).
+ * "arena_allocs" (int32: how many times a lane workspace has been (re)allocated -- it only grows), or
+ * "host_enqueue_us" (int32: host microseconds per image spent enqueueing in the last dc_forward_batch).
  * Returns the number of elements copied (or <0). */
 int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t capacity_bytes);
+/* Test hooks (never needed for correct results; every setting gives the same outputs bit for bit):
+ *   "beam_chunk_floats"  cap, in floats, of the beam search's full-logits buffer (default 2^28): proposals advance in
+ *                        chunks of max(64, cap / (beam * (V+1))) -- lets a test walk the chunk loop with few rows;
+ *   "decode_route"       0 = automatic (default), 1 = always the GEMM decode, 2 = always the persistent LDS-resident
+ *                        decode (rows <= 64 only; more rows fall back to the GEMM decode).
+ * Returns DC_OK or DC_E_INVALID for an unknown name / bad value. */
+int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value);
 
 /* ---- multi-GPU: image shards + ONE gather ------------------------------------ */
 /* The reference binds one device (densecap/utils.lua:22-36) and loops over images on it

@@ -475,7 +475,8 @@ def _topk_margin(v, k):
 def lm_beamsearch(codes, Wt, T, beam_size, return_margins=False):
     """LM:beamsearch (LanguageModel.lua:170-290), one proposal at a time with the beams as the minibatch, exactly as
     written -- including the zeroed next-word log-probabilities of finished beams (:243-247), beams initialised with
-    fill(1) (:209), and seq[i] = beams[argmax beam_logprobs] (:281-282).  Returns int64 (N,T), 1-based ids."""
+    fill(1) (:209), the first beam expansion seeding h with the CELL state (:224), and seq[i] = beams[argmax
+    beam_logprobs] (:281-282).  (Consequence of :224: beam_size = 1 is NOT LM:sample.)  Returns int64 (N,T), 1-based ids."""
     import torch
     N = codes.shape[0]
     Hd = Wt["lstm_w"].shape[1] // 4
@@ -497,7 +498,10 @@ def lm_beamsearch(codes, Wt, T, beam_size, return_margins=False):
         beam_logprobs, idx = _topk_sorted(lp0, beam_size)
         margins[i] = min(margins[i], _topk_margin(lp0, beam_size))
         beams[:, 0] = idx + 1
-        h = h.expand(beam_size, Hd).clone(); c = c.expand(beam_size, Hd).clone()
+        # :221-226 `layer.cell = layer.cell:expand(..):clone()` then `layer.output = layer.cell:expand(..):clone()`: the
+        # hidden state of every beam is seeded with the CELL state (torch-rnn's nn.LSTM with remember_states takes h0 from
+        # self.output, c0 from self.cell) -- as written, not "fixed"
+        c = c.expand(beam_size, Hd).clone(); h = c.clone()
         for t in range(1, T):
             words = torch.from_numpy(beams[:, t - 1])
             h, c = lstm_step(Wt["lstm_b"] + Wt["lm_emb"][words - 1] @ Wx, h, c, Wh)

@@ -5,7 +5,7 @@ reader is tested against bytes it did not produce.  The file is a miniature dens
 round-trip tests never exercised:
 
   * serialized Lua closures: TYPE_FUNCTION (6), TYPE_LEGACY_RECUR_FUNCTION (7), TYPE_RECUR_FUNCTION (8)
-    [int index][int size][bytecode][upvalue table]  -- must be skipped, not fatal;
+    [int index][int size][bytecode][upvalue table] (tag 6: no index, File.lua)  -- must be skipped, not fatal;
   * object back-references (a second occurrence of an index carries no body), incl. modules shared between
     `nets.*` and the nn.gModule `recog_net` (DenseCapModel.lua:127-162) whose forwardnodes are graph.Node objects;
   * a legacy nn.SpatialConvolutionMM whose weight is 2-D (nOutputPlane x nInputPlane*kH*kW);
@@ -88,8 +88,10 @@ def obj(cls, pairs, versioned=True):
 
 
 def lua_function(tag, upvalues):
-    """[int tag][int index][int size][bytecode][upvalue table]"""
-    i32(tag); i32(new_index())
+    """tags 7/8: [int tag][int index][int size][bytecode][upvalue table]; tag 6 (pre-2015 TYPE_FUNCTION): no index"""
+    i32(tag)
+    if tag != FUNCTION:
+        i32(new_index())
     code = b"\x1bLJ\x02 fake bytecode"
     i32(len(code)); out.extend(code)
     upvalues()

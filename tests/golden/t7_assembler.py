@@ -1,0 +1,411 @@
+"""Byte-level assembler for Torch7 `.t7` files and, on top of it, a CHECKPOINT-SHAPED densecap file (test infrastructure).
+
+`assemble_densecap_checkpoint(path, W)` writes what `train.lua:157-185` saves -- `{opt, iter, loss_history,
+results_history, model = nn.DenseCapModel}` after `model:clearState(); model:float()` -- with the module tree of the
+reference, field for field where the reader could trip:
+
+  * `model.net` (nn.Sequential of conv_net1, conv_net2, localization_layer, recog_net; DenseCapModel.lua:48-124) comes
+    FIRST and carries the module bodies; `model.nets.*` are back-references to the same objects (pairs() order of a real
+    file is arbitrary; tests/golden/handmade_checkpoint.t7 has the opposite order);
+  * the VGG-16 convolutions as loadcaffe leaves them (names conv1_1.., `nn.SpatialConvolution` with dW/dH/padW/padH,
+    `nn.SpatialMaxPooling` with ceil_mode = true), layers 1..10 / 11..30 / 32..38 (DenseCapModel.lua:61-64);
+  * the RPN exactly as build_rpn nests it (LocalizationLayer.lua:609-690), LocalizationLayer's other nets
+    (box_sampler_helper, roi_pooling, criterions), its opt table and nil-valued intermediates;
+  * `nets.recog_net` = the nn.gModule of _buildRecognitionNet (DenseCapModel.lua:127-162): forwardnodes / backwardnodes of
+    graph.Node objects whose data.module back-reference nets.recog_base / objectness_branch / box_reg_branch /
+    language_model, plus nn.PosSlicer / nn.ApplyBoxTransform / nn.Identity nodes;
+  * nn.LanguageModel with every field of LM:__init (LanguageModel.lua:10-74) incl. `net` (ParallelTable of back-references)
+    and idx_to_token keyed by NUMBERS (doubles), as cjson-born vocabularies are after utils.read_json + the train.lua fix-up;
+  * parameters as train.lua leaves them: `model:getParameters()` flattened the trainable tensors into ONE FloatStorage, so
+    every weight/bias after conv_net1 is an OFFSET VIEW of a shared storage (first use carries the storage body, later
+    tensors refer back to its index); conv_net1 (not fine-tuned) keeps private storages; a few modules carry gradWeight /
+    gradBias tensors on empty-after-clearState or live storages; serialized closures (tags 8 and 6: tag 6 has NO object
+    index, File.lua) sit on some modules.
+
+Nothing here imports densecap_amd: the reader is tested against bytes it did not produce.
+Format (little endian): int32 tag; NUMBER f64; STRING int32 n + bytes; BOOLEAN int32; TABLE int32 index [int32 n, n x
+(key, value)]; TORCH int32 index [string "V 1", string class, payload]; tensor payload int32 ndim, int64 sizes, int64
+strides, int64 1-based offset, storage object; storage payload int64 n + raw data; RECUR_FUNCTION (8) / LEGACY (7):
+int32 index, int32 size, bytecode, upvalue table; FUNCTION (6): int32 size, bytecode, upvalue table (no index).
+"""
+import struct
+
+import numpy as np
+
+NIL, NUMBER, STRING, TABLE, TORCH, BOOLEAN, FUNCTION, LEGACY_RECUR_FUNCTION, RECUR_FUNCTION = range(9)
+
+
+class Asm:
+    def __init__(self, f):
+        self.f = f
+        self.next = 1
+
+    # ---- primitives ------------------------------------------------------------------------------------------------
+    def i32(self, v): self.f.write(struct.pack("<i", int(v)))
+    def i64(self, v): self.f.write(struct.pack("<q", int(v)))
+    def f64(self, v): self.f.write(struct.pack("<d", float(v)))
+
+    def raw_string(self, s):
+        b = s.encode("latin-1")
+        self.i32(len(b)); self.f.write(b)
+
+    def new_index(self):
+        v = self.next
+        self.next += 1
+        return v
+
+    def num(self, v): self.i32(NUMBER); self.f64(v)
+    def string(self, s): self.i32(STRING); self.raw_string(s)
+    def boolean(self, v): self.i32(BOOLEAN); self.i32(1 if v else 0)
+    def nil(self): self.i32(NIL)
+    def backref(self, tag, index): self.i32(tag); self.i32(index)
+
+    def value(self, v):
+        """python scalar / str / None / callable -> object"""
+        if callable(v): return v()
+        if v is None: return self.nil()
+        if isinstance(v, bool): return self.boolean(v)
+        if isinstance(v, (int, float)): return self.num(v)
+        if isinstance(v, str): return self.string(v)
+        raise TypeError(type(v))
+
+    def table(self, pairs):
+        """pairs: list of (key, value), each a python scalar / str / callable emitting one object."""
+        self.i32(TABLE); idx = self.new_index(); self.i32(idx); self.i32(len(pairs))
+        for k, v in pairs:
+            self.value(k); self.value(v)
+        return idx
+
+    def array(self, items):
+        return self.table([(i + 1, it) for i, it in enumerate(items)])
+
+    def torch_header(self, cls, versioned=True):
+        self.i32(TORCH); idx = self.new_index(); self.i32(idx)
+        if versioned:
+            self.raw_string("V 1")
+        self.raw_string(cls)
+        return idx
+
+    def storage(self, data, cls="torch.FloatStorage"):
+        idx = self.torch_header(cls)
+        data = np.ascontiguousarray(data)
+        self.i64(data.size); self.f.write(data.tobytes())
+        return idx
+
+    def tensor(self, shape, strides, offset1, emit_storage, cls="torch.FloatTensor"):
+        idx = self.torch_header(cls)
+        self.i32(len(shape))
+        for s in shape: self.i64(s)
+        for s in strides: self.i64(s)
+        self.i64(offset1)
+        emit_storage()
+        return idx
+
+    def ftensor(self, a):
+        a = np.ascontiguousarray(a, np.float32)
+        return self.tensor(a.shape, [s // 4 for s in a.strides], 1, lambda: self.storage(a.reshape(-1)))
+
+    def empty_tensor(self, cls="torch.FloatTensor"):
+        """torch.Tensor() after clearState: 0 dims, offset 1, nil storage"""
+        idx = self.torch_header(cls)
+        self.i32(0); self.i64(1); self.nil()
+        return idx
+
+    def obj(self, cls, pairs, versioned=True):
+        idx = self.torch_header(cls, versioned)
+        self.table(pairs)
+        return idx
+
+    def lua_function(self, tag, upvalues):
+        self.i32(tag)
+        if tag != FUNCTION:                     # File.lua: only the RECUR encodings are memoised objects
+            self.i32(self.new_index())
+        code = b"\x1bLJ\x02\x00 fake bytecode of a closure"
+        self.i32(len(code)); self.f.write(code)
+        upvalues()
+
+
+class FlatParams:
+    """One FloatStorage holding many tensors back to back (what nn.Module:getParameters leaves behind): the first tensor
+    emitted carries the storage body, the others refer back to its object index."""
+
+    def __init__(self, asm, arrays):
+        self.a = asm
+        self.offsets = {}
+        flat, pos = [], 0
+        for key, arr in arrays:
+            arr = np.ascontiguousarray(arr, np.float32)
+            self.offsets[key] = (pos, arr.shape)
+            flat.append(arr.reshape(-1)); pos += arr.size
+        self.flat = np.concatenate(flat) if flat else np.zeros(0, np.float32)
+        self.index = None
+
+    def tensor(self, key):
+        pos, shape = self.offsets[key]
+        strides, s = [], 1
+        for d in reversed(shape):
+            strides.insert(0, s); s *= d
+
+        def st():
+            if self.index is None:
+                self.index = self.a.storage(self.flat)
+            else:
+                self.a.backref(TORCH, self.index)
+        return self.a.tensor(shape, strides, pos + 1, st)
+
+
+def _np(a):
+    a = a.detach().cpu().numpy() if hasattr(a, "detach") else a
+    return np.ascontiguousarray(a, np.float32)
+
+
+def assemble_densecap_checkpoint(path, W, with_grads=("rpn_conv", "obj")):
+    """Write a checkpoint-shaped `.t7` holding the weights dict W (densecap_amd.weights layout).  Returns the number of
+    serialized objects."""
+    cw = [_np(w) for w in W["conv_w"]]; cb = [_np(b) for b in W["conv_b"]]
+    V, T = int(W["vocab_size"]), int(W["seq_length"])
+    anchors = _np(W["anchors"])
+    k = anchors.shape[1]
+    x0, y0, sx, sy = [float(v) for v in W["field_centers"]]
+    itt = W.get("idx_to_token") or {i: "w%d" % i for i in range(1, V + 1)}
+    E, D = _np(W["lm_enc_w"]).shape
+    Hd = _np(W["lstm_w"]).shape[1] // 4
+    R = _np(W["rpn_conv_w"]).shape[0]
+    vgg_names = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2",
+                 "conv4_3", "conv5_1", "conv5_2", "conv5_3"]
+    with open(path, "wb") as f:
+        a = Asm(f)
+        # trainable parameters in getParameters order (module order of model.net, then the LM): one flat storage
+        flat_list = []
+        for i in range(4, 13):
+            flat_list += [("conv%d_w" % i, cw[i]), ("conv%d_b" % i, cb[i])]
+        for nm in ("rpn_conv", "rpn_box", "rpn_score", "fc6", "fc7", "obj", "boxreg", "lm_enc"):
+            flat_list += [(nm + "_w", _np(W[nm + "_w"])), (nm + "_b", _np(W[nm + "_b"]))]
+        flat_list += [("lm_emb", _np(W["lm_emb"])), ("lstm_w", _np(W["lstm_w"])), ("lstm_b", _np(W["lstm_b"])),
+                      ("lm_out_w", _np(W["lm_out_w"])), ("lm_out_b", _np(W["lm_out_b"]))]
+        flat = FlatParams(a, flat_list)
+        shared = {}
+
+        def grads(nm, wshape, bshape):
+            if nm in with_grads:     # gradWeight / gradBias survive clearState (full size, zeros)
+                return [("gradWeight", lambda: a.ftensor(np.zeros(wshape, np.float32))),
+                        ("gradBias", lambda: a.ftensor(np.zeros(bshape, np.float32)))]
+            return [("gradWeight", a.empty_tensor), ("gradBias", a.empty_tensor)]
+
+        def conv(nm, w, b, name=None, private=False, pad=1, ksz=3):
+            def emit():
+                wt = (lambda: a.ftensor(w)) if private else (lambda: flat.tensor(nm + "_w"))
+                bt = (lambda: a.ftensor(b)) if private else (lambda: flat.tensor(nm + "_b"))
+                pairs = [("weight", wt), ("bias", bt), ("nOutputPlane", w.shape[0]), ("nInputPlane", w.shape[1]),
+                         ("kH", ksz), ("kW", ksz), ("dH", 1), ("dW", 1), ("padH", pad), ("padW", pad), ("train", False),
+                         ("output", a.empty_tensor), ("gradInput", a.empty_tensor), ("_type", "torch.FloatTensor")]
+                pairs += grads(nm, w.shape, b.shape)
+                if name:
+                    pairs.append(("name", name))
+                a.obj("nn.SpatialConvolution", pairs)
+            return emit
+
+        def simple(cls, pairs=(), versioned=True):
+            return lambda: a.obj(cls, list(pairs) + [("train", False)], versioned)
+
+        def seq(items, cls="nn.Sequential", remember=None):
+            def emit():
+                idx = a.obj(cls, [("modules", lambda: a.array(items)), ("train", False), ("output", a.empty_tensor),
+                                  ("gradInput", a.empty_tensor)])
+                if remember:
+                    shared[remember] = idx
+            return emit
+
+        def linear(nm, remember=None, name=None):
+            w = _np(W[nm + "_w"]); b = _np(W[nm + "_b"])
+
+            def emit():
+                pairs = [("weight", lambda: flat.tensor(nm + "_w")), ("bias", lambda: flat.tensor(nm + "_b")),
+                         ("train", False), ("output", a.empty_tensor), ("gradInput", a.empty_tensor)]
+                pairs += grads(nm, w.shape, b.shape)
+                if name:
+                    pairs.append(("name", name))
+                idx = a.obj("nn.Linear", pairs)
+                if remember:
+                    shared[remember] = idx
+            return emit
+
+        relu = simple("nn.ReLU", [("inplace", True), ("threshold", 0), ("val", 0)])
+        pool = simple("nn.SpatialMaxPooling", [("kW", 2), ("kH", 2), ("dW", 2), ("dH", 2), ("padW", 0), ("padH", 0),
+                                               ("ceil_mode", True), ("indices", a.empty_tensor)])
+        # ---- VGG-16 layers 1..30 (DenseCapModel.lua:61-63; no pool5) -------------------------------------------------
+        net1, net2 = [], []
+        for i in range(13):
+            c = conv("conv%d" % i, cw[i], cb[i], name=vgg_names[i], private=i < 4)
+            (net1 if i < 4 else net2).extend([c, relu])
+            if i in (1, 3):
+                net1.append(pool)
+            if i in (6, 9):
+                net2.append(pool)
+        # ---- RPN (LocalizationLayer.lua:609-690) --------------------------------------------------------------------
+        make_anchors = simple("nn.MakeAnchors", [("x0", x0), ("y0", y0), ("sx", sx), ("sy", sy),
+                                                 ("anchors", lambda: a.ftensor(anchors))])
+        reshape = lambda: simple("nn.ReshapeBoxFeatures", [("k", k)])()
+        box_branch = seq([conv("rpn_box", _np(W["rpn_box_w"]), _np(W["rpn_box_b"]), pad=0, ksz=1),
+                          simple("nn.RegularizeLayer", [("w", 0)]),
+                          seq([seq([make_anchors, reshape]), reshape], "nn.ConcatTable"),
+                          seq([simple("nn.ApplyBoxTransform"), simple("nn.Identity")], "nn.ConcatTable")])
+        rpn_branch = seq([conv("rpn_score", _np(W["rpn_score_w"]), _np(W["rpn_score_b"]), pad=0, ksz=1), reshape])
+        rpn = seq([conv("rpn_conv", _np(W["rpn_conv_w"]), _np(W["rpn_conv_b"])), relu,
+                   seq([box_branch, rpn_branch], "nn.ConcatTable"), simple("nn.FlattenTable")])
+        loc_opt = [("input_dim", 512), ("output_height", 7), ("output_width", 7),
+                   ("field_centers", lambda: a.array([x0, y0, sx, sy])), ("backend", "cudnn"), ("rpn_filter_size", 3),
+                   ("rpn_num_filters", R), ("zero_box_conv", True), ("std", 0.01), ("anchor_scale", 1.0),
+                   ("sampler_batch_size", 256), ("sampler_high_thresh", 0.7), ("sampler_low_thresh", 0.5),
+                   ("train_remove_outbounds_boxes", 1), ("mid_box_reg_weight", 0.05), ("mid_objectness_weight", 0.1),
+                   ("box_reg_decay", 5e-5)]
+
+        def localization_layer():
+            shared["localization_layer"] = a.obj("nn.LocalizationLayer", [
+                ("opt", lambda: a.table(loc_opt)), ("losses", lambda: a.table([])),
+                ("nets", lambda: a.table([
+                    ("rpn", rpn),
+                    ("box_sampler_helper", simple("nn.BoxSamplerHelper", [("box_sampler", simple("nn.BoxSampler", [
+                        ("low_thresh", 0.5), ("high_thresh", 0.7), ("batch_size", 256)]))])),
+                    ("roi_pooling", simple("nn.BilinearRoiPooling", [("height", 7), ("width", 7)])),
+                    ("invert_box_transform", simple("nn.InvertBoxTransform")),
+                    ("obj_crit_pos", simple("nn.OurCrossEntropyCriterion")),
+                    ("obj_crit_neg", simple("nn.OurCrossEntropyCriterion")),
+                    ("box_reg_crit", simple("nn.SmoothL1Criterion", [("sizeAverage", True)]))])),
+                ("roi_boxes", a.empty_tensor), ("rpn_out", None), ("image_height", None), ("image_width", None),
+                ("nms_thresh", 0.7), ("max_proposals", 300), ("timing", False), ("dump_vars", False),
+                ("timer_hook", lambda: a.lua_function(RECUR_FUNCTION, lambda: a.table([
+                    (1, lambda: a.table([("name", "_ENV")])), (2, lambda: a.table([("name", "self"), ("value", 3)]))]))),
+                ("old_hook", lambda: a.lua_function(FUNCTION, lambda: a.table([]))),
+                ("train", False), ("output", lambda: a.table([])), ("gradInput", a.empty_tensor)])
+
+        # ---- recognition base: VGG layers 32..38 (View is layer 31 and is skipped by recog_start = 32) ----------------
+        drop = simple("nn.Dropout", [("p", 0.5), ("v2", True), ("inplace", True), ("noise", a.empty_tensor)])
+        recog_base = seq([linear("fc6", name="fc6"), relu, drop, linear("fc7", name="fc7"), relu, drop],
+                         remember="recog_base")
+
+        # ---- language model (LanguageModel.lua:10-74) -----------------------------------------------------------------
+        def lstm():
+            shared["lstm"] = a.obj("nn.LSTM", [
+                ("input_dim", E), ("hidden_dim", Hd), ("weight", lambda: flat.tensor("lstm_w")),
+                ("bias", lambda: flat.tensor("lstm_b")), ("gradWeight", a.empty_tensor), ("gradBias", a.empty_tensor),
+                ("cell", a.empty_tensor), ("gates", a.empty_tensor), ("buffer1", a.empty_tensor),
+                ("buffer2", a.empty_tensor), ("buffer3", a.empty_tensor), ("grad_a_buffer", a.empty_tensor),
+                ("h0", a.empty_tensor), ("c0", a.empty_tensor), ("remember_states", False), ("train", False),
+                ("output", a.empty_tensor), ("gradInput", a.empty_tensor)])
+
+        def image_encoder():
+            shared["image_encoder"] = a.obj("nn.Sequential", [("modules", lambda: a.array([
+                linear("lm_enc"), relu, simple("nn.View", [("size", lambda: a.storage(np.array([1, -1], np.int64), "torch.LongStorage")),
+                                                   ("numElements", 1), ("numInputDims", 1)])])),
+                ("train", False)])
+
+        def lookup_table():
+            shared["lookup_table"] = a.obj("nn.LookupTable", [
+                ("weight", lambda: flat.tensor("lm_emb")), ("gradWeight", a.empty_tensor), ("shouldScaleGradByFreq", False),
+                ("_count", lambda: a.empty_tensor("torch.IntTensor")), ("_input", lambda: a.empty_tensor("torch.LongTensor")),
+                ("train", False)])
+
+        def view_in():
+            shared["view_in"] = a.obj("nn.View", [("numElements", 1), ("numInputDims", 3), ("train", False)])
+
+        def view_out():
+            shared["view_out"] = a.obj("nn.View", [("numElements", 1), ("numInputDims", 2), ("train", False)])
+
+        def rnn():
+            shared["rnn"] = a.obj("nn.Sequential", [("modules", lambda: a.array([
+                lstm, view_in, lambda: a.obj("nn.Linear", [("weight", lambda: flat.tensor("lm_out_w")),
+                                                           ("bias", lambda: flat.tensor("lm_out_b")),
+                                                           ("gradWeight", a.empty_tensor), ("gradBias", a.empty_tensor),
+                                                           ("train", False)]),
+                view_out])), ("train", False)])
+
+        def language_model():
+            shared["language_model"] = a.obj("nn.LanguageModel", [
+                ("vocab_size", V), ("input_encoding_size", E), ("image_vector_dim", D), ("rnn_size", Hd),
+                ("seq_length", T), ("num_layers", 1), ("dropout", 0),
+                ("idx_to_token", lambda: a.table([(int(i), str(itt[i])) for i in sorted(itt)])),
+                ("START_TOKEN", V + 1), ("END_TOKEN", V + 1), ("NULL_TOKEN", V + 2), ("sample_argmax", True),
+                ("image_encoder", image_encoder), ("lookup_table", lookup_table), ("rnn", rnn),
+                ("view_in", lambda: a.backref(TORCH, shared["view_in"])),
+                ("view_out", lambda: a.backref(TORCH, shared["view_out"])),
+                # self.net = Sequential{ParallelTable{image_encoder, start_token_generator (nil at __init time), lookup_table},
+                #                       JoinTable(1,2), rnn}: back-references only
+                ("net", seq([seq([lambda: a.backref(TORCH, shared["image_encoder"]),
+                                  lambda: a.backref(TORCH, shared["lookup_table"])], "nn.ParallelTable"),
+                             simple("nn.JoinTable", [("dimension", 1), ("nInputDims", 2)]),
+                             lambda: a.backref(TORCH, shared["rnn"])])),
+                ("recompute_backward", True), ("_forward_sampled", True), ("train", False),
+                ("output", a.empty_tensor), ("gradInput", lambda: a.table([]))])
+
+        # ---- recog_net = nn.gModule (DenseCapModel.lua:127-162) ------------------------------------------------------
+        def node(module_emit, name=None, nid=0):
+            data = [("module", module_emit), ("mapindex", lambda: a.table([])), ("forwardNodeId", nid)]
+            if name:
+                data.append(("annotations", lambda: a.table([("name", name)])))
+            else:
+                data.append(("annotations", lambda: a.table([])))
+            return lambda: a.obj("nngraph.Node", [("data", lambda: a.table(data)), ("children", lambda: a.table([])),
+                                                  ("visited", False), ("marked", False)], versioned=False)
+
+        def recog_net():
+            fwd = [node(simple("nn.Identity"), nid=1), node(simple("nn.Identity"), nid=2),
+                   node(simple("nn.Identity"), nid=3), node(simple("nn.Identity"), nid=4),
+                   node(recog_base, "recog_base", 5),
+                   node(linear("obj", remember="objectness_branch"), "objectness_branch", 6),
+                   node(simple("nn.PosSlicer"), "code_slicer", 7), node(simple("nn.PosSlicer"), "box_slicer", 8),
+                   node(linear("boxreg", remember="box_reg_branch"), "box_reg_branch", 9),
+                   node(simple("nn.ApplyBoxTransform"), nid=10), node(language_model, nid=11)]
+            shared["recog_net"] = a.obj("nn.gModule", [
+                ("name", "recognition_network"), ("forwardnodes", lambda: a.array(fwd)),
+                ("backwardnodes", lambda: a.array([
+                    node(lambda: a.backref(TORCH, shared["language_model"]), nid=11),
+                    node(lambda: a.backref(TORCH, shared["recog_base"]), "recog_base", 5)])),
+                ("nInputs", 4), ("verbose", False), ("train", False), ("output", lambda: a.table([])),
+                ("gradInput", lambda: a.table([]))])
+
+        def remember_seq(items, key):
+            def emit():
+                shared[key] = a.obj("nn.Sequential", [("modules", lambda: a.array(items)), ("train", False),
+                                                      ("output", a.empty_tensor), ("gradInput", a.empty_tensor)])
+            return emit
+
+        model_opt = [("cnn_name", "vgg-16"), ("backend", "cudnn"), ("path_offset", ""), ("dtype", "torch.CudaTensor"),
+                     ("vocab_size", V), ("std", 0.01), ("final_nms_thresh", 0.3), ("mid_box_reg_weight", 0.05),
+                     ("mid_objectness_weight", 0.1), ("end_box_reg_weight", 0.1), ("end_objectness_weight", 0.1),
+                     ("captioning_weight", 1.0), ("seq_length", T), ("rnn_encoding_size", E), ("rnn_size", Hd),
+                     ("input_dim", 512), ("output_height", 7), ("output_width", 7),
+                     ("field_centers", lambda: a.array([x0, y0, sx, sy])),
+                     ("idx_to_token", lambda: a.table([(int(i), str(itt[i])) for i in sorted(itt)]))]
+
+        def model():
+            a.obj("nn.DenseCapModel", [
+                ("opt", lambda: a.table(model_opt)),
+                ("net", seq([remember_seq(net1, "conv_net1"), remember_seq(net2, "conv_net2"), localization_layer,
+                             recog_net])),
+                ("nets", lambda: a.table([
+                    ("conv_net1", lambda: a.backref(TORCH, shared["conv_net1"])),
+                    ("conv_net2", lambda: a.backref(TORCH, shared["conv_net2"])),
+                    ("localization_layer", lambda: a.backref(TORCH, shared["localization_layer"])),
+                    ("recog_base", lambda: a.backref(TORCH, shared["recog_base"])),
+                    ("objectness_branch", lambda: a.backref(TORCH, shared["objectness_branch"])),
+                    ("box_reg_branch", lambda: a.backref(TORCH, shared["box_reg_branch"])),
+                    ("language_model", lambda: a.backref(TORCH, shared["language_model"])),
+                    ("recog_net", lambda: a.backref(TORCH, shared["recog_net"]))])),
+                ("crits", lambda: a.table([
+                    ("objectness_crit", simple("nn.LogisticCriterion")),
+                    ("box_reg_crit", simple("nn.BoxRegressionCriterion", [("w", 0.1)])),
+                    ("lm_crit", simple("nn.TemporalCrossEntropyCriterion", [("batch_average", True), ("time_average", True)]))])),
+                ("finetune_cnn", False), ("train", False), ("timing", False), ("dump_vars", False),
+                ("cnn_backward", False), ("output", lambda: a.table([])), ("gradInput", a.empty_tensor)])
+
+        train_opt = [("checkpoint_path", "checkpoint.t7"), ("learning_rate", 1e-5), ("optim_beta1", 0.9),
+                     ("optim_beta2", 0.999), ("max_iters", -1), ("save_checkpoint_every", 10000), ("gpu", 0),
+                     ("seq_length", T), ("vocab_size", V),
+                     ("idx_to_token", lambda: a.table([(int(i), str(itt[i])) for i in sorted(itt)]))]
+        a.table([("opt", lambda: a.table(train_opt)), ("iter", 620000),
+                 ("loss_history", lambda: a.table([(10000, lambda: a.table([("captioning_loss", 2.25), ("total_loss", 5.5)]))])),
+                 ("results_history", lambda: a.table([(620000, lambda: a.table([
+                     ("ap_results", lambda: a.table([("map", 0.0570)])), ("loss_results", lambda: a.table([]))]))])),
+                 ("model", model)])
+        return a.next - 1

@@ -114,3 +114,66 @@ def test_bench_world2_rccl_gather():
     d = _run_bench(2, [])
     assert d["n_gpus"] == 2 and d["config"]["gather"].startswith("dc_gather_results")
     assert d["config"]["total_output_boxes"] > 0
+
+
+def _loopback_gather(world, n_local, P, T, shapes=None, seed=0):
+    """`world` dc_comm objects on an in-process loopback hub (id "dc-loopback:<name>"), one thread per rank, all on
+    GPU 0: drives dc_gather_results' whole control flow -- shape handshake, device staging, per-peer offsets block*peer,
+    unpack order r*n_local+i -- without RCCL (which refuses two ranks on one device)."""
+    import threading
+    from densecap_amd import dist as D
+    from densecap_amd.ops import Context
+    ident = ("dc-loopback:test-%d-%d-%d" % (world, n_local, seed)).encode().ljust(128, b"\0")
+    rng = np.random.default_rng(seed)
+    data = []
+    for r in range(world):
+        nl, Pr, Tr = shapes[r] if shapes else (n_local, P, T)
+        shard = []
+        for i in range(nl):
+            k = int(rng.integers(0, Pr + 1))
+            shard.append((rng.standard_normal((k, 4)).astype(np.float32), rng.standard_normal(k).astype(np.float32),
+                          rng.integers(1, 9999, (k, Tr)).astype(np.int32)))
+        data.append(shard)
+    ctxs = [Context(0) for _ in range(world)]
+    out, errs = [None] * world, [None] * world
+
+    def run(r):
+        try:
+            comm = D.Comm(ctxs[r], r, world, ident)
+            try:
+                _, Pr, Tr = shapes[r] if shapes else (n_local, P, T)
+                out[r] = comm.gather(data[r], Pr, Tr)
+            finally:
+                comm.close()
+        except Exception as e:       # noqa: BLE001 -- reported per rank below
+            errs[r] = e
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th: t.start()
+    for t in th: t.join(120)
+    assert not any(t.is_alive() for t in th), "a rank hung in dc_gather_results"
+    for c in ctxs: c.close()
+    return data, out, errs
+
+
+@pytest.mark.parametrize("world,n_local", [(2, 3), (4, 2), (8, 4)])
+def test_gather_results_loopback_world_gt1(world, n_local):
+    data, out, errs = _loopback_gather(world, n_local, P=37, T=15, seed=world)
+    assert errs == [None] * world, errs
+    assert all(o is None for o in out[1:]) and len(out[0]) == world
+    for r in range(world):
+        assert len(out[0][r]) == n_local
+        for (b, s, t), (b2, s2, t2) in zip(data[r], out[0][r]):
+            np.testing.assert_array_equal(b, b2); np.testing.assert_array_equal(s, s2); np.testing.assert_array_equal(t, t2)
+
+
+def test_gather_results_refuses_unequal_shards_without_hanging():
+    """dist.shard_range gives uneven shards when n % world != 0: the shape handshake must turn that into an error on
+    EVERY rank (under RCCL, mismatched byte counts would hang or corrupt)."""
+    shapes = [(3, 20, 15), (3, 20, 15), (2, 20, 15), (3, 20, 15)]           # rank 2 brings one image less
+    _, out, errs = _loopback_gather(4, 3, 20, 15, shapes=shapes, seed=9)
+    assert all(e is not None for e in errs), errs
+    assert "rank 2" in str(errs[0]) and "disagree" in str(errs[1])
+    shapes = [(2, 20, 15), (2, 24, 15)]                                      # another capacity
+    _, out, errs = _loopback_gather(2, 2, 20, 15, shapes=shapes, seed=10)
+    assert all(e is not None for e in errs), errs

@@ -412,8 +412,8 @@ def _prefix(row, end):
 def test_beamsearch_teacher_forced(beam):
     """LM:beamsearch (LanguageModel.lua:170-290) through dc_op_lm_sample with dc_set_beam_size, on the ORACLE's codes:
     identical token rows (the whole row, including the deterministic filler after END), except rows where the oracle's
-    own selection margin (gap at a top-k boundary or between neighbours in a merge) is below 1e-4.  beam = 1 must
-    also give the greedy LM:sample captions."""
+    own selection margin (gap at a top-k boundary or between neighbours in a merge) is below 1e-4.  (beam = 1 is not
+    LM:sample in the reference: LanguageModel.lua:224 seeds the beams' hidden state with the cell state.)"""
     import torch
     from densecap_amd import DenseCapModel
     from densecap_amd._lib import check
@@ -423,7 +423,9 @@ def test_beamsearch_teacher_forced(beam):
     m = DenseCapModel(W, device=0)
     try:
         ctx = m.ctx
-        n = 70                                             # crosses the 64-proposal chunk of the HIP path
+        n = 70
+        # all proposals advance together by default; a small cap on the logits buffer walks the chunk loop (64 + 6 rows)
+        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"beam_chunk_floats", 1), "dc_debug_set")
         codes = np.maximum(np.random.default_rng(beam).standard_normal((n, 4096)), 0).astype(np.float32)
         oseq, margins = O.lm_beamsearch(torch.from_numpy(codes), W, 7, beam, return_margins=True)
         m.setBeamSize(beam)
@@ -434,11 +436,6 @@ def test_beamsearch_teacher_forced(beam):
         for r in bad:
             assert margins[r] < 1e-4, "row %d differs (hip %s oracle %s) with oracle margin %g" % (r, seq[r], oseq[r], margins[r])
         assert seq.min() >= 1 and seq.max() <= 301
-        if beam == 1:
-            m.setBeamSize(0)
-            check(ctx.h, ctx.lib.dc_op_lm_sample(ctx.h, cd.ptr, n, td.ptr), "dc_op_lm_sample")
-            greedy = td.numpy()         # same words up to END; after END a finished beam carries filler, greedy keeps sampling
-            assert [_prefix(r, 301) for r in greedy] == [_prefix(r, 301) for r in seq]
         with pytest.raises(Exception):
             m.setBeamSize(33)
     finally:

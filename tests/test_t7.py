@@ -155,3 +155,44 @@ def test_daemon_protocol_with_fake_model(tmp_path):
     np.testing.assert_allclose(out["boxes"], [[17.0, 35.0, 8.0, 12.0]])
     assert not (ind / "frame7.jpg").exists() and (ind / "broken.jpg").exists()
     np.testing.assert_allclose(D.scale_boxes_xywh([[1, 1, 10, 10]], 1.5), [[1, 1, 15, 15]])
+
+
+def test_reads_checkpoint_shaped_file_assembled_from_bytes(tmp_path):
+    """tests/golden/t7_assembler.py writes what train.lua:157-185 saves (model.net first with the bodies, model.nets as
+    back-references, the nn.gModule recog_net with nngraph.Node objects, LocalizationLayer's other nets / opt / closures
+    (tag 8 with an index, tag 6 without), trainable parameters as OFFSET VIEWS of one flat storage like getParameters
+    leaves them, empty post-clearState tensors, LongStorage fields, number-keyed idx_to_token).  The product reader must
+    bring every tensor back bit for bit.  Reduced fc / vocabulary sizes here; the -m gpu test
+    (test_gpu_config0.py) does the same at the real VGG-16 / V = 10,497 shapes and runs the file through the HIP path."""
+    from densecap_amd import t7
+    from densecap_amd.weights import make_synthetic_weights
+    from tests.golden.t7_assembler import assemble_densecap_checkpoint
+    W = make_synthetic_weights(seed=5, vocab_size=40, seq_length=6, fc_dim=256)
+    W["idx_to_token"] = {i: "tok%d" % i for i in range(1, 41)}
+    p = tmp_path / "ckpt.t7"
+    nobj = assemble_densecap_checkpoint(str(p), W)
+    assert nobj > 400
+    ck = t7.load(str(p))
+    assert ck["iter"] == 620000 and ck["results_history"][620000]["ap_results"]["map"] == 0.057
+    model = ck["model"]
+    nets = model["nets"]
+    mods = t7._lua_list(model["net"]["modules"])
+    assert mods[0] is nets["conv_net1"] and mods[2] is nets["localization_layer"] and mods[3] is nets["recog_net"]
+    loc = nets["localization_layer"]
+    assert isinstance(loc["timer_hook"], t7.LuaFunction) and isinstance(loc["old_hook"], t7.LuaFunction)
+    assert loc["rpn_out"] is None and loc["roi_boxes"].size == 0
+    nodes = t7._lua_list(nets["recog_net"]["forwardnodes"])
+    assert nodes[4]["data"]["module"] is nets["recog_base"] and nodes[10]["data"]["module"] is nets["language_model"]
+    assert nodes[5]["data"]["module"] is nets["objectness_branch"] and nodes[8]["data"]["module"] is nets["box_reg_branch"]
+    lm = nets["language_model"]
+    assert t7._lua_list(t7._lua_list(lm["net"]["modules"])[0]["modules"])[0] is lm["image_encoder"]
+    B = t7.weights_from_checkpoint(ck)
+    for i in range(13):
+        np.testing.assert_array_equal(B["conv_w"][i], W["conv_w"][i].numpy())
+        np.testing.assert_array_equal(B["conv_b"][i], W["conv_b"][i].numpy())
+    for k in ("rpn_conv_w", "rpn_conv_b", "rpn_box_w", "rpn_box_b", "rpn_score_w", "rpn_score_b", "fc6_w", "fc6_b", "fc7_w",
+              "fc7_b", "obj_w", "obj_b", "boxreg_w", "boxreg_b", "lm_enc_w", "lm_enc_b", "lm_emb", "lstm_w", "lstm_b",
+              "lm_out_w", "lm_out_b", "anchors"):
+        np.testing.assert_array_equal(B[k], np.asarray(W[k]), err_msg=k)
+    assert B["field_centers"] == (8.5, 8.5, 16.0, 16.0) and B["vocab_size"] == 40 and B["seq_length"] == 6
+    assert B["idx_to_token"] == W["idx_to_token"]
