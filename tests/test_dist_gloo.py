@@ -120,3 +120,41 @@ def test_bench_line_contract_single_process_stub():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["unit"] == "images/s" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
     assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def _run_stub_bench(world, extra, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", str(world), "--stub", "--dist-backend", "gloo", "--steps", "5", "--warmup", "1",
+                        "--repeats", "2", "--proposals", "40"] + extra, capture_output=True, text=True, timeout=timeout, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    return json.loads(lines[0]), p.stderr
+
+
+def test_bench_world8_control_flow_under_gloo():
+    """The driver's 8-GPU launch, on CPU: 8 ranks, the lane choice broadcast from rank 0 (the stub's per-rank trial
+    picks a different winner on every rank), the communicator-style carrier (--gather abi -> StubComm), the gather's
+    [rank][image] order checked record by record against the global image ids, max-over-ranks time, one JSON line."""
+    d, _ = _run_stub_bench(8, ["--gather", "abi"])
+    assert d["n_gpus"] == 8 and d["steps"] == 5 and d["scaling"] == "weak" and d["data"] == "stub"
+    assert d["config"]["gather"].startswith("dc_gather_results") and d["config"]["gather_order_verified"] is True
+    assert d["lanes"] == 2            # rank 0's trial {2: 102, 3: 100, 4: 101}; rank 1 alone would pick 4 (StubModel.autotuneLanes)
+    assert d["sustained"]["images"] % (8 * 5) == 0 and d["sustained"]["images_per_s"] > 0
+    assert abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+
+
+def test_bench_world8_carrier_failure_falls_back_on_every_rank():
+    """A carrier that cannot be created on ONE rank (librccl missing, ncclCommInitRank refused) must be dropped by ALL
+    ranks together (all_ranks_ok) -- otherwise the job deadlocks with some ranks in the communicator and others in
+    torch.distributed.  (A rank that dies INSIDE a collective cannot be recovered by anyone; not modelled.)"""
+    d, err = _run_stub_bench(8, ["--gather", "abi", "--stub-comm-fail", "create:5"])
+    assert d["config"]["gather"].startswith("torch.distributed.gather") and "dc_gather_results" in d["config"]["gather"]
+    assert d["config"]["gather_order_verified"] is True and "WARNING" in err
