@@ -188,7 +188,6 @@ __global__ void rpn_decode_kernel(const float* __restrict__ heads, int h, int w,
 // ---------------------------------------------------------------------------------------
 constexpr int NMS_BUCKET_BITS = 16;
 constexpr int NMS_BUCKETS = 1 << NMS_BUCKET_BITS;
-constexpr int NMS_MAX_WORDS = 1024;      // up to 65536 boxes
 constexpr int NMS_WIN0 = 4096;
 
 __device__ __forceinline__ uint32_t sort_key(float s, bool valid) {
@@ -596,9 +595,11 @@ static size_t nms_mask_words(int n) {
   }
   return best;
 }
+// one `removed0` bit per sorted box (the reference has no box limit, box_utils.lua:154-256: neither has this)
+static size_t nms_removed_words(int n) { return ((size_t)n + 63) / 64; }
 size_t nms_workspace_bytes(int n) {
   return align256((size_t)n * 4) * 6 + align256((size_t)n * 16) + align256(NMS_BUCKETS * 4) * 3 + align256(256) * 2 +
-         align256(NMS_MAX_WORDS * 8) + align256(nms_mask_words(n) * 8);
+         align256(nms_removed_words(n) * 8) + align256(nms_mask_words(n) * 8);
 }
 hipError_t nms_workspace_bind(NmsWorkspace& ws, void* base, int n) {
   char* p = static_cast<char*>(base);
@@ -616,7 +617,7 @@ hipError_t nms_workspace_bind(NmsWorkspace& ws, void* base, int n) {
   ws.cursor = reinterpret_cast<int32_t*>(p); p += align256(NMS_BUCKETS * 4);
   ws.state = reinterpret_cast<int32_t*>(p); p += align256(256);
   ws.nvalid = reinterpret_cast<int32_t*>(p); p += align256(256);
-  ws.removed0 = reinterpret_cast<unsigned long long*>(p); p += align256(NMS_MAX_WORDS * 8);
+  ws.removed0 = reinterpret_cast<unsigned long long*>(p); p += align256(nms_removed_words(n) * 8);
   ws.zero_bytes = (size_t)(p - reinterpret_cast<char*>(ws.hist));
   ws.off = reinterpret_cast<int32_t*>(p); p += align256(NMS_BUCKETS * 4);
   ws.mask = reinterpret_cast<u64*>(p);
@@ -626,7 +627,7 @@ hipError_t nms_workspace_bind(NmsWorkspace& ws, void* base, int n) {
 hipError_t launch_nms(NmsWorkspace& ws, const float* boxes, const float* scores, const uint8_t* valid, int n,
                       const int32_t* n_dev, float thresh, int max_boxes, int32_t* picks, int32_t* count,
                       hipStream_t s) {
-  if (n > ws.n_cap || n > NMS_MAX_WORDS * 64) return hipErrorInvalidValue;
+  if (n > ws.n_cap) return hipErrorInvalidValue;
   hipError_t e;
   if (n <= 0) return hipMemsetAsync(count, 0, 4, s);
   if ((e = hipMemsetAsync(ws.hist, 0, ws.zero_bytes, s)) != hipSuccess) return e;

@@ -152,7 +152,7 @@ struct NmsWorkspace {
   int32_t* off = nullptr;         // (NMS_BUCKETS)
   int32_t* state = nullptr;       // {count, done}
   int32_t* nvalid = nullptr;      // (1)
-  unsigned long long* removed0 = nullptr;  // (1024) bits suppressed by picks of earlier windows
+  unsigned long long* removed0 = nullptr;  // (ceil(n/64)) bits suppressed by picks of earlier windows
   unsigned long long* mask = nullptr;      // window bit mask
   size_t mask_words = 0;
   size_t zero_bytes = 0;          // hist..removed0 are contiguous and zeroed per call

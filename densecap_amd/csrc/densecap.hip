@@ -271,7 +271,7 @@ int effective_proposals(const dc_ctx* ctx, int H, int W) {
   int fh = H, fw = W;
   for (int i = 0; i < DC_NUM_VGG_CONVS; ++i)
     if (kVgg[i].pool_after) { fh = (fh + 1) / 2; fw = (fw + 1) / 2; }
-  return std::min(ctx->k * fh * fw, 65536);
+  return ctx->k * fh * fw;
 }
 
 // bytes of one image's slot in the pinned result staging: {count; boxes; scores; tokens | fc7 codes}
@@ -798,8 +798,8 @@ const char* dc_last_error(const dc_ctx* ctx) { return ctx ? ctx->err.c_str() : g
 
 int dc_set_test_args(dc_ctx* ctx, float rpn_nms_thresh, float final_nms_thresh, int num_proposals) {
   if (!ctx) return DC_E_INVALID;
-  if (num_proposals != -1 && (num_proposals <= 0 || num_proposals > 65536))
-    return ctx->fail(DC_E_UNSUPPORTED, "num_proposals must be -1 (uncapped) or in [1,65536] (got %d)", num_proposals);
+  if (num_proposals != -1 && (num_proposals <= 0 || num_proposals > (1 << 20)))
+    return ctx->fail(DC_E_UNSUPPORTED, "num_proposals must be -1 (uncapped) or in [1,1048576] (got %d)", num_proposals);
   ctx->rpn_nms_thresh = rpn_nms_thresh;
   ctx->final_nms_thresh = final_nms_thresh;
   ctx->num_proposals = num_proposals;
@@ -985,16 +985,12 @@ static void drain_lanes(dc_ctx* ctx) {
     if (_r != DC_OK) { drain_lanes(ctx); return _r; } \
   } while (0)
 
-// The NMS bit-mask workspace addresses at most NMS_MAX_WORDS*64 = 65536 candidates (boxes.hip): images whose conv5_3
-// map has more than 65536/k cells (about 1184x1184 px for k = 12) are refused up front with a message.
-static int check_anchor_count(dc_ctx* ctx, int H, int W, const char* who) {
-  int fh = H, fw = W;
-  for (int i = 0; i < DC_NUM_VGG_CONVS; ++i)
-    if (kVgg[i].pool_after) { fh = (fh + 1) / 2; fw = (fw + 1) / 2; }
-  const long A = (long)ctx->k * fh * fw;
-  if (A > 65536)
-    return ctx->fail(DC_E_UNSUPPORTED, "%s: %dx%d image -> %dx%d map x %d anchors = %ld RPN boxes; the NMS supports at most 65536",
-                     who, W, H, fw, fh, ctx->k, A);
+// The reference puts no limit on the image size (box_utils.lua:154-256 handles any number of boxes).  What bounds an
+// image here is the 32-bit operand addressing of the convolution kernels: the largest activation, conv1_x's
+// (H, W, 64) fp32 map, must stay below 4 GiB -- about 16 Mpx.
+static int check_image_size(dc_ctx* ctx, int H, int W, const char* who) {
+  if ((size_t)H * W * 64 * 4 >= 0xffffe000ull)
+    return ctx->fail(DC_E_UNSUPPORTED, "%s: a %dx%d image exceeds the conv kernels' 4 GiB activation limit (~16 Mpx)", who, W, H);
   return DC_OK;
 }
 
@@ -1002,7 +998,7 @@ static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, i
   if (!ctx) return DC_E_INVALID;
   if (!ctx->have_weights) return ctx->fail(DC_E_STATE, "dc_forward_*: weights not loaded");
   if (!imgs || !outs || n <= 0 || H < 32 || W < 32) return ctx->fail(DC_E_INVALID, "dc_forward_*: bad arguments");
-  DCCHK(check_anchor_count(ctx, H, W, "dc_forward_*"));
+  DCCHK(check_image_size(ctx, H, W, "dc_forward_*"));
   HIPCHK(hipSetDevice(ctx->device));
   const int P = effective_proposals(ctx, H, W);
   for (int i = 0; i < n; ++i)
@@ -1037,7 +1033,7 @@ int dc_forward_images(dc_ctx* ctx, const float* const* imgs, const int* H, const
   for (int i = 0; i < n; ++i) {
     if (!imgs[i] || H[i] < 32 || W[i] < 32 || outs[i].capacity <= 0)
       return ctx->fail(DC_E_INVALID, "dc_forward_images: image %d: null pointer, side below 32 px or capacity <= 0", i);
-    DCCHK(check_anchor_count(ctx, H[i], W[i], "dc_forward_images"));
+    DCCHK(check_image_size(ctx, H[i], W[i], "dc_forward_images"));
   }
   HIPCHK(hipSetDevice(ctx->device));
   const int nl = std::min(n, ctx->max_lanes);
@@ -1066,7 +1062,7 @@ int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img
   if (!ctx) return DC_E_INVALID;
   if (!ctx->have_weights) return ctx->fail(DC_E_STATE, "dc_extract_features: weights not loaded");
   if (!img_chw || capacity <= 0 || H < 32 || W < 32) return ctx->fail(DC_E_INVALID, "dc_extract_features: bad arguments");
-  DCCHK(check_anchor_count(ctx, H, W, "dc_extract_features"));
+  DCCHK(check_image_size(ctx, H, W, "dc_extract_features"));
   HIPCHK(hipSetDevice(ctx->device));
   Lane& L = lane0(ctx);
   DCCHK(harvest(ctx, L));
@@ -1088,7 +1084,7 @@ int dc_extract_features_images(dc_ctx* ctx, const float* const* imgs, const int*
   for (int i = 0; i < n; ++i) {
     if (!imgs[i] || H[i] < 32 || W[i] < 32)
       return ctx->fail(DC_E_INVALID, "dc_extract_features_images: image %d: null pointer or side below 32 px", i);
-    DCCHK(check_anchor_count(ctx, H[i], W[i], "dc_extract_features_images"));
+    DCCHK(check_image_size(ctx, H[i], W[i], "dc_extract_features_images"));
   }
   HIPCHK(hipSetDevice(ctx->device));
   const int nl = std::min(n, ctx->max_lanes);
@@ -1326,7 +1322,7 @@ int dc_op_rpn_decode(dc_ctx* ctx, const float* heads, int h, int w, int k, const
 int dc_op_nms(dc_ctx* ctx, const float* boxes, const float* scores, const uint8_t* valid, int n, float thresh,
               int max_boxes, int32_t* picks, int32_t* count) {
   OP_PROLOGUE();
-  if (n < 0 || n > 65536) return ctx->fail(DC_E_INVALID, "dc_op_nms: n must be in [0,65536]");
+  if (n < 0) return ctx->fail(DC_E_INVALID, "dc_op_nms: n must be >= 0");
   if (n == 0) { HIPCHK(hipMemsetAsync(count, 0, 4, s)); OP_EPILOGUE(); }
   void* base = nullptr;
   HIPCHK(hipMalloc(&base, nms_workspace_bytes(n)));

@@ -173,7 +173,7 @@ class DenseCapModel:
             return P
         for _ in range(4):                       # four ceil-mode 2x2 pools (conv5_3 map)
             H, W = (H + 1) // 2, (W + 1) // 2
-        return min(self.num_anchors * H * W, 65536)
+        return self.num_anchors * H * W
 
     def forward_raw(self, img):
         """forward_test without string decoding: (boxes (K,4) xcycwh, scores (K,), tokens (K,T))."""

@@ -118,12 +118,12 @@ function Model:setTestArgs(kwargs)
                                          self.opt.num_proposals), 'dc_set_test_args')
 end
 -- rows the result buffers need: num_proposals, or every anchor of the image when it is -1 (uncapped RPN NMS,
--- LocalizationLayer.lua:322-324): k * ceil(H/16) * ceil(W/16) after the four ceil-mode pools, at most 65536
+-- LocalizationLayer.lua:322-324): k * ceil(H/16) * ceil(W/16) after the four ceil-mode pools
 function Model:_capacity(H, W)
   local P = self.opt.num_proposals
   if P ~= -1 then return P end
   for _ = 1, 4 do H, W = math.floor((H + 1) / 2), math.floor((W + 1) / 2) end
-  return math.min(self.num_anchors * H * W, 65536)
+  return self.num_anchors * H * W
 end
 -- language_model.beam_size: nil / 0 = greedy LM:sample, n = LM:beamsearch with n beams (1..32)
 function Model:setBeamSize(n)

@@ -148,25 +148,19 @@ def test_config4_shard_64_images_1000_proposals(model, weights):
     for i in range(64):
         st = {}
         ora = O.forward_test(imgs[i], weights, 0.7, 0.3, 1000, 15, stages=st)
-        # asserts: lists identical, or every departure carries a < 1e-4 near-tie proof from the oracle's data
-        rep = parity.compare_final(O, weights, batch[i], ora, st, 0.3, 15, {})
-        why = rep.get("final_list_flips", []) + rep.get("token_near_ties", [])
+        # lists identical, or the departure is REPLAYED (tests/parity.py::hybrid_nms) through the single-image entry point
+        # -- bit-identical to the batch result, asserted -- where the HIP path's own stage inputs exist
+        rep = parity.final_or_replay(model, O, weights, imgs[i], batch[i], ora, st, 1000)
+        why = rep.get("rpn_flips", []) + rep.get("final_list_flips", []) + rep.get("token_near_ties", [])
         if why:
-            # a departure: the near-tie exists in the oracle's data (asserted above); now show it is the whole story --
-            # the same image through the single-image entry point is bit-identical to its batch result, and there
-            # every integer stage is bit-exact on the HIP path's own inputs, every continuous stage within 1e-4
-            single = model.forward_raw(imgs[i])
-            for x, y in zip(single, batch[i]):
-                np.testing.assert_array_equal(x, y)
-            full = parity.strict_check(model, weights, imgs[i], 1000)
-            proofs.append(dict(image=100 + i, why=why, fc7_codes_rel_err=full["fc7_codes_rel_err"],
-                               final_boxes_pre_nms_rel_err=full["final_boxes_pre_nms_rel_err"]))
+            proofs.append(dict(image=100 + i, flipped_decisions=why, fc7_codes_rel_err=rep.get("fc7_codes_rel_err"),
+                               final_boxes_pre_nms_rel_err=rep.get("final_boxes_pre_nms_rel_err")))
         identical += not why
         boxes_total += rep["matched"]
     assert boxes_total > 64 * 100
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     import json
-    json.dump(dict(images=64, identical=identical, boxes_matched=boxes_total, proven_near_ties=proofs),
+    json.dump(dict(images=64, identical=identical, boxes_matched=boxes_total, replayed_departures=proofs),
               open(os.path.join(ROOT, "gpurun_out", "config4_shard_parity.json"), "w"), indent=1)
 
 
@@ -204,7 +198,8 @@ def test_config3_batch32_300_proposals(model, weights):
         # P=300 against the ORACLE (not against the HIP path itself): final lists identical or proven near-tie
         st = {}
         ora = O.forward_test(base[i], weights, 0.7, 0.3, 300, 15, stages=st)
-        parity.compare_final(O, weights, batch[i], ora, st, 0.3, 15, {})
+        parity.final_or_replay(model, O, weights, base[i], batch[i], ora, st, 300)
+        model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=300)
         b, s, t = model.forward_raw(base[i])
         for rep in range(i, 32, 4):
             np.testing.assert_array_equal(batch[rep][0], b)
@@ -602,10 +597,9 @@ def test_abi_edge_cases_report_errors_and_truncate(model, weights):
     assert lib.dc_set_lanes(h, 0) == -1 and lib.dc_set_lanes(h, 5) == -1
     assert lib.dc_set_beam_size(h, -1) == -5 and lib.dc_set_group(h, 7) == -1                # DC_E_UNSUPPORTED / DC_E_INVALID
     assert lib.dc_debug_fetch(h, b"no_such_tensor", b.ctypes.data, b.nbytes) < 0
-    # an image too large for the NMS mask (k * ceil(H/16) * ceil(W/16) > 65536 anchors) is refused, not mangled
-    big = np.zeros((3, 1300, 1300), np.float32)
-    assert lib.dc_forward_test(h, big.ctypes.data, 1300, 1300, 0, C.byref(r2)) == -5
-    assert b"65536" in lib.dc_last_error(h)
+    # an image whose conv1 activation would pass the kernels' 32-bit operand offsets (~16 Mpx) is refused up front
+    assert lib.dc_forward_test(h, img.ctypes.data, 4200, 4200, 0, C.byref(r2)) == -5
+    assert b"16 Mpx" in lib.dc_last_error(h)
     # and the context still works afterwards
     again = model.forward_raw(img)
     for x, y in zip(again, full):
@@ -645,3 +639,12 @@ def test_forward_images_of_mixed_sizes_equals_one_by_one(model, weights, tmp_pat
     res = json.load(open(out_dir / "results.json"))["results"]
     assert [r["img_name"] for r in res] == ["p0.png", "p1.png", "p2.png"]
     assert all(len(r["boxes"]) == len(r["captions"]) > 0 for r in res)
+
+
+def test_large_image_beyond_65536_anchors(model, weights):
+    """The reference puts no limit on the number of RPN boxes (box_utils.lua:154-256; `-image_size` above ~1184 px):
+    1600x1200 -> 75x100 map x 12 = 90,000 anchors through the windowed NMS, final outputs against the oracle."""
+    from densecap_amd.weights import make_synthetic_image
+    from tests import parity
+    r = parity.strict_check(model, weights, make_synthetic_image(1200, 1600, 21), 1000, stages=False)
+    assert r["K"] > 0 and r["matched"] == r["K_oracle"]

@@ -325,6 +325,25 @@ def test_nms_exact_vs_oracle(ctx, n, thr, maxb, ties):
     assert ops.nms(ctx, b, thr, maxb).tolist() == O.nms(b, thr, maxb).tolist()
 
 
+@pytest.mark.parametrize("n,maxb", [(90000, 1000), (150000, None)])
+def test_nms_beyond_65536_boxes(ctx, n, maxb):
+    """No box limit in the reference (box_utils.lua:154-256): 90,000 = a 1600x1200 image's anchors; 150,000 near-duplicate
+    clusters, uncapped, walk the 4096-row window and five 32768-row windows with suppression carried across all of them."""
+    from densecap_amd import ops
+    from oracle import densecap_oracle as O
+    rng = np.random.default_rng(n)
+    if maxb is None:
+        ncl, per = n // 50, 50
+        cxy = rng.uniform(0, 6000, (ncl, 1, 2)); wh = rng.uniform(30, 60, (ncl, 1, 2))
+        xy = cxy + rng.uniform(-2, 2, (ncl, per, 2))
+        b = np.concatenate([xy, xy + wh + rng.uniform(-2, 2, (ncl, per, 2))], 2).reshape(-1, 4)
+        b5 = np.concatenate([b, np.round(rng.uniform(0, 1, (n, 1)), 4)], 1).astype(np.float32)
+    else:
+        b5 = _random_boxes5(rng, n, True)
+    got, ref = ops.nms(ctx, b5, 0.6, maxb), O.nms(b5, 0.6, maxb)
+    assert got.tolist() == ref.tolist() and len(ref) >= (1000 if maxb else 2000)
+
+
 def test_nms_valid_mask_equals_compaction(ctx):
     # LocalizationLayer.lua:285-298 compacts by `valid` before NMS; masking is equivalent
     from densecap_amd import ops
