@@ -99,30 +99,14 @@ __device__ __forceinline__ float pool_window(const GemmDesc& d, int win, float v
 // roles, so each 32x32 accumulator block is held TRANSPOSED: a lane owns one output row m (lane&31) and its registers
 // walk 16 of the block's 32 columns n.  The row arg-max is then a compare chain inside the lane -- no LDS transpose.
 // Each element is the same fp32 fmaf chain over k either way.
-template <int TM, int TN, bool CONV, int NS, bool AMAX = false>
-__global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
+// One output tile [m0, m0+BM) x [n0, n0+BN) (tile_n = n0 / BN indexes the arg-max partials); Meff = rows of the problem.
+template <int TM, int TN, bool CONV, int NS, bool AMAX>
+__device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const int n0, const int tile_n, const int Meff,
+                                        float* const smem) {
   static_assert(!(AMAX && CONV), "arg-max epilogue is for dense GEMMs");
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int PA = BM / 32, PB = BN / 32;
   constexpr int STAGE = (BM + BN) * BK;  // floats per ring stage
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-
-  const int nblk = ntm * ntn;
-  int bid = blockIdx.x;
-  {
-    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, o = bid >> 3;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
-  }
-  int tile_m, tile_n;
-  if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
-  else           { tile_n = bid % ntn; tile_m = bid / ntn; }
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  int Meff = d.M;
-  if (d.m_dev != nullptr) {             // device-side row count (e.g. boxes surviving the final NMS)
-    const int me = *d.m_dev;
-    if (me < Meff) Meff = me;
-    if (m0 >= Meff) return;
-  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -440,6 +424,63 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
 }
 
 
+// XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (b % 8); each XCD gets a contiguous run of logical tile ids so
+// that neighbours in the fast dimension share its L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7, o = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+}
+
+template <int TM, int TN, bool CONV, int NS, bool AMAX = false>
+__global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int bid = xcd_remap(blockIdx.x, ntm * ntn);
+  int tile_m, tile_n;
+  if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
+  else           { tile_n = bid % ntn; tile_m = bid / ntn; }
+  const int m0 = tile_m * (64 * TM);
+  int Meff = d.M;
+  if (d.m_dev != nullptr) {             // device-side row count (e.g. boxes surviving the final NMS)
+    const int me = *d.m_dev;
+    if (me < Meff) Meff = me;
+    if (m0 >= Meff) return;
+  }
+  v2_tile<TM, TN, CONV, NS, AMAX>(d, m0, tile_n * (64 * TN), tile_n, Meff, smem);
+}
+
+// Decode-step GEMM with a FINER LAST ROUND.  The 128x64 tiles of one launch (1576 at 1000 rows x 12,608 columns) do not
+// fill a whole number of rounds on the chip's 2 x 256 workgroup slots; the leftover tiles used to run one per CU while the
+// rest of the chip idled (the critical CU does 7 tiles against a mean of 6.16).  Here the first `nbig` tiles (whole rounds)
+// are 128x64 and each leftover tile is cut into two 64x64 tiles on the SAME launch -- twice the workgroups at half the
+// duration in the ragged round.  An element's K order does not depend on the tile it falls in (same fragment/lane walk
+// for every v2 shape), so results are bit-identical to the plain launch.
+template <int NS>
+__global__ __launch_bounds__(256) void mfma_gemm_v2_amax_mixed_kernel(GemmDesc d, int ntm, int ntn, int m_fastest, int nbig) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int Meff = d.M;
+  if (d.m_dev != nullptr) {
+    const int me = *d.m_dev;
+    if (me < Meff) Meff = me;
+  }
+  const int b = blockIdx.x;
+  if (b < nbig) {
+    const int bid = xcd_remap(b, nbig);
+    int tile_m, tile_n;
+    if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
+    else           { tile_n = bid % ntn; tile_m = bid / ntn; }
+    if (tile_m * 128 >= Meff) return;
+    v2_tile<2, 1, false, NS, true>(d, tile_m * 128, tile_n * 64, tile_n, Meff, smem);
+  } else {
+    const int r = b - nbig, bid = nbig + (r >> 1), half = r & 1;
+    int tile_m, tile_n;
+    if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
+    else           { tile_n = bid % ntn; tile_m = bid / ntn; }
+    const int m0 = tile_m * 128 + half * 64;
+    if (m0 >= Meff) return;
+    v2_tile<1, 1, false, NS, true>(d, m0, tile_n * 64, tile_n, Meff, smem);
+  }
+}
+
 // =========================================================================================
 // K-split variant of the 128x128 tile ("ks"): the four waves do not partition the tile, they partition K.
 //
@@ -701,6 +742,22 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
   }
 }
 
+// compute units of the current device (256 on MI355X); cached per device
+int device_cu_count() {
+  static std::mutex mu;
+  static std::vector<int> cus;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 256;
+  std::lock_guard<std::mutex> lock(mu);
+  if ((int)cus.size() <= dev) cus.resize(dev + 1, 0);
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: a process that drives several
 // devices (N contexts in N host threads, include/densecap.h) must raise it on each of them.  (device, kernel) pairs
 // already raised are remembered; a host mutex makes the table safe for one ctx per thread.
@@ -752,6 +809,18 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
       if (d.amax_cols % BN != 0 || (d.amax_cols > 0 && (d.C == nullptr || d.amax_n > d.amax_cols || d.amax_cols > d.N)))
         return hipErrorInvalidValue;
       const size_t lds3 = (size_t)3 * (BM + BN) * BK * sizeof(float);
+      if constexpr (TM == 2) {
+        // whole rounds as 128x64 tiles, the ragged last round as twice as many 64x64 tiles (see the mixed kernel)
+        const int total = ntm * ntn, slots = 2 * device_cu_count();
+        const int nbig = total / slots * slots, tail = total - nbig;
+        if (nbig > 0 && tail > 0 && 4 * tail <= 3 * slots) {
+          const void* fnm = reinterpret_cast<const void*>(&mfma_gemm_v2_amax_mixed_kernel<3>);
+          if (hipError_t e = ensure_dyn_lds(fnm, lds3); e != hipSuccess) return e;
+          hipLaunchKernelGGL((mfma_gemm_v2_amax_mixed_kernel<3>), dim3(nbig + 2 * tail), dim3(256), lds3, stream, d, ntm, ntn,
+                             m_fastest, nbig);
+          return hipGetLastError();
+        }
+      }
       const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, false, 3, true>);
       if (hipError_t e = ensure_dyn_lds(fn, lds3); e != hipSuccess) return e;
       hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, false, 3, true>), dim3(ntm * ntn), dim3(256), lds3, stream, d, ntm,

@@ -169,7 +169,7 @@ def test_errors_are_reported_not_thrown(model):
     with pytest.raises(DenseCapError):
         model.setTestArgs(num_proposals=0)
     with pytest.raises(DenseCapError):
-        model.setTestArgs(num_proposals=100000)
+        model.setTestArgs(num_proposals=2000000)
     model.setTestArgs(num_proposals=100)
     with pytest.raises(AssertionError):
         model.forward_raw(np.zeros((1, 4, 64, 64), np.float32))
