@@ -11,6 +11,9 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 CUSTOM = [tuple(int(v) for v in a.split(",")) for a in sys.argv[2:] if a.count(",") == 2]     # extra "M,N,K" shapes only
 ctx = Context(0)
 lib = ctx.lib
+if "--serial" in sys.argv:          # single-image mode: tail plans (K-split last round) are active, as in `bench.py --lanes 1`
+    check(ctx.h, lib.dc_set_lanes(ctx.h, 1))
+print("mode:", "serial (dc_set_lanes(1): tail plans on)" if "--serial" in sys.argv else "multi-lane planning (no tail plans)")
 
 def prof(reset):
     l = C.c_int64(0); ms = C.c_double(0); fl = C.c_double(0)
@@ -28,6 +31,7 @@ LIN = [("fc6", 1000, 4096, 25088), ("fc7", 1000, 4096, 4096), ("lm_enc", 1000, 5
 CONV = [("conv1_2", 600, 720, 64, 64), ("conv2_1", 300, 360, 64, 128), ("conv2_2", 300, 360, 128, 128),
         ("conv3_1", 150, 180, 128, 256), ("conv3_2", 150, 180, 256, 256), ("conv4_1", 75, 90, 256, 512),
         ("conv4_2", 75, 90, 512, 512), ("conv5_1", 38, 45, 512, 512), ("rpn_conv", 38, 45, 512, 256)]
+POOLED = {"conv1_2", "conv2_2", "conv3_2", "conv4_2"}       # (conv3_3 / conv4_3 have conv3_2 / conv4_2's shapes) also timed with the fused 2x2 ceil-mode pool epilogue (as the trunk runs them)
 if CUSTOM:
     LIN = [("%dx%dx%d" % c,) + c for c in CUSTOM]
     CONV = []
@@ -51,4 +55,13 @@ for name, H, Wd, Cin, Cout in CONV:
         check(ctx.h, lib.dc_op_conv3x3(ctx.h, A.ptr, W.ptr, b.ptr, Cc.ptr, 1, H, Wd, Cin, Cout, 1))
     l, ms, fl = prof(-1)
     print("%-10s %10.2f %10.1f %8.1f" % (name, fl / l / 1e9, ms / l * 1e3, fl / ms / 1e9))
+    if name in POOLED:
+        Cp = ctx.empty(((H + 1) // 2, (Wd + 1) // 2, Cout))
+        check(ctx.h, lib.dc_op_conv3x3_relu_pool(ctx.h, A.ptr, W.ptr, b.ptr, Cp.ptr, H, Wd, Cin, Cout))
+        prof(1)
+        for _ in range(reps):
+            check(ctx.h, lib.dc_op_conv3x3_relu_pool(ctx.h, A.ptr, W.ptr, b.ptr, Cp.ptr, H, Wd, Cin, Cout))
+        l, ms, fl = prof(-1)
+        print("%-10s %10.2f %10.1f %8.1f" % (name + "+pool", fl / l / 1e9, ms / l * 1e3, fl / ms / 1e9))
+        Cp.free()
     for x in (A, W, b, Cc): x.free()
