@@ -53,6 +53,13 @@ struct GemmDesc {
   // and writes its raw partial tile to splitk_ws[(slice*M + m)*N + n]; launch_splitk_reduce finishes the job
   int splitk = 1;
   float* splitk_ws = nullptr;
+  // stream-K over the tiles of rows [m_begin, M) (K-split kernel, launch_mfma_gemm_sk): sk_lo[0..sk_wgs] = unit offsets
+  // of the workgroups on the line of K units (unit = 2 K-tiles, sk_np units per tile, tiles n-fastest); sk_slots =
+  // sk_wgs partial tiles of 128x128 floats; sk_flags[0..sk_wgs) zeroed before the launch, sk_flags[-1] = fault word
+  const int* sk_lo = nullptr;
+  int sk_np = 0;
+  float* sk_slots = nullptr;
+  unsigned* sk_flags = nullptr;
   // row window (K-split kernel only): tiles cover rows [m_begin, M); a_rows = rows of the whole A operand
   // (extent of the conv input for the buffer descriptor) when M is only a prefix, 0 = M
   int m_begin = 0;
@@ -73,6 +80,11 @@ int mfma_gemm_splitk(const GemmDesc& d);
 // whole tiles (full rounds), rows [m_split, M) are split `tail_splitk` ways along K so the last partial round
 // fills the chip.  Returns false when it does not pay.
 bool mfma_gemm_tail_plan(const GemmDesc& d, int* m_split, int* tail_splitk);
+// Stream-K plan for the last, partial round of 128x128 tiles: rows [0, m_split) as whole tiles, the tiles of rows
+// [m_split, M) shared along K by `wgs` workgroups (np = K units per tile).  false when it does not pay.
+bool mfma_gemm_sk_plan(const GemmDesc& d, int* m_split, int* wgs, int* np);
+size_t mfma_gemm_sk_ws_floats(int wgs);
+hipError_t launch_mfma_gemm_sk(const GemmDesc& d, int wgs, int np, float* ws, hipStream_t stream);
 // force the K-split 128x128 kernel (honours m_begin / a_rows / splitk)
 hipError_t launch_mfma_gemm_ks(const GemmDesc& d, hipStream_t stream);
 // number of N-tiles launch_mfma_gemm will use for this problem (size of the arg-max partial rows)

@@ -93,6 +93,7 @@ struct dc_ctx {
   int beam_size = 0;         // 0 = greedy LM:sample; > 0 = LM:beamsearch (LanguageModel.lua:129-131)
   int64_t beam_chunk_floats = (int64_t)1 << 28;   // cap of the beam search's full-logits buffer (dc_debug_set)
   int decode_route = 0;      // 0 auto, 1 GEMM decode, 2 persistent LDS-resident decode (dc_debug_set)
+  int tail_mode = 0;         // partial last round in single-image mode: 0 stream-K, 1 K-split tail plan, 2 whole tiles (dc_debug_set)
   bool serial_mode = false;  // lanes == 1: idle CUs in a layer's last round are worth a tail split-K (dc_set_lanes)
   int num_proposals = 300;  // LocalizationLayer default (LocalizationLayer.lua:237); run_model sets 1000
   // dims
@@ -192,7 +193,22 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, float* ws = nullp
     if (e == hipSuccess)
       e = d.pool ? launch_splitk_reduce_pool(ws, sp, d.bias, d.C, 0, d.M, d.N, d.ldc, d.H, d.Wd, d.relu, s)
                  : launch_splitk_reduce(ws, sp, d.bias, d.C, d.M, d.N, d.ldc, d.relu, s);
-  } else if (ws_ok && ctx->serial_mode && mfma_gemm_tail_plan(d, &m_split, &tail_sp) &&
+  } else if (int sk_wgs = 0, sk_np = 0; ws_ok && ctx->serial_mode && ctx->tail_mode == 0 &&
+                                          mfma_gemm_sk_plan(d, &m_split, &sk_wgs, &sk_np) &&
+                                          mfma_gemm_sk_ws_floats(sk_wgs) <= ws_floats) {
+    // tile count not a multiple of the CU count: whole tiles for the full rounds, the last partial round shared evenly
+    // along K by all CUs (stream-K with in-kernel fix-up: no reduce launch, one partial tile per cut)
+    if (m_split > 0) {
+      GemmDesc a = d;
+      a.M = m_split; a.a_rows = d.M;
+      e = launch_mfma_gemm_ks(a, s);
+    }
+    if (e == hipSuccess) {
+      GemmDesc b = d;
+      b.m_begin = m_split; b.a_rows = d.M;
+      e = launch_mfma_gemm_sk(b, sk_wgs, sk_np, ws, s);
+    }
+  } else if (ws_ok && ctx->serial_mode && ctx->tail_mode <= 1 && mfma_gemm_tail_plan(d, &m_split, &tail_sp) &&
              (size_t)tail_sp * (d.M - m_split) * d.N <= ws_floats) {
     // tile count not a multiple of the CU count: whole tiles for the full rounds, K-split for the last one
     if (m_split > 0) {
@@ -1186,6 +1202,11 @@ int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value) {
   if (strcmp(name, "decode_route") == 0) {
     if (value < 0 || value > 2) return ctx->fail(DC_E_INVALID, "dc_debug_set: decode_route must be 0, 1 or 2");
     ctx->decode_route = (int)value;
+    return DC_OK;
+  }
+  if (strcmp(name, "tail_mode") == 0) {
+    if (value < 0 || value > 2) return ctx->fail(DC_E_INVALID, "dc_debug_set: tail_mode must be 0, 1 or 2");
+    ctx->tail_mode = (int)value;
     return DC_OK;
   }
   return ctx->fail(DC_E_INVALID, "dc_debug_set: unknown name '%s'", name);

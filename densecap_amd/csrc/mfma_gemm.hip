@@ -448,14 +448,15 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
   v2_tile<TM, TN, CONV, NS, AMAX>(d, m0, tile_n * (64 * TN), tile_n, Meff, smem);
 }
 
-// Decode-step GEMM with a FINER LAST ROUND.  The 128x64 tiles of one launch (1576 at 1000 rows x 12,608 columns) do not
+// 128x64-tile launches with a FINER LAST ROUND (the decode-step GEMM, conv1_2, conv2_1).  The 128x64 tiles of one launch
+// (decode step: 1576 at 1000 rows x 12,608 columns) do not
 // fill a whole number of rounds on the chip's 2 x 256 workgroup slots; the leftover tiles used to run one per CU while the
 // rest of the chip idled (the critical CU does 7 tiles against a mean of 6.16).  Here the first `nbig` tiles (whole rounds)
 // are 128x64 and each leftover tile is cut into two 64x64 tiles on the SAME launch -- twice the workgroups at half the
 // duration in the ragged round.  An element's K order does not depend on the tile it falls in (same fragment/lane walk
 // for every v2 shape), so results are bit-identical to the plain launch.
-template <int NS>
-__global__ __launch_bounds__(256) void mfma_gemm_v2_amax_mixed_kernel(GemmDesc d, int ntm, int ntn, int m_fastest, int nbig) {
+template <bool CONV, int NS, bool AMAX>
+__global__ __launch_bounds__(256) void mfma_gemm_v2_mixed_kernel(GemmDesc d, int ntm, int ntn, int m_fastest, int nbig) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int Meff = d.M;
   if (d.m_dev != nullptr) {
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_amax_mixed_kernel(GemmDesc d
     if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
     else           { tile_n = bid % ntn; tile_m = bid / ntn; }
     if (tile_m * 128 >= Meff) return;
-    v2_tile<2, 1, false, NS, true>(d, tile_m * 128, tile_n * 64, tile_n, Meff, smem);
+    v2_tile<2, 1, CONV, NS, AMAX>(d, tile_m * 128, tile_n * 64, tile_n, Meff, smem);
   } else {
     const int r = b - nbig, bid = nbig + (r >> 1), half = r & 1;
     int tile_m, tile_n;
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_amax_mixed_kernel(GemmDesc d
     else           { tile_n = bid % ntn; tile_m = bid / ntn; }
     const int m0 = tile_m * 128 + half * 64;
     if (m0 >= Meff) return;
-    v2_tile<1, 1, false, NS, true>(d, m0, tile_n * 64, tile_n, Meff, smem);
+    v2_tile<1, 1, CONV, NS, AMAX>(d, m0, tile_n * 64, tile_n, Meff, smem);
   }
 }
 
@@ -492,31 +493,22 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_amax_mixed_kernel(GemmDesc d
 // (fixed order ((w0+w1)+w2)+w3), one 64x64 quadrant per wave, and leave through the usual epilogue.
 // Because a tile's fragments are read during the previous tile's second half, a 2-stage ring is enough.
 // =========================================================================================
+// What a K segment of a 128x128 tile does with its result (stream-K, see mfma_gemm_sk_kernel): KS_NORMAL = the usual
+// epilogue (or the split-K partial store); KS_PUBLISH = the summed partial tile goes to this workgroup's slot in register
+// order, write-through, then its flag; KS_OWNER = the partial tiles of the `sk_npartner` workgroups after this one
+// (ascending K) are added to the own result in order, then the usual epilogue.
+enum { KS_NORMAL = 0, KS_PUBLISH = 1, KS_OWNER = 2 };
+constexpr int SK_SLOT_FLOATS = 128 * 128;
+constexpr unsigned SK_SPIN_LIMIT = 1u << 22;       // bounded: a partner that never shows up is reported, not waited for
+
+// One K segment [kt0, kt0+nkt) (nkt even) of the tile at (m0, n0).
 template <bool CONV>
-__global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
+__device__ __forceinline__ void ks_segment(const GemmDesc& d, const int m0, const int n0, const int Meff, const int slice,
+                                           const int kt0, const int nkt, const int mode, const int sk_wg,
+                                           const int sk_npartner, float* const smem) {
   constexpr int BM = 128, BN = 128;
   constexpr int PA = BM / 32, PB = BN / 32;
   constexpr int STAGE = (BM + BN) * BK;    // floats per ring stage
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-
-  const int nblk = ntm * ntn * d.splitk;
-  int bid = blockIdx.x;
-  {
-    const int q = nblk >> 3, rr = nblk & 7, x = bid & 7, o = bid >> 3;
-    bid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + o;
-  }
-  const int slice = bid % d.splitk;                  // K slice of this workgroup (split-K), fastest index
-  bid /= d.splitk;
-  int tile_m, tile_n;
-  if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
-  else           { tile_n = bid % ntn; tile_m = bid / ntn; }
-  const int m0 = d.m_begin + tile_m * BM, n0 = tile_n * BN;
-  int Meff = d.M;
-  if (d.m_dev != nullptr) {
-    const int me = *d.m_dev;
-    if (me < Meff) Meff = me;
-    if (m0 >= Meff) return;
-  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -625,9 +617,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
   };
 
-  // this workgroup's K range [kt0, kt0 + nkt) (the whole K unless split-K)
-  const int nkt = d.K / BK / d.splitk;
-  const int kt0 = slice * nkt;
+  // this segment's K range [kt0, kt0 + nkt)
   if constexpr (CONV) {
     const int cpt = d.Cin / BK;
     tap = kt0 / cpt;
@@ -682,6 +672,22 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
   // then ALL waves sum the four slots (fixed order ((w0+w1)+w2)+w3): wave w' takes register group e4 = w' of
   // the quadrant's four 32x32 tiles and stores bias/row-term/ReLU results (128-byte row segments).
   float* const slots = smem;                         // [4 waves][4 tiles][4 e4][64 lanes][4]
+  __amdgpu_buffer_rsrc_t rsrcP;                      // stream-K: this workgroup's partial-tile slot
+  if (mode == KS_PUBLISH)
+    rsrcP = __builtin_amdgcn_make_buffer_rsrc((void*)(d.sk_slots + (size_t)sk_wg * SK_SLOT_FLOATS), 0, SK_SLOT_FLOATS * 4, 0x00020000);
+  if (mode == KS_OWNER) {
+    // the partners' partial tiles: ONE lane polls their flags (relaxed), ONE agent acquire, then plain loads
+    if (tid == 0) {
+      for (int p = 1; p <= sk_npartner; ++p) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(d.sk_flags + sk_wg + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > SK_SPIN_LIMIT) { __hip_atomic_store(d.sk_flags - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+  }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -709,6 +715,18 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
           const f32x4 sw = *reinterpret_cast<const f32x4*>(slots + w * 4096 + off);
 #pragma unroll
           for (int c = 0; c < 4; ++c) s0[c] = s0[c] + sw[c];
+        }
+        if (mode != KS_NORMAL) {
+          const int sidx = ((q * 4 + (i * 2 + j)) * 4 + wid) * 256 + lane * 4;     // float index inside a slot
+          if (mode == KS_PUBLISH) {
+            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const __attribute__((ext_vector_type(4))) unsigned*>(&s0), rsrcP, sidx * 4, 0, 16);   // aux 16 = sc1: write-through
+            continue;
+          }
+          for (int p = 1; p <= sk_npartner; ++p) {                                  // ascending K: own (head) + partners in order
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(d.sk_slots + (size_t)(sk_wg + p) * SK_SLOT_FLOATS + sidx);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s0[c] = s0[c] + pv[c];
+          }
         }
         // registers e = 4*wid + c of tile (qi+i, qj+j): row = (e&3) + 8*(e>>2) + 4*hsel, col = lane&31
         const int col_l = (qj + j) * 32 + r;
@@ -739,6 +757,68 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
         }
       }
     __syncthreads();
+  }
+  if (mode == KS_PUBLISH) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its write-through stores
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(d.sk_flags + sk_wg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <bool CONV>
+__global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int bid = xcd_remap(blockIdx.x, ntm * ntn * d.splitk);
+  const int slice = bid % d.splitk;                  // K slice of this workgroup (split-K), fastest index
+  bid /= d.splitk;
+  int tile_m, tile_n;
+  if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
+  else           { tile_n = bid % ntn; tile_m = bid / ntn; }
+  const int m0 = d.m_begin + tile_m * 128, n0 = tile_n * 128;
+  int Meff = d.M;
+  if (d.m_dev != nullptr) {
+    const int me = *d.m_dev;
+    if (me < Meff) Meff = me;
+    if (m0 >= Meff) return;
+  }
+  const int nkt = d.K / BK / d.splitk;               // this workgroup's K range (the whole K unless split-K)
+  ks_segment<CONV>(d, m0, n0, Meff, slice, slice * nkt, nkt, KS_NORMAL, 0, 0, smem);
+}
+
+// =========================================================================================
+// Stream-K over the LAST, partial round of 128x128 tiles (single-image mode).  A layer whose tile count is not a multiple
+// of the CU count leaves CUs idle in its last round (conv4_x: 212 tiles on 256 CUs; conv3_x: 422 = 256 + 166).  The tiles
+// of that round (rows [m_begin, M), tile order n-fastest) are laid end to end as a line of K units (one unit = two K-tiles);
+// the line is cut into sk_wgs equal contiguous ranges, one per workgroup (d.sk_lo).  A range covers the tail of one tile
+// and/or the head of the next:
+//   * a segment that starts at K = 0 OWNS its tile: it adds the partial tiles of the workgroups that hold the rest of the
+//     tile's K range -- they come right after it on the line and computed their part EARLIER in their own time line, so
+//     the wait is normally empty -- in ascending K order and runs the epilogue;
+//   * every other segment publishes its partial tile (write-through stores, then a flag).
+// A tile's sum is thus a fixed function of the problem shape: own K range first, then the following ranges in order.
+// One workgroup per CU (the grid never exceeds the CU count), spins bounded (a timeout raises d.sk_flags[-1]).
+// =========================================================================================
+template <bool CONV>
+__global__ __launch_bounds__(256) void mfma_gemm_sk_kernel(GemmDesc d, int ntn) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int w = blockIdx.x, np = d.sk_np;
+  const int lo = d.sk_lo[w], hi = d.sk_lo[w + 1];
+  int u = lo;
+  while (u < hi) {
+    const int t = u / np, p0 = u - t * np;
+    const int p1 = min(np, p0 + (hi - u));
+    const int tile_n = t % ntn, tile_m = t / ntn;
+    const int m0 = d.m_begin + tile_m * 128, n0 = tile_n * 128;
+    int mode = KS_NORMAL, npartner = 0;
+    if (p0 > 0) mode = KS_PUBLISH;
+    else if (p1 < np) {
+      mode = KS_OWNER;                                  // workgroups w+1.. hold [p1, np) of this tile
+      const int tile_end = (t + 1) * np;
+      while (d.sk_lo[w + 1 + npartner] < tile_end) ++npartner;
+    }
+    ks_segment<CONV>(d, m0, n0, d.M, 0, 2 * p0, 2 * (p1 - p0), mode, w, npartner, smem);
+    u += p1 - p0;
+    __syncthreads();                                    // the LDS ring / slots are reused by the next segment
   }
 }
 
@@ -782,6 +862,20 @@ hipError_t ensure_dyn_lds(const void* fn, size_t bytes) {
   return e;
 }
 
+// 128x64 launches: whole rounds as 128x64 tiles, the ragged last round as twice as many 64x64 tiles (see the mixed kernel).
+// Returns hipErrorNotReady when the plain launch should be used (no ragged round worth splitting).
+template <bool CONV, bool AMAX>
+hipError_t launch_mixed(const GemmDesc& d, hipStream_t stream, int ntm, int ntn, int m_fastest, size_t lds) {
+  const int total = ntm * ntn, slots = 2 * device_cu_count();
+  const int nbig = total / slots * slots, tail = total - nbig;
+  if (nbig <= 0 || tail <= 0 || 4 * tail > 3 * slots) return hipErrorNotReady;
+  const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX>);
+  if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL((mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX>), dim3(nbig + 2 * tail), dim3(256), lds, stream, d, ntm, ntn,
+                     m_fastest, nbig);
+  return hipGetLastError();
+}
+
 template <int TM, int TN, bool CONV>
 hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -810,16 +904,7 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
         return hipErrorInvalidValue;
       const size_t lds3 = (size_t)3 * (BM + BN) * BK * sizeof(float);
       if constexpr (TM == 2) {
-        // whole rounds as 128x64 tiles, the ragged last round as twice as many 64x64 tiles (see the mixed kernel)
-        const int total = ntm * ntn, slots = 2 * device_cu_count();
-        const int nbig = total / slots * slots, tail = total - nbig;
-        if (nbig > 0 && tail > 0 && 4 * tail <= 3 * slots) {
-          const void* fnm = reinterpret_cast<const void*>(&mfma_gemm_v2_amax_mixed_kernel<3>);
-          if (hipError_t e = ensure_dyn_lds(fnm, lds3); e != hipSuccess) return e;
-          hipLaunchKernelGGL((mfma_gemm_v2_amax_mixed_kernel<3>), dim3(nbig + 2 * tail), dim3(256), lds3, stream, d, ntm, ntn,
-                             m_fastest, nbig);
-          return hipGetLastError();
-        }
+        if (hipError_t e = launch_mixed<false, true>(d, stream, ntm, ntn, m_fastest, lds3); e != hipErrorNotReady) return e;
       }
       const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, false, 3, true>);
       if (hipError_t e = ensure_dyn_lds(fn, lds3); e != hipSuccess) return e;
@@ -830,6 +915,9 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   }
   if (d.amax_val != nullptr) return hipErrorInvalidValue;
   const size_t lds = (size_t)3 * (BM + BN) * BK * sizeof(float);
+  if constexpr (TM == 2 && TN == 1) {
+    if (hipError_t e = launch_mixed<CONV, false>(d, stream, ntm, ntn, m_fastest, lds); e != hipErrorNotReady) return e;
+  }
   const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, CONV, 3>);
   if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, CONV, 3>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn,
@@ -922,6 +1010,82 @@ bool mfma_gemm_tail_plan(const GemmDesc& d, int* m_split, int* tail_splitk) {
   *m_split = (int)(rounds * 256 / ntn) * 128;       // rows covered by the full rounds (whole row-tiles: ntn | 256)
   *tail_splitk = best_s;
   return true;
+}
+
+// ---- stream-K plan -----------------------------------------------------------------------------------------------------
+// Rows [0, m_split) run as whole tiles in full rounds (launch_mfma_gemm_ks); the tiles of the last, partial round --
+// rows [m_split, M) -- are shared evenly by `wgs` workgroups along K (mfma_gemm_sk_kernel).  Returns false when the
+// problem has no partial round worth sharing.
+static const double kSkSegmentUs = 7.0;           // extra prologue + partial-tile publish / fetch of a cut tile
+bool mfma_gemm_sk_plan(const GemmDesc& d, int* m_split, int* wgs, int* np_out) {
+  if (d.amax_val != nullptr || d.rowterm != nullptr || d.m_dev != nullptr || d.N < 128 || d.N % 4) return false;
+  if (d.plan_M > 0 && d.plan_M != d.M) return false;      // groups of images: the doubled tile count quantises better as it is
+  if ((size_t)128 * d.K * 4 >= 0xfffffff0ull || (d.conv && (size_t)d.M * d.Cin * 4 >= CV_PAD)) return false;
+  const int G = device_cu_count();
+  const int ntm = (d.M + 127) / 128, ntn = (d.N + 127) / 128, nkt = d.K / BK;
+  if ((nkt & 1) || nkt < KS_MIN_KTILES || G % ntn) return false;
+  const long T = (long)ntm * ntn;
+  if (T < G / 2) return false;                      // few tiles: plain split-K (mfma_gemm_splitk) handles it
+  const long rounds = T / G, r = T % G;
+  if (r == 0) return false;
+  const int np = nkt / 2;
+  const long U = r * np;
+  long g = std::min<long>(G, U / 4);               // at least 4 units (8 K-tiles) per workgroup
+  if (g < 1) return false;
+  const double per = (double)((U + g - 1) / g) * 2.0 * kUsPerKtile + kSkSegmentUs;
+  if (per > 0.93 * nkt * kUsPerKtile) return false;   // the partial round as whole tiles is about as fast
+  *m_split = (int)(rounds * G / ntn) * 128;
+  *wgs = (int)g;
+  *np_out = np;
+  return true;
+}
+
+// device-resident unit offsets of a plan (they depend on the shape only): created once per (device, U, wgs)
+static const int* sk_plan_offsets(long U, int wgs) {
+  struct Ent { int dev; long U; int wgs; int* ptr; };
+  static std::mutex mu;
+  static std::vector<Ent> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  for (const Ent& e : cache)
+    if (e.dev == dev && e.U == U && e.wgs == wgs) return e.ptr;
+  std::vector<int> lo(wgs + 2);
+  for (int w = 0; w <= wgs; ++w) lo[w] = (int)((long)w * U / wgs);
+  lo[wgs + 1] = lo[wgs];                           // sentinel: the partner walk of the last workgroup stops here
+  int* p = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&p), lo.size() * sizeof(int)) != hipSuccess) return nullptr;
+  if (hipMemcpy(p, lo.data(), lo.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p); return nullptr; }
+  cache.push_back({dev, U, wgs, p});
+  return p;
+}
+
+size_t mfma_gemm_sk_ws_floats(int wgs) { return (size_t)wgs * SK_SLOT_FLOATS + 64 + (size_t)wgs; }
+
+// d: the whole problem with m_begin = m_split (rows [m_begin, M) are shared along K); ws >= mfma_gemm_sk_ws_floats(wgs)
+hipError_t launch_mfma_gemm_sk(const GemmDesc& d_in, int wgs, int np, float* ws, hipStream_t stream) {
+  GemmDesc d = d_in;
+  if (d.splitk != 1 || d.K % (2 * BK) || wgs < 1 || wgs > device_cu_count()) return hipErrorInvalidValue;
+  const int ntn = (d.N + 127) / 128, ntm = (d.M - d.m_begin + 127) / 128;
+  const long U = (long)ntm * ntn * np;
+  d.sk_lo = sk_plan_offsets(U, wgs);
+  if (d.sk_lo == nullptr) return hipErrorOutOfMemory;
+  d.sk_np = np;
+  d.sk_slots = ws;
+  d.sk_flags = reinterpret_cast<unsigned*>(ws + (size_t)wgs * SK_SLOT_FLOATS) + 16;     // [-1] = fault word
+  if (hipError_t e = hipMemsetAsync(d.sk_flags - 16, 0, (64 + (size_t)wgs) * sizeof(unsigned) - 0, stream); e != hipSuccess) return e;
+  const size_t lds_ks = (size_t)2 * (128 + 128) * BK * sizeof(float);
+  if (d.conv) {
+    if (d.Cin % BK != 0 || d.K != 9 * d.Cin) return hipErrorInvalidValue;
+    const void* fn = reinterpret_cast<const void*>(&mfma_gemm_sk_kernel<true>);
+    if (hipError_t e = ensure_dyn_lds(fn, lds_ks); e != hipSuccess) return e;
+    hipLaunchKernelGGL((mfma_gemm_sk_kernel<true>), dim3(wgs), dim3(256), lds_ks, stream, d, ntn);
+  } else {
+    const void* fn = reinterpret_cast<const void*>(&mfma_gemm_sk_kernel<false>);
+    if (hipError_t e = ensure_dyn_lds(fn, lds_ks); e != hipSuccess) return e;
+    hipLaunchKernelGGL((mfma_gemm_sk_kernel<false>), dim3(wgs), dim3(256), lds_ks, stream, d, ntn);
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_mfma_gemm_ks(const GemmDesc& d, hipStream_t stream) {

@@ -183,6 +183,9 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
  *                        chunks of max(64, cap / (beam * (V+1))) -- lets a test walk the chunk loop with few rows;
  *   "decode_route"       0 = automatic (default), 1 = always the GEMM decode, 2 = always the persistent LDS-resident
  *                        decode (rows <= 64 only; more rows fall back to the GEMM decode).
+ *   "tail_mode"          single-image mode (dc_set_lanes(1)), layers whose 128x128 tile count is not a multiple of the CU
+ *                        count: 0 = stream-K over the last round (default), 1 = K-split tail plan, 2 = whole tiles.  The
+ *                        three differ in the fp32 summation order of the affected rows (each one deterministic).
  * Returns DC_OK or DC_E_INVALID for an unknown name / bad value. */
 int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value);
 

@@ -118,6 +118,62 @@ def test_conv_splitk_and_tail_plans_single_lane(case):
         c.close()
 
 
+@pytest.mark.parametrize("case", [("conv2_2", 128, 300, 360, 128), ("conv3_1", 128, 150, 180, 256), ("conv3_2", 256, 150, 180, 256),
+                                  ("conv4_1", 256, 75, 90, 512), ("conv4_2", 512, 75, 90, 512),
+                                  ("webcam conv3_2", 256, 80, 120, 256), ("webcam conv2_2", 128, 160, 240, 128)])
+def test_streamk_last_round_all_routes(case):
+    """Single-image mode, layers whose 128x128 tile count is not a multiple of the CU count: the three routes of the
+    last partial round -- stream-K with in-kernel fix-up (default), the K-split tail plan, whole tiles (dc_debug_set
+    "tail_mode") -- each against fp64; stream-K three times over with fresh data in the same buffers (a stale partial tile
+    read across XCDs would show as a wrong block) and bit-identical to itself on a repeat."""
+    import torch
+    from densecap_amd import ops
+    from densecap_amd._lib import check
+    name, Cin, H, W, Cout = case
+    c = ops.Context(0)
+    try:
+        check(c.h, c.lib.dc_set_lanes(c.h, 1), "dc_set_lanes")
+        torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+        g = torch.Generator().manual_seed(Cin + H + Cout)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+        b = torch.randn(Cout, generator=g)
+        first = None
+        for rep in range(3):
+            x = torch.relu(torch.randn(1, Cin, H, W, generator=g)) * (1.0 + rep)
+            ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)).float().numpy()
+            for mode in ((0, 1, 2) if rep == 0 else (0,)):
+                check(c.h, c.lib.dc_debug_set(c.h, b"tail_mode", mode), "dc_debug_set")
+                out = ops.conv3x3(c, x.numpy(), w.numpy(), b.numpy(), relu=True)
+                _close(out, ref, rel=2e-5)
+                if mode == 0 and rep == 0:
+                    first = (x, out)
+            check(c.h, c.lib.dc_debug_set(c.h, b"tail_mode", 0), "dc_debug_set")
+        again = ops.conv3x3(c, first[0].numpy(), w.numpy(), b.numpy(), relu=True)
+        np.testing.assert_array_equal(again, first[1])
+    finally:
+        c.close()
+
+
+def test_streamk_dense_gemm_single_lane():
+    """The same machinery on a dense contraction whose tile count leaves a partial round: (6750, 512, 4608) = 212 tiles."""
+    from densecap_amd import ops
+    from densecap_amd._lib import check
+    c = ops.Context(0)
+    try:
+        check(c.h, c.lib.dc_set_lanes(c.h, 1), "dc_set_lanes")
+        M, N, K = 6750, 512, 4608
+        rng = np.random.default_rng(4)
+        x = rng.standard_normal((M, K)).astype(np.float32)
+        w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32)
+        ref = (x.astype(np.float64) @ w.astype(np.float64).T + b).astype(np.float32)
+        for mode in (0, 1, 2):
+            check(c.h, c.lib.dc_debug_set(c.h, b"tail_mode", mode), "dc_debug_set")
+            _close(ops.linear(c, x, w, b), ref, rel=2e-5)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("case", [(64, 150, 180, 64, 3), (64, 37, 53, 64, 3), (128, 75, 90, 128, 3), (32, 9, 11, 32, 3),
                                   (64, 301, 203, 64, 3),            # conv1_2-like, odd sizes: ceil-mode windows at both borders
                                   (128, 300, 360, 128, 1),          # conv2_2 at 720x600: tail plan (single-lane mode)

@@ -13,7 +13,11 @@ ctx = Context(0)
 lib = ctx.lib
 if "--serial" in sys.argv:          # single-image mode: tail plans (K-split last round) are active, as in `bench.py --lanes 1`
     check(ctx.h, lib.dc_set_lanes(ctx.h, 1))
-print("mode:", "serial (dc_set_lanes(1): tail plans on)" if "--serial" in sys.argv else "multi-lane planning (no tail plans)")
+for a in sys.argv:
+    if a.startswith("--tail-mode="):      # 0 stream-K (default), 1 K-split tail plan, 2 whole tiles
+        check(ctx.h, lib.dc_debug_set(ctx.h, b"tail_mode", int(a.split("=")[1])))
+print("mode:", "serial (dc_set_lanes(1): partial last rounds are shared along K)" if "--serial" in sys.argv else "multi-lane planning (whole tiles)",
+      [a for a in sys.argv if a.startswith("--tail-mode")])
 
 def prof(reset):
     l = C.c_int64(0); ms = C.c_double(0); fl = C.c_double(0)
