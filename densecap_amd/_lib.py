@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdensecap_hip.so")
+# DENSECAP_HIP_LIB: another build of the same library (the LuaJIT binding honours the same variable)
+LIB_PATH = os.environ.get("DENSECAP_HIP_LIB") or os.path.join(_HERE, "lib", "libdensecap_hip.so")
 
 DC_NUM_VGG_CONVS = 13
 c_float_p = C.POINTER(C.c_float)

@@ -689,6 +689,14 @@ __device__ __forceinline__ void ks_segment(const GemmDesc& d, const int m0, cons
     }
   }
   __syncthreads();
+  // stream-K owner: the first partner's partial tile (this thread's 16 pieces of it) is requested NOW, so that it travels
+  // during the LDS reduction below instead of costing one memory round trip per phase
+  f32x4 pre[16];
+  if (mode == KS_OWNER && sk_npartner >= 1) {
+    const float* ps = d.sk_slots + (size_t)(sk_wg + 1) * SK_SLOT_FLOATS + wid * 256 + lane * 4;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pre[k] = *reinterpret_cast<const f32x4*>(ps + k * 1024);
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int qi = (q >> 1) * 2, qj = (q & 1) * 2;   // quadrant q = accumulator tiles [qi..qi+1][qj..qj+1]
@@ -722,7 +730,12 @@ __device__ __forceinline__ void ks_segment(const GemmDesc& d, const int m0, cons
             __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const __attribute__((ext_vector_type(4))) unsigned*>(&s0), rsrcP, sidx * 4, 0, 16);   // aux 16 = sc1: write-through
             continue;
           }
-          for (int p = 1; p <= sk_npartner; ++p) {                                  // ascending K: own (head) + partners in order
+          // ascending K: own (head) + partners in order; the first partner's piece was prefetched
+          if (sk_npartner >= 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s0[c] = s0[c] + pre[q * 4 + i * 2 + j][c];
+          }
+          for (int p = 2; p <= sk_npartner; ++p) {
             const f32x4 pv = *reinterpret_cast<const f32x4*>(d.sk_slots + (size_t)(sk_wg + p) * SK_SLOT_FLOATS + sidx);
 #pragma unroll
             for (int c = 0; c < 4; ++c) s0[c] = s0[c] + pv[c];
@@ -1016,7 +1029,14 @@ bool mfma_gemm_tail_plan(const GemmDesc& d, int* m_split, int* tail_splitk) {
 // Rows [0, m_split) run as whole tiles in full rounds (launch_mfma_gemm_ks); the tiles of the last, partial round --
 // rows [m_split, M) -- are shared evenly by `wgs` workgroups along K (mfma_gemm_sk_kernel).  Returns false when the
 // problem has no partial round worth sharing.
-static const double kSkSegmentUs = 7.0;           // extra prologue + partial-tile publish / fetch of a cut tile
+// Measured on MI355X (profiles/r03_streamk_ablation.md): a cut tile costs ~33 us per workgroup on top of its K loop --
+// the second prologue and LDS reduction (~20 us) and, at the very end of the launch where nothing hides it, the owner's
+// fetch of its partner's partial tile (~11 us even with the prefetch).  So the partial round is shared along K only
+// where the K loop it saves is clearly longer than that: a layer with NO full round (conv4_2 / conv4_3 at 720x600:
+// 212 tiles of 144 K-tiles -> 120 K-tiles per CU, 311 -> 292 us).  Layers with full rounds before the partial one keep the
+// K-split tail plan (conv3_x: 304 vs 309 us), short K loops keep whole tiles (conv4_1: 165 vs 165 us).
+static const double kUsPerKtileMeasured = 2.16;   // one K-tile of the K-split kernel, one workgroup per CU, incl. its share of prologue/epilogue
+static const double kSkCutUs = 45.0;              // break-even saving of a cut (33 us measured + margin)
 bool mfma_gemm_sk_plan(const GemmDesc& d, int* m_split, int* wgs, int* np_out) {
   if (d.amax_val != nullptr || d.rowterm != nullptr || d.m_dev != nullptr || d.N < 128 || d.N % 4) return false;
   if (d.plan_M > 0 && d.plan_M != d.M) return false;      // groups of images: the doubled tile count quantises better as it is
@@ -1025,16 +1045,14 @@ bool mfma_gemm_sk_plan(const GemmDesc& d, int* m_split, int* wgs, int* np_out) {
   const int ntm = (d.M + 127) / 128, ntn = (d.N + 127) / 128, nkt = d.K / BK;
   if ((nkt & 1) || nkt < KS_MIN_KTILES || G % ntn) return false;
   const long T = (long)ntm * ntn;
-  if (T < G / 2) return false;                      // few tiles: plain split-K (mfma_gemm_splitk) handles it
-  const long rounds = T / G, r = T % G;
-  if (r == 0) return false;
+  if (T < G / 2 || T >= G) return false;            // few tiles: plain split-K; full rounds first: the K-split tail plan
   const int np = nkt / 2;
-  const long U = r * np;
-  long g = std::min<long>(G, U / 4);               // at least 4 units (8 K-tiles) per workgroup
+  const long U = T * np;
+  const long g = std::min<long>(G, U / 4);          // at least 4 units (8 K-tiles) per workgroup
   if (g < 1) return false;
-  const double per = (double)((U + g - 1) / g) * 2.0 * kUsPerKtile + kSkSegmentUs;
-  if (per > 0.93 * nkt * kUsPerKtile) return false;   // the partial round as whole tiles is about as fast
-  *m_split = (int)(rounds * G / ntn) * 128;
+  const double saved = ((double)nkt - 2.0 * (double)((U + g - 1) / g)) * kUsPerKtileMeasured;
+  if (saved < kSkCutUs) return false;
+  *m_split = 0;
   *wgs = (int)g;
   *np_out = np;
   return true;
