@@ -123,6 +123,31 @@ hipError_t launch_recog_heads(const float* codes, const float* w5 /*(5,D): obj, 
                               const float* roi_boxes, float* obj, float* trans, float* final_boxes, int n, int D,
                               hipStream_t s);
 
+// ---- persistent LDS-resident greedy decode for <= 64 rows (lm_persistent.hip; LanguageModel.lua:293-348) ------------
+struct LmPersistArgs {
+  const float* dec_w = nullptr;   // (V1pad + 4Hd, Hd): vocabulary rows, zero pad, then Wh^T (gate-major)
+  const float* out_b = nullptr;   // (V1)
+  const float* xg = nullptr;      // (V+2, 4Hd): b + Emb.Wx per token
+  const float* h0 = nullptr;      // (n, Hd) hidden state after the image step
+  const float* c0 = nullptr;      // (n, Hd) cell state after the image step
+  int32_t* seq = nullptr;         // (n, T) tokens out, 1-based
+  const int32_t* n_dev = nullptr; // optional device-side row count (<= n)
+  int n = 0, T = 0, V1 = 0, V1pad = 0;
+  // filled by the launcher from its scratch buffer
+  float* hbuf = nullptr;          // [2][64][Hd] h of the odd / even steps
+  unsigned long long* best = nullptr;   // [T+1][64] packed (logit key, ~column) arg-max per step and row
+  unsigned* sync = nullptr;       // [0] fault word, [16..) arrival counters
+  int nvocab_wg = 0, ngate_wg = 0;
+};
+size_t lm_persistent_scratch_bytes(int Hd, int T);
+bool lm_persistent_supported(int Hd, int V1pad, int n);
+// scratch: lm_persistent_scratch_bytes(Hd, T) device bytes (zeroed by the launcher where needed).  After the launch
+// scratch-relative word lm_persistent_fault_offset(...) is non-zero if the workgroups failed to rendezvous.
+hipError_t launch_lm_decode_persistent(LmPersistArgs a, int Hd, void* scratch, hipStream_t s);
+size_t lm_persistent_fault_offset(int Hd, int T);
+// hipFuncAttributeMaxDynamicSharedMemorySize per (device, kernel) -- mfma_gemm.hip
+hipError_t ensure_dyn_lds(const void* fn, size_t bytes);
+
 // ---- beam search row kernels (beam.hip; LanguageModel.lua:170-290) --------------------------
 size_t beam_topk_max_vocab();     // largest V+1 whose row fits the top-k kernel's LDS on the current device
 hipError_t launch_beam_logsoftmax_topk(const float* logits, int rows, int V1, int ld, const uint8_t* finished, int k,

@@ -71,6 +71,8 @@ struct Lane {
   float *bm_logits = nullptr, *bm_top_lp = nullptr, *bm_lp[2] = {nullptr, nullptr};
   int32_t *bm_top_idx = nullptr, *bm_beams[2] = {nullptr, nullptr}, *bm_parent = nullptr, *bm_tok = nullptr;
   uint8_t* bm_fin = nullptr;
+  void* pd_scratch = nullptr;           // persistent LDS-resident decode (<= 64 rows): h ping-pong, arg-max keys, counters
+  bool pd_used = false;                 // the in-flight forward took the persistent decode route (its fault word is checked)
   hipStream_t aux = nullptr;            // single-image mode: second half of the decode rows runs here
   hipStream_t aux2 = nullptr;           // single-image mode: the final NMS runs here, beside the decode
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
@@ -459,13 +461,51 @@ int lm_sample_parts(dc_ctx* ctx, Lane& L, const float* codes, const LmPart* part
   return DC_OK;
 }
 
+// <= 64 rows (webcam regime): ONE persistent launch for the T+1 LSTM steps with [Wout; Wh^T] resident in LDS
+// (lm_persistent.hip) after the encoder and the image step on the usual kernels.  Bit-identical tokens to the GEMM route.
+bool lm_use_persistent(const dc_ctx* ctx, int n) {
+  if (ctx->beam_size != 0 || ctx->decode_route == 1 || n > 64) return false;
+  return lm_persistent_supported(ctx->Hd, ctx->V1pad, n);
+}
+int lm_sample_persistent(dc_ctx* ctx, Lane& L, const float* codes, int r0, int n, const int32_t* n_dev, int32_t* seq_out,
+                         hipStream_t s, float* ws, size_t ws_floats) {
+  const int E = ctx->E, Hd = ctx->Hd, T = ctx->T, D = ctx->D;
+  if (L.pd_scratch == nullptr) HIPCHK(hipMalloc(&L.pd_scratch, lm_persistent_scratch_bytes(Hd, T)));
+  float* gates = L.gates + (size_t)r0 * 4 * Hd;
+  float* hstate = L.hstate + (size_t)r0 * Hd;
+  float* cstate = L.cstate + (size_t)r0 * Hd;
+  {  // image_encoder: Linear(4096,E)+ReLU (:27-30)
+    GemmDesc g;
+    g.A = codes + (size_t)r0 * D; g.W = ctx->enc_w; g.bias = ctx->enc_b; g.C = L.enc + (size_t)r0 * E;
+    g.M = n; g.N = E; g.K = D; g.ldc = E; g.relu = 1; g.m_dev = n_dev;
+    DCCHK(run_gemm(ctx, g, s, ws, ws ? ws_floats : 0));
+  }
+  {  // step 0: gates = (b + enc.Wx) + 0.Wh ; c0 = 0
+    GemmDesc g;
+    g.A = L.enc + (size_t)r0 * E; g.W = ctx->wxT; g.bias = ctx->lstm_b; g.C = gates;
+    g.M = n; g.N = 4 * Hd; g.K = E; g.ldc = 4 * Hd; g.m_dev = n_dev;
+    DCCHK(run_gemm(ctx, g, s));
+  }
+  KCHK(launch_lstm_step_tail(nullptr, nullptr, 0, 0, 0, nullptr, gates, cstate, hstate, n, n_dev, Hd, 1, nullptr, T, 0, s));
+  LmPersistArgs a;
+  a.dec_w = ctx->dec_w; a.out_b = ctx->out_b; a.xg = ctx->xg; a.h0 = hstate; a.c0 = cstate;
+  a.seq = seq_out + (size_t)r0 * T; a.n_dev = n_dev; a.n = n; a.T = T; a.V1 = ctx->V + 1; a.V1pad = ctx->V1pad;
+  KCHK(launch_lm_decode_persistent(a, Hd, L.pd_scratch, s));
+  L.pd_used = true;
+  return DC_OK;
+}
+
 // `plan`: rows of one image when n covers a group (0 = n); see GemmDesc::plan_M
 int lm_sample(dc_ctx* ctx, Lane& L, const float* codes, int n, int plan, const int32_t* n_dev, int32_t* seq_out) {
+  if (lm_use_persistent(ctx, n))
+    return lm_sample_persistent(ctx, L, codes, 0, n, n_dev, seq_out, L.stream, L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0);
   const LmPart whole{L.stream, 0, n, L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0};
   return lm_sample_parts(ctx, L, codes, &whole, 1, n_dev, seq_out, plan);
 }
 // decode rows [r0, r0+n) of the lane's buffers (codes / seq_out are the BASE pointers); n_dev: device row count
 int lm_sample_rows(dc_ctx* ctx, Lane& L, const float* codes, int r0, int n, const int32_t* n_dev, int32_t* seq_out) {
+  if (lm_use_persistent(ctx, n))
+    return lm_sample_persistent(ctx, L, codes, r0, n, n_dev, seq_out, L.stream, L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0);
   const LmPart part{L.stream, r0, n, L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0};
   return lm_sample_parts(ctx, L, codes, &part, 1, n_dev, seq_out, 0);
 }
@@ -581,6 +621,7 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
   if (img_on_device) HIPCHK(hipMemcpyAsync(L.img, img, g * img_elems * 4, hipMemcpyDeviceToDevice, s));
   else HIPCHK(hipMemcpyAsync(L.img, img, g * img_elems * 4, hipMemcpyHostToDevice, s));
   L.g = g;
+  L.pd_used = false;
   HIPCHK(hipEventRecord(L.ev[0], s));
   // ---- VGG-16 trunk (DenseCapModel.lua:73-76) -------------------------------------------
   int h = H, w = W, cur = 0;
@@ -692,6 +733,10 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
     char* hs = static_cast<char*>(L.host_stage) + i * stride;
     const size_t r0 = (size_t)i * P;
     HIPCHK(hipMemcpyAsync(hs, L.count2 + i * 64, 4, hipMemcpyDeviceToHost, s));
+    *reinterpret_cast<uint32_t*>(hs + 64) = 0;
+    if (L.pd_used)     // the persistent decode's fault word (bounded spins: a failed rendezvous is reported, not waited for)
+      HIPCHK(hipMemcpyAsync(hs + 64, static_cast<char*>(L.pd_scratch) + lm_persistent_fault_offset(ctx->Hd, ctx->T), 4,
+                            hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hs + 256, L.out_boxes + r0 * 4, (size_t)P * 16, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hs + 256 + (size_t)P * 16, L.out_scores + r0, (size_t)P * 4, hipMemcpyDeviceToHost, s));
     if (features_only)
@@ -719,6 +764,12 @@ int harvest(dc_ctx* ctx, Lane& L) {
   const size_t stride = host_stage_stride(ctx, P);
   for (int i = 0; i < L.g; ++i) {
     const char* hs = static_cast<const char*>(L.host_stage) + i * stride;
+    if (*reinterpret_cast<const uint32_t*>(hs + 64) != 0u) {
+      ctx->decode_route = 1;        // do not take the route again on this ctx
+      L.pending = nullptr;
+      return ctx->fail(DC_E_HIP, "persistent decode: its workgroups failed to rendezvous within the spin bound (GPU shared "
+                                 "with another job?); the GEMM decode will be used from now on -- repeat the call");
+    }
     int K = *reinterpret_cast<const int32_t*>(hs);
     if (L.pending_feats) {
       K = std::min(K, L.pending_capacity);
@@ -795,6 +846,7 @@ void dc_destroy(dc_ctx* ctx) {
     Lane& L = *lp;
     if (L.arena.p) hipFree(L.arena.p);
     if (L.beam_base) hipFree(L.beam_base);
+    if (L.pd_scratch) hipFree(L.pd_scratch);
     if (L.host_stage) hipHostFree(L.host_stage);
     for (auto& ev : L.ev) if (ev) hipEventDestroy(ev);
     if (L.ev_fork) hipEventDestroy(L.ev_fork);
@@ -1382,13 +1434,22 @@ int dc_op_lm_sample(dc_ctx* ctx, const float* codes, int n, int32_t* tokens) {
   L.cstate = (float*)p; p += al((size_t)n * Hd * 4);
   L.logits = (float*)p; p += al((size_t)n * V1 * 4);
   L.tok = (int32_t*)p;
+  L.pd_used = false;
   int rc = ctx->beam_size > 0 ? lm_beamsearch(ctx, L, codes, n, tokens, s) : lm_sample(ctx, L, codes, n, 0, nullptr, tokens);
   hipError_t e2 = hipStreamSynchronize(s);
+  uint32_t pd_fault = 0;
+  if (rc == DC_OK && e2 == hipSuccess && L.pd_used)
+    e2 = hipMemcpy(&pd_fault, static_cast<char*>(L.pd_scratch) + lm_persistent_fault_offset(ctx->Hd, ctx->T), 4, hipMemcpyDeviceToHost);
   L.enc = sv.enc; L.gates = sv.gates; L.hstate = sv.h; L.cstate = sv.c; L.logits = sv.logits; L.tok = sv.tok;
   hipFree(base);
   prof_collect(ctx);
   if (rc != DC_OK) return rc;
   if (e2 != hipSuccess) return ctx->fail(DC_E_HIP, "lm_sample sync: %s", hipGetErrorString(e2));
+  if (pd_fault != 0u) {
+    ctx->decode_route = 1;
+    return ctx->fail(DC_E_HIP, "persistent decode: its workgroups failed to rendezvous within the spin bound; the GEMM decode "
+                               "will be used from now on -- repeat the call");
+  }
   return DC_OK;
 }
 

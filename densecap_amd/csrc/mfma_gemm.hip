@@ -851,6 +851,8 @@ int device_cu_count() {
   return cus[dev];
 }
 
+}  // namespace
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: a process that drives several
 // devices (N contexts in N host threads, include/densecap.h) must raise it on each of them.  (device, kernel) pairs
 // already raised are remembered; a host mutex makes the table safe for one ctx per thread.
@@ -877,6 +879,8 @@ hipError_t ensure_dyn_lds(const void* fn, size_t bytes) {
 
 // 128x64 launches: whole rounds as 128x64 tiles, the ragged last round as twice as many 64x64 tiles (see the mixed kernel).
 // Returns hipErrorNotReady when the plain launch should be used (no ragged round worth splitting).
+namespace {
+
 template <bool CONV, bool AMAX>
 hipError_t launch_mixed(const GemmDesc& d, hipStream_t stream, int ntm, int ntn, int m_fastest, size_t lds) {
   const int total = ntm * ntn, slots = 2 * device_cu_count();

@@ -37,6 +37,8 @@ __global__ __launch_bounds__(256) void bilinear_roi_pool_kernel(const float* __r
   for (int v = blockIdx.x; v < B * split; v += gridDim.x) {
     const int b = v / split, part = v - b * split;
     const bool live = b < b_live;
+    if (!live) continue;          // boxes past the RPN NMS count: nothing downstream reads their rows (every consumer is
+                                  // bounded by the same device-side count), so they are neither sampled nor zero-filled
     __syncthreads();
     if (live && threadIdx.x < npts) {
       const int i = threadIdx.x / WW, j = threadIdx.x - i * WW;

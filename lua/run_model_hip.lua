@@ -1,44 +1,37 @@
 --[[
-run_model.lua with the model swapped for the MI355X path.  Differences from the reference's
-run_model.lua are the three marked lines; preprocessing (run_model.lua:67-74), result JSON
-(:89-95,:182-188) and flags are the reference's own.
+run_model.lua on the MI355X path, with EVERY flag of the reference script (-input_image, -input_dir, -input_split,
+-max_images, -output_dir, -output_vis, -output_vis_dir, -image_size, ... run_model.lua:26-61).
+
+Nothing of run_model.lua is restated here: the reference's own script is loaded as text, the two statements that
+choose the device and take the model out of the checkpoint are replaced, and the result is run with the caller's
+arguments.  These two substitutions are the whole integration (INTEGRATION.md section 2):
+
+  run_model.lua:146   local dtype, use_cudnn = utils.setup_gpus(opt.gpu, opt.use_cudnn)
+                  ->  local dtype, use_cudnn = 'torch.FloatTensor', false          -- host tensors stay float; no cutorch
+  run_model.lua:148   local model = checkpoint.model
+                  ->  local model = require('DenseCapModelHIP').fromCheckpoint(checkpoint.model, opt.gpu)
+
+usage (from the densecap checkout, lua/ on package.path, libdensecap_hip.so on the loader path or in DENSECAP_HIP_LIB):
+    th /path/to/lua/run_model_hip.lua -input_dir imgs -max_images 10 -output_vis_dir vis/data
+(No Lua runtime exists in the build container: the substitutions are checked against the reference text by
+tests/test_abi_and_host.py::test_lua_run_model_substitutions_match_the_reference.)
 --]]
-require 'torch'
-require 'nn'
-require 'image'
-require 'densecap.DenseCapModel'            -- needed to deserialise the checkpoint's classes
-local utils = require 'densecap.utils'
-local box_utils = require 'densecap.box_utils'
-local DenseCapModelHIP = require 'DenseCapModelHIP'   -- (1) new
+local path = os.getenv('DENSECAP_RUN_MODEL') or 'run_model.lua'
+local f = assert(io.open(path, 'r'), 'run_model_hip.lua: cannot open ' .. path .. ' (run from the densecap checkout or set DENSECAP_RUN_MODEL)')
+local src = f:read('*a')
+f:close()
 
-local cmd = torch.CmdLine()
-cmd:option('-checkpoint', 'data/models/densecap/densecap-pretrained-vgg16.t7')
-cmd:option('-image_size', 720)
-cmd:option('-rpn_nms_thresh', 0.7)
-cmd:option('-final_nms_thresh', 0.3)
-cmd:option('-num_proposals', 1000)
-cmd:option('-input_image', '')
-cmd:option('-gpu', 0)
-local opt = cmd:parse(arg)
+local SUBSTITUTIONS = {
+  {"local dtype, use_cudnn = utils%.setup_gpus%(opt%.gpu, opt%.use_cudnn%)",
+   "local dtype, use_cudnn = 'torch.FloatTensor', false"},
+  {"local model = checkpoint%.model",
+   "local model = require('DenseCapModelHIP').fromCheckpoint(checkpoint.model, opt.gpu)"},
+}
+for _, s in ipairs(SUBSTITUTIONS) do
+  local n
+  src, n = src:gsub(s[1], (s[2]:gsub('%%', '%%%%')))
+  assert(n == 1, 'run_model_hip.lua: expected exactly one match of "' .. s[1] .. '" in ' .. path .. ', found ' .. n)
+end
 
-local checkpoint = torch.load(opt.checkpoint)
-local model = DenseCapModelHIP.fromCheckpoint(checkpoint.model, opt.gpu)   -- (2) was: checkpoint.model
-model:convert('torch.FloatTensor', false)                                  -- (3) dtype is irrelevant
-model:setTestArgs{rpn_nms_thresh = opt.rpn_nms_thresh, final_nms_thresh = opt.final_nms_thresh,
-                  num_proposals = opt.num_proposals}
-model:evaluate()
-
-local img = image.load(opt.input_image, 3)
-img = image.scale(img, opt.image_size):float()
-local H, W = img:size(2), img:size(3)
-local img_caffe = img:view(1, 3, H, W)
-img_caffe = img_caffe:index(2, torch.LongTensor{3, 2, 1}):mul(255)
-local vgg_mean = torch.FloatTensor{103.939, 116.779, 123.68}
-img_caffe:add(-1, vgg_mean:view(1, 3, 1, 1):expand(1, 3, H, W))
-
-local boxes_xcycwh, scores, captions = model:forward_test(img_caffe)
-local boxes_xywh = box_utils.xcycwh_to_xywh(boxes_xcycwh)
-utils.write_json('vis/data/results.json', {
-  results = {{img_name = paths.basename(opt.input_image), boxes = boxes_xywh:totable(),
-              scores = scores:float():view(-1):totable(), captions = captions}},
-  opt = opt})
+local chunk = assert((loadstring or load)(src, '@' .. path .. ' (model swapped for DenseCapModelHIP)'))
+return chunk(...)

@@ -143,3 +143,23 @@ def test_lua_ffi_cdef_matches_the_header():
         return names
     for st in ("dc_weights", "dc_result"):
         assert fields(cdef, st) == fields(hdr, st), st
+
+
+def test_lua_run_model_substitutions_match_the_reference():
+    """lua/run_model_hip.lua runs the reference's own run_model.lua with two statements replaced (so every flag of
+    run_model.lua:26-61 is kept without restating the script).  No Lua here: check that each Lua pattern, read as the
+    literal it escapes, occurs exactly once in the reference script -- where the reference tree is present."""
+    ref = "/root/reference/run_model.lua"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present on this box")
+    lua = open(os.path.join(ROOT, "lua", "run_model_hip.lua")).read()
+    pats = re.findall(r'\{"((?:[^"\\]|\\.)*)",\s*\n\s*"((?:[^"\\]|\\.)*)"\}', lua)
+    assert len(pats) == 2
+    text = open(ref).read()
+    for pat, repl in pats:
+        literal = re.sub(r"%(.)", r"\1", pat)          # Lua escapes a magic character with %
+        assert text.count(literal) == 1, literal
+        assert "DenseCapModelHIP" in repl or "torch.FloatTensor" in repl
+    # the flags a user expects are the reference's own (they are never restated in our file)
+    for flag in ("-input_dir", "-max_images", "-output_vis_dir", "-input_split"):
+        assert flag in text and ("'%s'" % flag) not in lua
