@@ -135,8 +135,9 @@ struct LmPersistArgs {
   int n = 0, T = 0, V1 = 0, V1pad = 0;
   // filled by the launcher from its scratch buffer
   float* hbuf = nullptr;          // [2][64][Hd] h of the odd / even steps
-  unsigned long long* best = nullptr;   // [T+1][64] packed (logit key, ~column) arg-max per step and row
+  unsigned long long* best = nullptr;   // [T+1][8][64] packed (logit key, ~column) arg-max per step, XCD shard and row
   unsigned* sync = nullptr;       // [0] fault word, [16..) arrival counters
+  unsigned long long* trace = nullptr;  // [2][32][8] phase time stamps of one vocabulary / one gate workgroup (PD_TRACE builds)
   int nvocab_wg = 0, ngate_wg = 0;
 };
 size_t lm_persistent_scratch_bytes(int Hd, int T);
@@ -145,6 +146,7 @@ bool lm_persistent_supported(int Hd, int V1pad, int n);
 // scratch-relative word lm_persistent_fault_offset(...) is non-zero if the workgroups failed to rendezvous.
 hipError_t launch_lm_decode_persistent(LmPersistArgs a, int Hd, void* scratch, hipStream_t s);
 size_t lm_persistent_fault_offset(int Hd, int T);
+size_t lm_persistent_trace_offset(int Hd, int T);
 // hipFuncAttributeMaxDynamicSharedMemorySize per (device, kernel) -- mfma_gemm.hip
 hipError_t ensure_dyn_lds(const void* fn, size_t bytes);
 

@@ -94,7 +94,7 @@ struct dc_ctx {
   double host_enqueue_ms = 0;  // host ms per image spent enqueueing in the last dc_forward_batch
   int beam_size = 0;         // 0 = greedy LM:sample; > 0 = LM:beamsearch (LanguageModel.lua:129-131)
   int64_t beam_chunk_floats = (int64_t)1 << 28;   // cap of the beam search's full-logits buffer (dc_debug_set)
-  int decode_route = 0;      // 0 auto, 1 GEMM decode, 2 persistent LDS-resident decode (dc_debug_set)
+  int decode_route = 0;      // 0 / 1 GEMM decode (default), 2 persistent LDS-resident decode at <= 64 rows (dc_debug_set)
   int tail_mode = 0;         // partial last round in single-image mode: 0 stream-K, 1 K-split tail plan, 2 whole tiles (dc_debug_set)
   bool serial_mode = false;  // lanes == 1: idle CUs in a layer's last round are worth a tail split-K (dc_set_lanes)
   int num_proposals = 300;  // LocalizationLayer default (LocalizationLayer.lua:237); run_model sets 1000
@@ -463,8 +463,13 @@ int lm_sample_parts(dc_ctx* ctx, Lane& L, const float* codes, const LmPart* part
 
 // <= 64 rows (webcam regime): ONE persistent launch for the T+1 LSTM steps with [Wout; Wh^T] resident in LDS
 // (lm_persistent.hip) after the encoder and the image step on the usual kernels.  Bit-identical tokens to the GEMM route.
+// Measured (profiles/r03_persistent_decode.md): at <= 64 rows BOTH routes are bounded by the same thing -- the 256-long
+// chain of dependent v_mfma_f32_32x32x2_f32 on one accumulator block per wave (10.8 us a step; the K order is part of the
+// result, so the chain cannot be cut without changing tokens) -- and the persistent launch then pays two cross-XCD
+// hand-offs a step (~9 us) where the GEMM route pays two kernel boundaries (~6 us): 0.71 vs 0.66 ms per 50-row decode.
+// The persistent route is therefore OPT-IN (dc_debug_set "decode_route" = 2); the default stays the GEMM route.
 bool lm_use_persistent(const dc_ctx* ctx, int n) {
-  if (ctx->beam_size != 0 || ctx->decode_route == 1 || n > 64) return false;
+  if (ctx->beam_size != 0 || ctx->decode_route != 2 || n > 64) return false;
   return lm_persistent_supported(ctx->Hd, ctx->V1pad, n);
 }
 int lm_sample_persistent(dc_ctx* ctx, Lane& L, const float* codes, int r0, int n, const int32_t* n_dev, int32_t* seq_out,
@@ -1198,6 +1203,13 @@ int dc_mfma_profile(dc_ctx* ctx, int reset, int64_t* launches, double* total_ms,
 
 int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t capacity_bytes) {
   if (!ctx || !name || !host_buf) return DC_E_INVALID;
+  if (strcmp(name, "pd_trace") == 0) {       // phase time stamps of the last persistent decode (PD_TRACE builds only; else zeros)
+    if (ctx->lanes.empty()) return ctx->fail(DC_E_STATE, "no decode has run yet");
+    Lane& L0 = *ctx->lanes[0];
+    if (capacity_bytes < 2 * 32 * 8 * 8 || L0.pd_scratch == nullptr) return ctx->fail(DC_E_INVALID, "dc_debug_fetch: pd_trace needs 4096 bytes and a persistent decode");
+    HIPCHK(hipMemcpy(host_buf, static_cast<char*>(L0.pd_scratch) + lm_persistent_trace_offset(ctx->Hd, ctx->T), 2 * 32 * 8 * 8, hipMemcpyDeviceToHost));
+    return 2 * 32 * 8;
+  }
   if (ctx->lanes.empty() || !ctx->lanes[0]->arena.p) return ctx->fail(DC_E_STATE, "no forward has run yet");
   Lane& L = *ctx->lanes[0];
   const int P = L.P;

@@ -28,6 +28,7 @@ namespace {
 
 constexpr int PD_ROWS = 64;                 // rows one launch decodes
 constexpr int PD_COLS = 64;                 // weight rows (output columns) resident per workgroup
+constexpr int PD_SHARDS = 8;                // arg-max merge targets per (step, row): 165 atomics on one word cost ~5 us a step, 21 do not
 constexpr unsigned PD_SPIN_LIMIT = 1u << 21;
 
 __device__ __forceinline__ float pd_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
@@ -41,19 +42,20 @@ __device__ __forceinline__ unsigned long long pd_key(float v, int col) {
 
 // wait until *cnt >= target: ONE lane polls (relaxed, device scope), ONE agent acquire, workgroup barrier.
 // Returns false when the launch has been declared faulty (here or elsewhere).
+template <bool ACQUIRE = true>
 __device__ __forceinline__ bool pd_wait(unsigned* cnt, unsigned target, unsigned* fault, int* s_ok) {
   if (threadIdx.x == 0) {
     unsigned spins = 0;
     int ok = 1;
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
       if (++spins > PD_SPIN_LIMIT || __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
         __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = 0;
         break;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     *s_ok = ok;
   }
   __syncthreads();
@@ -65,6 +67,12 @@ __device__ __forceinline__ void pd_arrive(unsigned* cnt) {
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+#ifdef PD_TRACE
+#define PD_STAMP(slot) do { if (tid == 0 && (wg == 0 || gw == 0)) a.trace[((size_t)(is_vocab ? 0 : 1) * 32 + it) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define PD_STAMP(slot) do { } while (0)
+#endif
 
 template <int HD>
 __global__ __launch_bounds__(256) void lm_decode_persistent_kernel(LmPersistArgs a) {
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(256) void lm_decode_persistent_kernel(LmPersistArgs
   unsigned* const fault = a.sync;
   unsigned* const cnt_tok = a.sync + 16;                     // [T+2]
   unsigned* const cnt_h = a.sync + 16 + (T + 2);             // [T+2]
-  unsigned long long* const best = a.best;                   // [T+1][PD_ROWS]
+  unsigned long long* const best = a.best;                   // [T+1][PD_SHARDS][PD_ROWS]: one shard per XCD (block b runs on XCD b % 8)
 
   // ---- this workgroup's 64 weight rows -> LDS, once ------------------------------------------------------------------
   for (int idx = tid; idx < PD_COLS * (HD / 4); idx += 256) {
@@ -130,11 +138,27 @@ __global__ __launch_bounds__(256) void lm_decode_persistent_kernel(LmPersistArgs
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    PD_STAMP(0);
     if (compute) {
       if (it >= 1 && !pd_wait(cnt_h + it, (unsigned)a.ngate_wg, fault, s_ok)) return;      // h of this step has landed
+      PD_STAMP(1);
       if (wave_live) {
-        const float* hin = it == 0 ? a.h0 : a.hbuf + (size_t)(it & 1) * PD_ROWS * HD;
-        const float* ap = hin + (size_t)arow * HD + 4 * hsel;
+        // it == 0: h_0 comes row-major from the image step's tail kernel (a lane's 16-byte pieces are HD floats apart:
+        // 32 cache lines per wave load, paid once); later steps read hbuf in FRAGMENT order -- piece (row block wm,
+        // k-group i, half hsel, row r) at ((wm*NI + i)*2 + hsel)*32 + r -- so that one wave load is 1 KiB contiguous
+        const float* ap;
+        int astride;                                          // floats between consecutive k-groups of this lane
+#ifdef PD_ABL_ROWMAJOR
+        if (true) {
+#else
+        if (it == 0) {
+#endif
+          ap = (it == 0 ? a.h0 : a.hbuf + (size_t)(it & 1) * PD_ROWS * HD) + (size_t)arow * HD + 4 * hsel;
+          astride = 8;
+        } else {
+          ap = a.hbuf + (size_t)(it & 1) * PD_ROWS * HD + ((size_t)(wm * NI) * 2 + hsel) * 32 * 4 + r * 4;
+          astride = 2 * 32 * 4;
+        }
         const float* bp = wl + (wn * 32 + r) * PITCH + 4 * hsel;
         // The row's K = HD operand (HD/8 16-byte pieces per lane) arrives from L2 / the fabric (it was written by other
         // CUs a moment ago): pieces are requested two chunks (2 x 16 groups = ~3.5 us of MFMAs) ahead of their use.
@@ -143,14 +167,18 @@ __global__ __launch_bounds__(256) void lm_decode_persistent_kernel(LmPersistArgs
         f32x4 abuf[2][CH];
         auto load_chunk = [&](int c, int slot) {
 #pragma unroll
-          for (int i = 0; i < CH; ++i) abuf[slot][i] = *reinterpret_cast<const f32x4*>(ap + 8 * (c * CH + i));
+          for (int i = 0; i < CH; ++i) abuf[slot][i] = *reinterpret_cast<const f32x4*>(ap + (size_t)astride * (c * CH + i));
         };
         auto mfma_chunk = [&](int c, int slot) {
 #pragma unroll
           for (int i = 0; i < CH; ++i) {
             const f32x4 bf = *reinterpret_cast<const f32x4*>(bp + 8 * (c * CH + i));
 #pragma unroll
+#ifdef PD_ABL_NOMFMA
+            for (int e = 0; e < 1; ++e) acc[e] += bf[e] * abuf[slot][i][e];
+#else
             for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[e], abuf[slot][i][e], acc, 0, 0, 0);
+#endif
           }
         };
         load_chunk(0, 0);
@@ -165,6 +193,7 @@ __global__ __launch_bounds__(256) void lm_decode_persistent_kernel(LmPersistArgs
         }
       }
     }
+    PD_STAMP(2);
     if (is_vocab) {
       if (!compute) continue;
       // ---- row arg-max over this wave's 32 columns, merged across workgroups by one atomic max per (row, wave) ---------
@@ -180,22 +209,38 @@ __global__ __launch_bounds__(256) void lm_decode_persistent_kernel(LmPersistArgs
         const float ov = __shfl_xor(bv, 32, 64);
         const int oi = __shfl_xor(bi, 32, 64);
         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+#ifdef PD_ABL_NOATOMIC
+        if (hsel == 0 && row_live && bi != 0x7fffffff && wg == 0 && wn == 0)
+#else
         if (hsel == 0 && row_live && bi != 0x7fffffff)
-          __hip_atomic_fetch_max(best + (size_t)it * PD_ROWS + m, pd_key(bv, bi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+          __hip_atomic_fetch_max(best + ((size_t)it * PD_SHARDS + (wg & (PD_SHARDS - 1))) * PD_ROWS + m, pd_key(bv, bi),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      PD_STAMP(3);
       pd_arrive(cnt_tok + it);
+      PD_STAMP(4);
       continue;
     }
     // ---- gate workgroups ---------------------------------------------------------------------------------------------
     int tok = V1;                                             // it == 0: the START token (LanguageModel.lua:32,320)
     if (it >= 1) {
-      if (!pd_wait(cnt_tok + it, (unsigned)a.nvocab_wg, fault, s_ok)) return;              // every candidate is in
-      const unsigned long long k = __hip_atomic_load(best + (size_t)it * PD_ROWS + min(m, n - 1), __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
+      // every candidate is in; the keys are read with device-scope atomic loads (written by device-scope atomics): no
+      // acquire fence on this hop
+      if (!pd_wait<false>(cnt_tok + it, (unsigned)a.nvocab_wg, fault, s_ok)) return;
+      PD_STAMP(3);
+      unsigned long long k = 0ull;
+#pragma unroll
+      for (int sh = 0; sh < PD_SHARDS; ++sh) {
+        const unsigned long long ks = __hip_atomic_load(best + ((size_t)it * PD_SHARDS + sh) * PD_ROWS + min(m, n - 1),
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        k = ks > k ? ks : k;
+      }
       tok = (int)(~(unsigned)(k & 0xffffffffull)) + 1;
       if (gw == 0 && wn == 0 && hsel == 0 && row_live) a.seq[(size_t)m * T + (it - 1)] = tok;
       if (it == T) break;
     }
+    PD_STAMP(4);
     if (wave_live) {
       // gates = (b + x.Wx) + h.Wh (xg row of the token first, as the tail kernel of the GEMM route), [i f o g]
       const float* x = a.xg + (size_t)(tok - 1) * 4 * HD + unit0;
@@ -211,23 +256,36 @@ __global__ __launch_bounds__(256) void lm_decode_persistent_kernel(LmPersistArgs
         cst[c] = cn;
         hv[c] = og * tanhf(cn);
       }
-      if (row_live)                                           // write-through (sc1): readers on other XCDs need no release fence
+      if (row_live) {                                         // write-through (sc1): readers on other XCDs need no release fence
+#ifdef PD_ABL_ROWMAJOR
+        const size_t piece = ((size_t)m * HD + unit0) / 4;
+#else
+        const size_t piece = (((size_t)wm * NI + (unit0 >> 3)) * 2 + ((unit0 >> 2) & 1)) * 32 + r;     // fragment order
+#endif
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const __attribute__((ext_vector_type(4))) unsigned*>(&hv), rsrcH,
-                                               (int)((((size_t)((it + 1) & 1) * PD_ROWS + m) * HD + unit0) * sizeof(float)), 0, 16);
+                                               (int)(((size_t)((it + 1) & 1) * PD_ROWS * HD + piece * 4) * sizeof(float)), 0, 16);
+      }
     }
+    PD_STAMP(5);
     pd_arrive(cnt_h + it + 1);
+    PD_STAMP(6);
   }
 }
 
 }  // namespace
 
+size_t lm_persistent_fault_offset(int Hd, int T);
 size_t lm_persistent_scratch_bytes(int Hd, int T) {
-  return (size_t)2 * PD_ROWS * Hd * sizeof(float) + (size_t)(T + 1) * PD_ROWS * sizeof(unsigned long long) +
-         (size_t)(16 + 2 * (T + 2) + 16) * sizeof(unsigned);
+  return (size_t)2 * PD_ROWS * Hd * sizeof(float) + (size_t)(T + 1) * PD_SHARDS * PD_ROWS * sizeof(unsigned long long) +
+         (size_t)(16 + 2 * (T + 2) + 16) * sizeof(unsigned) + 2 * 32 * 8 * sizeof(unsigned long long);
+}
+
+size_t lm_persistent_trace_offset(int Hd, int T) {
+  return lm_persistent_fault_offset(Hd, T) + (size_t)(16 + 2 * (T + 2) + 16) * sizeof(unsigned);
 }
 
 size_t lm_persistent_fault_offset(int Hd, int T) {
-  return (size_t)2 * PD_ROWS * Hd * sizeof(float) + (size_t)(T + 1) * PD_ROWS * sizeof(unsigned long long);
+  return (size_t)2 * PD_ROWS * Hd * sizeof(float) + (size_t)(T + 1) * PD_SHARDS * PD_ROWS * sizeof(unsigned long long);
 }
 
 bool lm_persistent_supported(int Hd, int V1pad, int n) {
@@ -244,12 +302,13 @@ hipError_t launch_lm_decode_persistent(LmPersistArgs a, int Hd, void* scratch, h
   if (!lm_persistent_supported(Hd, a.V1pad, a.n)) return hipErrorInvalidValue;
   char* p = static_cast<char*>(scratch);
   a.hbuf = reinterpret_cast<float*>(p); p += (size_t)2 * PD_ROWS * Hd * sizeof(float);
-  a.best = reinterpret_cast<unsigned long long*>(p); p += (size_t)(a.T + 1) * PD_ROWS * sizeof(unsigned long long);
-  a.sync = reinterpret_cast<unsigned*>(p);
+  a.best = reinterpret_cast<unsigned long long*>(p); p += (size_t)(a.T + 1) * PD_SHARDS * PD_ROWS * sizeof(unsigned long long);
+  a.sync = reinterpret_cast<unsigned*>(p); p += (size_t)(16 + 2 * (a.T + 2) + 16) * sizeof(unsigned);
+  a.trace = reinterpret_cast<unsigned long long*>(p);
   a.nvocab_wg = a.V1pad / PD_COLS;
   a.ngate_wg = 4 * Hd / PD_COLS;
   // every polled word starts from zero on EVERY launch (best[] is an atomic-max target: zero = below every key)
-  const size_t zero_bytes = (size_t)(a.T + 1) * PD_ROWS * sizeof(unsigned long long) + (size_t)(16 + 2 * (a.T + 2) + 16) * sizeof(unsigned);
+  const size_t zero_bytes = (size_t)(a.T + 1) * PD_SHARDS * PD_ROWS * sizeof(unsigned long long) + (size_t)(16 + 2 * (a.T + 2) + 16) * sizeof(unsigned);
   if (hipError_t e = hipMemsetAsync(a.best, 0, zero_bytes, s); e != hipSuccess) return e;
   const size_t lds = (size_t)PD_COLS * (Hd + 8) * sizeof(float) + 64;
   const void* fn = reinterpret_cast<const void*>(&lm_decode_persistent_kernel<512>);

@@ -181,8 +181,9 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
 /* Test hooks (never needed for correct results; every setting gives the same outputs bit for bit):
  *   "beam_chunk_floats"  cap, in floats, of the beam search's full-logits buffer (default 2^28): proposals advance in
  *                        chunks of max(64, cap / (beam * (V+1))) -- lets a test walk the chunk loop with few rows;
- *   "decode_route"       0 = automatic (default), 1 = always the GEMM decode, 2 = always the persistent LDS-resident
- *                        decode (rows <= 64 only; more rows fall back to the GEMM decode).
+ *   "decode_route"       0 / 1 = the GEMM decode (default), 2 = the persistent LDS-resident decode (one launch for all
+ *                        T+1 LSTM steps, [Wout; Wh^T] resident in LDS) wherever it applies: greedy decode of <= 64 rows,
+ *                        rnn_size 512.  Tokens are bit-identical on both routes; measured no faster.
  *   "tail_mode"          single-image mode (dc_set_lanes(1)), layers whose 128x128 tile count is not a multiple of the CU
  *                        count: 0 = stream-K over the last round (default), 1 = K-split tail plan, 2 = whole tiles.  The
  *                        three differ in the fp32 summation order of the affected rows (each one deterministic).

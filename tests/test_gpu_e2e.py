@@ -651,8 +651,8 @@ def test_large_image_beyond_65536_anchors(model, weights):
 
 
 def test_persistent_decode_equals_gemm_decode(model, weights):
-    """<= 64 rows take the persistent LDS-resident decode (lm_persistent.hip: one launch for all T+1 steps, [Wout; Wh^T]
-    resident in LDS, device-wide hand-offs per step); dc_debug_set("decode_route", 1) forces the GEMM route.  Same MFMA
+    """dc_debug_set("decode_route", 2): <= 64 rows take the persistent LDS-resident decode (lm_persistent.hip: one launch for
+    all T+1 steps, [Wout; Wh^T] resident in LDS, device-wide hand-offs per step); 1 (or the default 0) = the GEMM route.  Same MFMA
     chain per element, same association, same tie rule: the two routes must give IDENTICAL tokens -- at every row count
     around the 32-row block boundary, call after call (the polled words are re-zeroed per launch)."""
     import ctypes as C
@@ -664,17 +664,18 @@ def test_persistent_decode_equals_gemm_decode(model, weights):
             codes = np.maximum(rng.standard_normal((n, 4096)), 0).astype(np.float32)
             cd = ctx.to_device(codes); td = ctx.empty((n, 15), np.int32)
             outs = {}
-            for route in (1, 0, 0, 0):
+            for route in (1, 2, 2, 2):
                 check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", route), "dc_debug_set")
                 check(ctx.h, ctx.lib.dc_op_lm_sample(ctx.h, cd.ptr, n, td.ptr), "dc_op_lm_sample")
                 outs.setdefault(route, []).append(td.numpy().copy())
-            for t in outs[0]:
+            for t in outs[2]:
                 np.testing.assert_array_equal(t, outs[1][0], err_msg="persistent decode != GEMM decode at %d rows" % n)
             assert outs[1][0].min() >= 1 and outs[1][0].max() <= weights["vocab_size"] + 1
             cd.free(); td.free()
-        # 65 rows: beyond the persistent kernel's block -> the GEMM route on both settings
+        # 65 rows: beyond the persistent kernel's block -> the GEMM route whatever the setting
         codes = np.maximum(rng.standard_normal((65, 4096)), 0).astype(np.float32)
         cd = ctx.to_device(codes); td = ctx.empty((65, 15), np.int32)
+        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 2), "dc_debug_set")
         check(ctx.h, ctx.lib.dc_op_lm_sample(ctx.h, cd.ptr, 65, td.ptr), "dc_op_lm_sample")
         assert td.numpy().min() >= 1
     finally:
@@ -683,7 +684,7 @@ def test_persistent_decode_equals_gemm_decode(model, weights):
 
 def test_webcam_regime_forward_both_decode_routes(model, weights):
     """forward_test at the webcam settings (480 px, 50 proposals, single_machine_demo.lua:25-26), single-image mode: the
-    persistent decode route (default at <= 64 rows) against the oracle (every stage), and bit-identical to the GEMM route --
+    persistent decode route (decode_route = 2) against the oracle (every stage), and bit-identical to the GEMM route --
     also with captions after the final NMS (device-side row count) and for a pair of images in one group."""
     from densecap_amd._lib import check
     from densecap_amd.weights import make_synthetic_image
@@ -692,12 +693,13 @@ def test_webcam_regime_forward_both_decode_routes(model, weights):
     img = make_synthetic_image(320, 480, 31)
     try:
         model.setLanes(1)
+        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 2), "dc_debug_set")
         r = parity.strict_check(model, weights, img, 50)
         assert r["K"] > 0 and r["matched"] == r["K_oracle"]
         for order in (False, True):
             model.setCaptionOrder(order)
             model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=50)
-            check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 0), "dc_debug_set")
+            check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 2), "dc_debug_set")
             a = model.forward_raw(img)
             check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 1), "dc_debug_set")
             b = model.forward_raw(img)
@@ -705,9 +707,10 @@ def test_webcam_regime_forward_both_decode_routes(model, weights):
                 np.testing.assert_array_equal(x, y)
             assert len(a[0]) > 0
         model.setCaptionOrder(False)
-        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 0), "dc_debug_set")
+        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 2), "dc_debug_set")
         model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=30)
         imgs = np.stack([make_synthetic_image(320, 480, 40 + s) for s in range(2)])
+        model.setLanes(3)                                   # (group invariance is a multi-lane property: single-image mode re-plans the last tile round)
         model.setGroup(2)                                   # 2 x 30 rows in one persistent launch
         pair = model.forward_batch(imgs)
         model.setGroup(0)
