@@ -69,8 +69,10 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float* __restrict
   static_assert(COUT == 64, "two 32-channel accumulator blocks");
   constexpr int TR = 4, TC = 32, PR = TR + 2, PC = TC + 2, KP = 28;
   __shared__ float patch[3 * PR * PC];
-  __shared__ float wsm[4 * 32 * 68];                 // weights (64 x 27 floats) first, then the output transpose tiles
-  static_assert(4 * 32 * 68 >= COUT * 27, "weights fit in the transpose buffer");
+  constexpr int OP = 72;                             // transpose-tile pitch in floats: the two lane halves write pixel rows 4
+                                                     // apart, 4*72 = 32 (mod 64) banks apart -> no write conflicts (68 had 2-way)
+  __shared__ float wsm[4 * 32 * OP];                 // weights (64 x 27 floats) first, then the output transpose tiles
+  static_assert(4 * 32 * OP >= COUT * 27, "weights fit in the transpose buffer");
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, hsel = lane >> 5;
   const int x0 = blockIdx.x * TC, y0 = blockIdx.y * TR;
@@ -111,10 +113,10 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float* __restrict
   }
   // Epilogue.  C/D map of the 32x32 MFMA: col (channel) = lane&31, row (pixel) = (e&3) + 8*(e>>2) + 4*hsel.  The wave's
   // result -- 32 consecutive pixels x 64 channels -- is ONE contiguous 8 KiB run of the channels-last output, so it is
-  // transposed through LDS ([pixel][64 + 4 pad] floats) and leaves as 16-byte stores, 1 KiB contiguous per instruction
+  // transposed through LDS ([pixel][64 + 8 pad] floats) and leaves as 16-byte stores, 1 KiB contiguous per instruction
   // (dword stores in MFMA order reach ~2.5 TB/s on this 110 MB store-bound kernel).
   __syncthreads();                                   // all waves are done with the patch / weights
-  float* ot = wsm + wid * (32 * 68);
+  float* ot = wsm + wid * (32 * OP);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const float bv = bias[r + 32 * j];
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float* __restrict
     for (int e = 0; e < 16; ++e) {
       float v = acc[j][e] + bv;
       if (relu) v = v > 0.f ? v : 0.f;
-      ot[((e & 3) + 8 * (e >> 2) + 4 * hsel) * 68 + r + 32 * j] = v;
+      ot[((e & 3) + 8 * (e >> 2) + 4 * hsel) * OP + r + 32 * j] = v;
     }
   }
   // (same wave reads what it wrote: no barrier needed, the LDS ops of a wave complete in order)
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float* __restrict
     const int px = idx >> 4, c4 = idx & 15;
     const int x = x0 + px;
     if (x < W) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(ot + px * 68 + c4 * 4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ot + px * OP + c4 * 4);
       *reinterpret_cast<f32x4*>(out + ((size_t)y * W + x) * COUT + c4 * 4) = v;
     }
   }

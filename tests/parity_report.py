@@ -14,7 +14,8 @@ from tests import parity  # noqa: E402
 W = make_synthetic_weights(seed=1234)
 m = DenseCapModel(W, device=0)
 rows = []
-SETTINGS = [(600, 720, 1000, 0), (600, 720, 1000, 1), (600, 720, 300, 2), (720, 1080, 2000, 5), (480, 720, 1000, 7)]
+SETTINGS = [(600, 720, 1000, 0), (600, 720, 1000, 1), (600, 720, 300, 2), (720, 1080, 2000, 5), (480, 720, 1000, 7),
+            (320, 480, 50, 8), (1200, 1600, 1000, 9)]
 SETTINGS += [(600, 720, 1000, sd) for sd in range(10, 10 + int(os.environ.get("PARITY_EXTRA", "0")))]
 for (H, Wd, P, seed) in SETTINGS:
     r = dict(H=H, W=Wd, P=P, seed=seed)

@@ -9,9 +9,8 @@ REPO=$(pwd)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-# one stream throughout (the un-timed setup/warm-up images would otherwise use the two-stream decode of single-image mode)
-export DENSECAP_NO_DECODE_SPLIT=1
-BENCH="python $REPO/bench.py --lanes 1 --no-cpu-baseline --no-alt-pass"
+# one lane = one stream for the profiled images (per-launch events switch the two-stream decode off); the short legs only
+BENCH="python $REPO/bench.py --lanes 1 --no-cpu-baseline --no-alt-pass --sustain-seconds 0"
 run() {  # name, bench args, rocprof args...
   local name=$1 args=$2; shift 2
   rm -rf /tmp/rp_$name
@@ -25,13 +24,19 @@ run write "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc WRITE_SIZE
 run mfma "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT
 # the DEFAULT (multi-lane) schedule -- the one the headline number comes from -- under the kernel trace as well
 # (rocprofv3 serialises dispatches, so the overlap itself is not visible; per-kernel durations and counts are)
-unset DENSECAP_NO_DECODE_SPLIT
-BENCH="python $REPO/bench.py --no-cpu-baseline --no-alt-pass"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-alt-pass --sustain-seconds 0"
 run default "--steps 10 --warmup 3 --repeats 2" --kernel-trace --stats
 grep '^{' /tmp/rp_default.json > "$OUT/bench_default_under_rocprof.json"
 cd "$REPO"
 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-python bench.py --height 320 --width 480 --proposals 50 --lanes 1 --steps 30 --no-cpu-baseline --no-alt-pass > "$OUT/bench_webcam_480_p50.json" 2>/dev/null
-python bench.py --proposals 300 --steps 32 --no-cpu-baseline > "$OUT/bench_config3_p300.json" 2>/dev/null
-python bench.py --height 720 --width 1080 --proposals 2000 --steps 12 --warmup 2 --no-cpu-baseline > "$OUT/bench_config5.json" 2>/dev/null
+Q="--no-cpu-baseline --sustain-seconds 2 --repeats 3"
+python bench.py --height 320 --width 480 --proposals 50 --lanes 1 --steps 30 --no-alt-pass $Q > "$OUT/bench_webcam_480_p50.json" 2>/dev/null
+python bench.py --height 480 --width 720 --proposals 1000 --steps 32 $Q > "$OUT/bench_config0_720x480.json" 2>/dev/null
+python bench.py --proposals 300 --steps 32 $Q > "$OUT/bench_config3_p300.json" 2>/dev/null
+python bench.py --height 720 --width 1080 --proposals 2000 --steps 12 --warmup 2 $Q > "$OUT/bench_config5.json" 2>/dev/null
+python tools/gemm_bench.py 5 --serial > "$OUT/gemm_bench_serial.txt" 2>/dev/null
+python tools/gemm_bench.py 5 > "$OUT/gemm_bench_multilane.txt" 2>/dev/null
+python tools/decode_bench.py 20 1000 300 50 > "$OUT/decode_bench.txt" 2>/dev/null
+PARITY_EXTRA=8 python tests/parity_report.py > "$OUT/parity_report.log" 2>&1
+cp gpurun_out/parity_report.json "$OUT/parity_report.json" 2>/dev/null
 ls -la "$OUT"

@@ -80,7 +80,8 @@ def main():
         summ["_commit"] = None
     json.dump(summ, open(prefix + "_pmc_summary.json", "w"), indent=1)
     for extra in ("default_kernel_stats.csv", "bench_default_under_rocprof.json", "bench_default.json",
-                  "bench_webcam_480_p50.json", "bench_config3_p300.json", "bench_config5.json"):
+                  "bench_webcam_480_p50.json", "bench_config3_p300.json", "bench_config5.json", "bench_config0_720x480.json",
+                  "gemm_bench_serial.txt", "gemm_bench_multilane.txt", "decode_bench.txt", "parity_report.json"):
         if os.path.exists(os.path.join(d, extra)):
             shutil.copy(os.path.join(d, extra), prefix + "_" + extra.replace("default_kernel_stats", "kernel_stats_default_lanes"))
     for f, e in summ.items():
