@@ -1004,11 +1004,15 @@ bool mfma_gemm_tail_plan(const GemmDesc& d, int* m_split, int* tail_splitk) {
   if (d.plan_M > 0 && d.plan_M != d.M) return false;      // groups of images: the doubled tile count quantises better as it is
   if ((size_t)128 * d.K * 4 >= 0xfffffff0ull || (d.conv && (size_t)d.M * d.Cin * 4 >= CV_PAD)) return false;
   const int ntm = (d.M + 127) / 128, ntn = (d.N + 127) / 128, nkt = d.K / BK;
-  if ((nkt & 1) || nkt < 16 || 256 % ntn) return false;
+  // the K-split kernel's domain only: below KS_MIN_KTILES the 128x64 kernel is the faster one (conv2_1, K = 576: a tail
+  // plan used to force it onto the K-split kernel in single-image mode, 205 vs 167 us)
+  if ((nkt & 1) || nkt < KS_MIN_KTILES || 256 % ntn) return false;
   const long T = (long)ntm * ntn;
-  if (T < 128) return false;                        // few tiles: plain split-K (mfma_gemm_splitk) handles it
   const long rounds = T / 256, r = T % 256;
-  if (r == 0) return false;
+  // Measured (profiles/r03_streamk_ablation.md): the plan pays only behind at least one full round and with a sizeable
+  // remainder -- 844 tiles (r = 76): 351 -> 317 us, 422 tiles (r = 166): 319 -> 300 us; 300 tiles (r = 44, 480x320
+  // conv2_2): 108 -> 134 us, 150 tiles and no full round (480x320 conv3_2): 118 -> 130 us
+  if (rounds < 1 || r < 64) return false;
   const double t_tile = nkt * kUsPerKtile;
   const double base = t_tile;                       // the partial round as whole tiles
   double best = base;
@@ -1054,6 +1058,8 @@ bool mfma_gemm_sk_plan(const GemmDesc& d, int* m_split, int* wgs, int* np_out) {
   const long U = T * np;
   const long g = std::min<long>(G, U / 4);          // at least 4 units (8 K-tiles) per workgroup
   if (g < 1) return false;
+  if (4 * ((U + g - 1) / g) < 3 * (long)np) return false;   // ranges shorter than 3/4 of a tile cut tiles in three: the owner then
+                                                    // waits on a partner that finishes with it (480x320 conv3_2: 118 -> 128 us)
   const double saved = ((double)nkt - 2.0 * (double)((U + g - 1) / g)) * kUsPerKtileMeasured;
   if (saved < kSkCutUs) return false;
   *m_split = 0;
