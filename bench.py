@@ -27,8 +27,8 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 HBM_PEAK_GBPS = 8000.0
-PMC_PROFILE = os.path.join("profiles", "r02_pmc_summary.json")
-PARITY_REPORT = os.path.join("profiles", "r02_parity_report.json")
+PMC_PROFILE = os.path.join("profiles", "r03_pmc_summary.json")
+PARITY_REPORT = os.path.join("profiles", "r03_parity_report.json")
 
 VGG = [(3, 64, 0), (64, 64, 1), (64, 128, 0), (128, 128, 1), (128, 256, 0), (256, 256, 0), (256, 256, 1),
        (256, 512, 0), (512, 512, 0), (512, 512, 1), (512, 512, 0), (512, 512, 0), (512, 512, 0)]
@@ -421,6 +421,13 @@ def main():
             all(np.array_equal(x, y) for x, y in zip(gathered[r][i], ref.forward_batch_device([r * n_img + i], 1, H, W)[0]))
             for r in range(world) for i in range(K))
         assert gather_order_verified, "gather delivered records in a wrong order"
+    host_enqueue_us = None
+    if on_gpu:
+        try:       # host time spent enqueueing one image of the last timed region (the N-GPU ceiling is 1 / this per rank)
+            he, _ = model.debug_fetch("host_enqueue_us", (1,), np.int32)
+            host_enqueue_us = int(he[0])
+        except Exception:
+            pass
     order = sorted(range(len(elapsed_all)), key=lambda i: elapsed_all[i])
     elapsed = elapsed_all[order[len(order) // 2]]          # median repeat
     nrep = len(elapsed_all)
@@ -606,6 +613,7 @@ def main():
                                  "note": "latency-bound by construction (greedy dependency chain), see DESIGN.md 4.2"}
             out["hbm_stages"] = hb
             out["lanes"] = args.lanes
+            out["host_enqueue_us_per_image"] = host_enqueue_us
             if lane_trials is not None:
                 out["lanes_trial_images_per_s"] = {str(k): v for k, v in lane_trials.items()}
             if alt is not None:
@@ -646,7 +654,9 @@ def main():
                     "file": PARITY_REPORT, "images": len(rep),
                     "final_lists_identical": sum(1 for r in rep if not r.get("final_list_flips") and not r.get("token_near_ties")
                                                  and r.get("matched") == r.get("K_oracle") == r.get("K")),
-                    "near_tie_departures": sum(len(r.get("final_list_flips", [])) + len(r.get("token_near_ties", [])) for r in rep),
+                    "images_with_replayed_rpn_decisions": sum(1 for r in rep if r.get("rpn_flips")),
+                    "replayed_final_nms_decisions": sum(r.get("final_list_flips_n", len(r.get("final_list_flips", []))) for r in rep),
+                    "token_near_ties": sum(len(r.get("token_near_ties", [])) for r in rep),
                     "decode_rows": sum(r.get("decode_rows", 0) for r in rep),
                     "decode_rows_identical": sum(r.get("decode_rows_identical", 0) for r in rep)}
             except Exception:

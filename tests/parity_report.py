@@ -20,6 +20,10 @@ SETTINGS += [(600, 720, 1000, sd) for sd in range(10, 10 + int(os.environ.get("P
 for (H, Wd, P, seed) in SETTINGS:
     r = dict(H=H, W=Wd, P=P, seed=seed)
     r.update(parity.strict_check(m, W, make_synthetic_image(H, Wd, seed), P))
+    for key in ("rpn_flips", "final_list_flips"):          # keep the count, and the first few decisions as examples
+        if key in r:
+            r[key + "_n"] = len(r[key])
+            r[key] = r[key][:4]
     rows.append(r)
     print(json.dumps(r, default=str), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

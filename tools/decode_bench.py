@@ -18,6 +18,13 @@ ctx = m.ctx
 if "--gemm-route" in sys.argv:          # force the GEMM decode also at <= 64 rows
     check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 1), "dc_debug_set")
 rng = np.random.default_rng(0)
+beam = 0
+for a in sys.argv:
+    if a.startswith("--beam="):          # LM:beamsearch with that many beams instead of the greedy LM:sample
+        beam = int(a.split("=")[1])
+        m.setBeamSize(beam)
+if beam:
+    print("beam search, %d beams (all proposals advance together: rows = proposals x beams)" % beam)
 for n in rows:
     codes = np.maximum(rng.standard_normal((n, 4096)), 0).astype(np.float32)
     cd = ctx.to_device(codes); td = ctx.empty((n, 15), np.int32)
