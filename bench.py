@@ -370,6 +370,10 @@ def main():
             dist.broadcast(lt, src=0)
             args.lanes = int(lt.item())
             model.setLanes(args.lanes)
+    if on_gpu and args.lanes == 1:
+        # per-launch events from the first image on: the whole invocation stays on ONE stream (single-image mode would run
+        # the un-timed setup / warm-up images with the two-stream decode and leave their kernels in a rocprofv3 trace)
+        model.mfma_profile(reset=1)
     model.forward_batch_device(imgs, min(args.lanes, n_img), H, W)
     wres = model.forward_batch_device(imgs, max(Wm, 1), H, W)
     if dist is not None:
