@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 from densecap_amd import DenseCapModel  # noqa: E402
+from densecap_amd._lib import check  # noqa: E402
 from densecap_amd.weights import make_synthetic_image, make_synthetic_weights  # noqa: E402
 from tests import parity  # noqa: E402
 
@@ -24,9 +25,15 @@ def main(n_cases, seed):
         P = int(rng.choice([1, 2, 7, 50, 64, 65, 128, 300, 1000, -1]))
         rthr = float(rng.choice([0.0, 0.3, 0.7, 1.0])); fthr = float(rng.choice([-1.0, 0.0, 0.3, 0.5, 1.0]))
         lanes = int(rng.choice([1, 3])); order = bool(rng.integers(0, 2))
+        if rng.integers(0, 6) == 0:          # now and then an image large enough for full tile rounds + a partial one
+            H = int(rng.integers(420, 760)); Wd = int(rng.integers(520, 1000))
+        route = int(rng.choice([0, 2])); tail = int(rng.choice([0, 1, 2]))      # round-3 routes: every one must match the oracle
         img = make_synthetic_image(H, Wd, 1000 + case)
         m.setLanes(lanes); m.setCaptionOrder(order)
-        rec = dict(case=case, H=H, W=Wd, P=P, rpn_thr=rthr, final_thr=fthr, lanes=lanes, caption_after_nms=order)
+        check(m.ctx.h, m.ctx.lib.dc_debug_set(m.ctx.h, b"decode_route", route), "dc_debug_set")
+        check(m.ctx.h, m.ctx.lib.dc_debug_set(m.ctx.h, b"tail_mode", tail), "dc_debug_set")
+        rec = dict(case=case, H=H, W=Wd, P=P, rpn_thr=rthr, final_thr=fthr, lanes=lanes, caption_after_nms=order,
+                   decode_route=route, tail_mode=tail)
         try:
             # stage tensors are only inspected in the reference caption order (the device "seq" buffer is filled there)
             rec.update(parity.strict_check(m, W, img, P, rpn_thr=rthr, final_thr=fthr, stages=not order))
