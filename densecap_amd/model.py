@@ -57,6 +57,7 @@ class DenseCapModel:
         self.vocab_size = int(weights["vocab_size"])
         self.seq_length = int(weights["seq_length"])
         self.idx_to_token = weights.get("idx_to_token")
+        self.captions_after_final_nms = False
         self._keep = []  # host arrays referenced by the struct during dc_load_weights
         w = DcWeights()
 
@@ -128,6 +129,7 @@ class DenseCapModel:
         """False (default): decode all proposals then NMS, as the reference does.  True: final NMS first,
         decode only the survivors (bit-identical outputs, less LSTM work)."""
         check(self.ctx.h, self.lib.dc_set_caption_order(self.ctx.h, int(bool(after_final_nms))), "dc_set_caption_order")
+        self.captions_after_final_nms = bool(after_final_nms)
         return self
 
     def setGroup(self, images):

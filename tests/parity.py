@@ -249,6 +249,22 @@ def strict_check(model, weights, img, P, rpn_thr=0.7, final_thr=0.3, T=None, sta
             return compare_final(O, weights, hip, ora, st, final_thr, T, report)
         except NeedsStageProof:
             pass                                   # a departure: the stage data below are needed to replay it
+    restore_order = bool(getattr(model, "captions_after_final_nms", False))
+    if restore_order:
+        # the stage buffers (the pre-NMS token rows above all) are only filled in the reference caption order: run the image
+        # again in that order -- same outputs bit for bit, asserted -- and inspect that run
+        model.setCaptionOrder(False)
+        again = model.forward_raw(img)
+        for x, y in zip(again, hip):
+            np.testing.assert_array_equal(x, y, err_msg="caption order changed the outputs")
+    try:
+        return _strict_check_stages(model, weights, img, P, rpn_thr, final_thr, T, O, torch, hip, ora, st, report)
+    finally:
+        if restore_order:
+            model.setCaptionOrder(True)
+
+
+def _strict_check_stages(model, weights, img, P, rpn_thr, final_thr, T, O, torch, hip, ora, st, report):
     H, W = img.shape[1:]
     fh, fw = st["feat"].shape[1:]
     k = O.DEFAULT_ANCHORS.shape[1]
