@@ -306,6 +306,27 @@ def main():
     comm = None
     gather_note = None
 
+    abandoned = []     # carriers stuck in a call that never returned: never closed, the process leaves through os._exit
+
+    def guarded(fn, what, timeout=90.0):
+        """Run a carrier call that has never executed on this kind of hardware before (RCCL point-to-point inside
+        libdensecap_hip.so) in a daemon thread: a call that HANGS must cost the carrier, not the measurement.  Returns
+        (result, error); error is an exception or a TimeoutError."""
+        import threading
+        box = {}
+
+        def run():
+            try:
+                box["v"] = fn()
+            except Exception as e:       # noqa: BLE001
+                box["e"] = e
+        th = threading.Thread(target=run, daemon=True)
+        th.start()
+        th.join(timeout)
+        if th.is_alive():
+            return None, TimeoutError("%s did not return within %.0f s" % (what, timeout))
+        return box.get("v"), box.get("e")
+
     def all_ranks_ok(ok):
         t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -335,10 +356,10 @@ def main():
         idt = idt.to(coll_device) if coll_device is not None else idt
         dist.broadcast(idt, src=0)                       # rendezvous id of the RCCL communicator, out of band
         if all_ranks_ok(err is None):
-            try:
-                comm = D.Comm(ctx, rank, world, bytes(idt.cpu().numpy().tobytes()))
-            except Exception as e:
-                err = e
+            idb = bytes(idt.cpu().numpy().tobytes())
+            comm, err = guarded(lambda: D.Comm(ctx, rank, world, idb), "dc_comm_create (ncclCommInitRank)")
+            if isinstance(err, TimeoutError):
+                abandoned.append("dc_comm_create")
         if not all_ranks_ok(comm is not None):
             # The measurement must not be lost to the carrier: say so loudly and carry the same records over
             # torch.distributed instead (the line's config.gather records which carrier ran and why).
@@ -380,13 +401,13 @@ def main():
         # communicator / buffer setup of the first collective is not part of a step; a carrier that fails here is replaced
         warm = ([wres[0]] * K)[:K]
         if comm is not None:
-            err = None
-            try:
-                gather(warm)
-            except Exception as e:
-                err = e
+            _, err = guarded(lambda: gather(warm), "dc_gather_results (warm-up)")
+            stuck = isinstance(err, TimeoutError)
             if not all_ranks_ok(err is None):
-                comm.close()
+                if stuck:
+                    abandoned.append(comm)        # a thread is still inside it: never touch it again
+                else:
+                    comm.close()
                 comm = None
                 gather_note = "dc_gather_results failed in the warm-up (%s)" % (err if err is not None else "on another rank")
                 print("bench.py[rank %d]: WARNING: %s -- gathering with torch.distributed.gather instead" % (rank, gather_note),
@@ -675,6 +696,9 @@ def main():
         comm.close()
     if dist is not None:
         dist.barrier()
+        if abandoned:
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)                   # a carrier call never returned on this rank: no orderly teardown possible
         dist.destroy_process_group()
 
 
