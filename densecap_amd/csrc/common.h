@@ -55,11 +55,13 @@ struct GemmDesc {
   float* splitk_ws = nullptr;
   // stream-K over the tiles of rows [m_begin, M) (K-split kernel, launch_mfma_gemm_sk): sk_lo[0..sk_wgs] = unit offsets
   // of the workgroups on the line of K units (unit = 2 K-tiles, sk_np units per tile, tiles n-fastest); sk_slots =
-  // sk_wgs partial tiles of 128x128 floats; sk_flags[0..sk_wgs) zeroed before the launch, sk_flags[-1] = fault word
+  // sk_wgs partial tiles of 128x128 floats; sk_flags[0..sk_wgs) zeroed before the launch; sk_fault = sticky device word
+  // raised when an owner gives up waiting for a partner (checked by the host with the results)
   const int* sk_lo = nullptr;
   int sk_np = 0;
   float* sk_slots = nullptr;
   unsigned* sk_flags = nullptr;
+  unsigned* sk_fault = nullptr;
   // row window (K-split kernel only): tiles cover rows [m_begin, M); a_rows = rows of the whole A operand
   // (extent of the conv input for the buffer descriptor) when M is only a prefix, 0 = M
   int m_begin = 0;

@@ -95,6 +95,7 @@ struct dc_ctx {
   int beam_size = 0;         // 0 = greedy LM:sample; > 0 = LM:beamsearch (LanguageModel.lua:129-131)
   int64_t beam_chunk_floats = (int64_t)1 << 28;   // cap of the beam search's full-logits buffer (dc_debug_set)
   int decode_route = 0;      // 0 / 1 GEMM decode (default), 2 persistent LDS-resident decode at <= 64 rows (dc_debug_set)
+  uint32_t* fault_dev = nullptr;   // sticky device word: a stream-K owner gave up waiting for its partner (checked with the results)
   int tail_mode = 0;         // partial last round in single-image mode: 0 stream-K, 1 K-split tail plan, 2 whole tiles (dc_debug_set)
   bool serial_mode = false;  // lanes == 1: idle CUs in a layer's last round are worth a tail split-K (dc_set_lanes)
   int num_proposals = 300;  // LocalizationLayer default (LocalizationLayer.lua:237); run_model sets 1000
@@ -208,6 +209,11 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, float* ws = nullp
     if (e == hipSuccess) {
       GemmDesc b = d;
       b.m_begin = m_split; b.a_rows = d.M;
+      if (ctx->fault_dev == nullptr && hipMalloc(reinterpret_cast<void**>(&ctx->fault_dev), 64) == hipSuccess) {
+        ctx->owned.push_back(ctx->fault_dev);
+        (void)hipMemset(ctx->fault_dev, 0, 64);
+      }
+      b.sk_fault = ctx->fault_dev;
       e = launch_mfma_gemm_sk(b, sk_wgs, sk_np, ws, s);
     }
   } else if (ws_ok && ctx->serial_mode && ctx->tail_mode <= 1 && mfma_gemm_tail_plan(d, &m_split, &tail_sp) &&
@@ -739,6 +745,8 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
     const size_t r0 = (size_t)i * P;
     HIPCHK(hipMemcpyAsync(hs, L.count2 + i * 64, 4, hipMemcpyDeviceToHost, s));
     *reinterpret_cast<uint32_t*>(hs + 64) = 0;
+    *reinterpret_cast<uint32_t*>(hs + 68) = 0;
+    if (ctx->fault_dev != nullptr) HIPCHK(hipMemcpyAsync(hs + 68, ctx->fault_dev, 4, hipMemcpyDeviceToHost, s));
     if (L.pd_used)     // the persistent decode's fault word (bounded spins: a failed rendezvous is reported, not waited for)
       HIPCHK(hipMemcpyAsync(hs + 64, static_cast<char*>(L.pd_scratch) + lm_persistent_fault_offset(ctx->Hd, ctx->T), 4,
                             hipMemcpyDeviceToHost, s));
@@ -769,6 +777,13 @@ int harvest(dc_ctx* ctx, Lane& L) {
   const size_t stride = host_stage_stride(ctx, P);
   for (int i = 0; i < L.g; ++i) {
     const char* hs = static_cast<const char*>(L.host_stage) + i * stride;
+    if (*reinterpret_cast<const uint32_t*>(hs + 68) != 0u) {
+      (void)hipMemset(ctx->fault_dev, 0, 64);
+      ctx->tail_mode = 1;           // stop sharing tiles between workgroups on this ctx
+      L.pending = nullptr;
+      return ctx->fail(DC_E_HIP, "stream-K: a workgroup's partner never published its partial tile within the spin bound (GPU "
+                                 "shared with another job?); this ctx now uses the K-split tail plan -- repeat the call");
+    }
     if (*reinterpret_cast<const uint32_t*>(hs + 64) != 0u) {
       ctx->decode_route = 1;        // do not take the route again on this ctx
       L.pending = nullptr;
@@ -1305,6 +1320,18 @@ int dc_synchronize(dc_ctx* ctx) {
   return DC_OK;
 }
 
+
+// stream-K fault word after a synchronised per-op call
+static int check_sk_fault(dc_ctx* ctx, const char* who) {
+  if (ctx->fault_dev == nullptr) return DC_OK;
+  uint32_t f = 0;
+  if (hipMemcpy(&f, ctx->fault_dev, 4, hipMemcpyDeviceToHost) != hipSuccess) return ctx->fail(DC_E_HIP, "%s: fault word read failed", who);
+  if (f == 0) return DC_OK;
+  (void)hipMemset(ctx->fault_dev, 0, 64);
+  ctx->tail_mode = 1;
+  return ctx->fail(DC_E_HIP, "%s: stream-K partner never published its partial tile within the spin bound", who);
+}
+
 // ---- per-op entry points --------------------------------------------------------------------
 #define OP_PROLOGUE()                         \
   if (!ctx) return DC_E_INVALID;              \
@@ -1338,7 +1365,7 @@ int dc_op_conv3x3(dc_ctx* ctx, const float* in, const float* w, const float* b, 
   prof_collect(ctx);
   if (rc != DC_OK) return rc;
   if (e2 != hipSuccess) return ctx->fail(DC_E_HIP, "dc_op_conv3x3 sync: %s", hipGetErrorString(e2));
-  return DC_OK;
+  return check_sk_fault(ctx, "dc_op_conv3x3");
 }
 int dc_op_conv3x3_relu_pool(dc_ctx* ctx, const float* in, const float* w, const float* b, float* out, int H, int W,
                             int Cin, int Cout) {
@@ -1353,7 +1380,7 @@ int dc_op_conv3x3_relu_pool(dc_ctx* ctx, const float* in, const float* w, const 
   prof_collect(ctx);
   if (rc != DC_OK) return rc;
   if (e2 != hipSuccess) return ctx->fail(DC_E_HIP, "dc_op_conv3x3_relu_pool sync: %s", hipGetErrorString(e2));
-  return DC_OK;
+  return check_sk_fault(ctx, "dc_op_conv3x3_relu_pool");
 }
 int dc_op_conv3x3_c3(dc_ctx* ctx, const float* in, const float* w, const float* b, float* out, int H, int W, int Cout,
                      int relu) {
@@ -1377,7 +1404,7 @@ int dc_op_linear(dc_ctx* ctx, const float* A, const float* W, const float* bias,
   prof_collect(ctx);
   if (rc != DC_OK) return rc;
   if (e2 != hipSuccess) return ctx->fail(DC_E_HIP, "dc_op_linear sync: %s", hipGetErrorString(e2));
-  return DC_OK;
+  return check_sk_fault(ctx, "dc_op_linear");
 }
 int dc_op_make_anchors(dc_ctx* ctx, float* out, int h, int w, float x0, float y0, float sx, float sy,
                        const float* anchors_dev, int k) {

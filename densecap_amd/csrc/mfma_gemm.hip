@@ -682,7 +682,10 @@ __device__ __forceinline__ void ks_segment(const GemmDesc& d, const int m0, cons
         unsigned spins = 0;
         while (__hip_atomic_load(d.sk_flags + sk_wg + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
           __builtin_amdgcn_s_sleep(4);
-          if (++spins > SK_SPIN_LIMIT) { __hip_atomic_store(d.sk_flags - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          if (++spins > SK_SPIN_LIMIT) {          // the partner never published: report it (sticky word the host checks), do not hang
+            if (d.sk_fault != nullptr) __hip_atomic_store(d.sk_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -809,7 +812,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
 //     the wait is normally empty -- in ascending K order and runs the epilogue;
 //   * every other segment publishes its partial tile (write-through stores, then a flag).
 // A tile's sum is thus a fixed function of the problem shape: own K range first, then the following ranges in order.
-// One workgroup per CU (the grid never exceeds the CU count), spins bounded (a timeout raises d.sk_flags[-1]).
+// One workgroup per CU (the grid never exceeds the CU count), spins bounded (a timeout raises the sticky word d.sk_fault,
+// which the host checks with the results: DC_E_HIP instead of a hang or silently wrong tiles).
 // =========================================================================================
 template <bool CONV>
 __global__ __launch_bounds__(256) void mfma_gemm_sk_kernel(GemmDesc d, int ntn) {
