@@ -129,7 +129,7 @@ int dc_forward_images(dc_ctx* ctx, const float* const* imgs, const int* H, const
                       dc_result* outs);
 /* Number of lanes (HIP streams with private workspaces, 1..4, default 3) dc_forward_batch
  * pipelines images over.  1 = single-image mode (lowest latency for one image at a time): a layer's last
- * partial round of tiles is K-split over the idle CUs (a different but fixed fp32 summation order) and the decode
+ * partial round of tiles may be shared along K by the idle CUs (a different but fixed fp32 summation order) and the decode
  * rows advance as two blocks on two streams (same arithmetic per row); per-kernel profiling (dc_mfma_profile)
  * keeps every kernel on one stream.  Results are bit-identical for a given lanes setting however images are batched. */
 int dc_set_lanes(dc_ctx* ctx, int lanes);
@@ -185,8 +185,9 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
  *                        T+1 LSTM steps, [Wout; Wh^T] resident in LDS) wherever it applies: greedy decode of <= 64 rows,
  *                        rnn_size 512.  Tokens are bit-identical on both routes; measured no faster.
  *   "tail_mode"          single-image mode (dc_set_lanes(1)), layers whose 128x128 tile count is not a multiple of the CU
- *                        count: 0 = stream-K over the last round (default), 1 = K-split tail plan, 2 = whole tiles.  The
- *                        three differ in the fp32 summation order of the affected rows (each one deterministic).
+ *                        count: 0 = per layer, whichever of stream-K over the last round / K-split tail plan / whole tiles
+ *                        was measured fastest for that shape class (default), 1 = never stream-K, 2 = whole tiles only.
+ *                        The routes differ in the fp32 summation order of the affected rows (each one deterministic).
  * Returns DC_OK or DC_E_INVALID for an unknown name / bad value. */
 int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value);
 
