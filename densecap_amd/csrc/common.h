@@ -57,6 +57,7 @@ struct GemmDesc {
   // of the workgroups on the line of K units (unit = 2 K-tiles, sk_np units per tile, tiles n-fastest); sk_slots =
   // sk_wgs partial tiles of 128x128 floats; sk_flags[0..sk_wgs) zeroed before the launch; sk_fault = sticky device word
   // raised when an owner gives up waiting for a partner (checked by the host with the results)
+  int stages = 0;             // LDS ring depth of the 128x64-tile kernel: 0 = by tile count, 3 (two workgroups per CU) or 2 (three per CU)
   const int* sk_lo = nullptr;
   int sk_np = 0;
   float* sk_slots = nullptr;

@@ -251,9 +251,9 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
   };
 
   const int nkt = d.K / BK;
-  // prologue: tiles 0..NS-2 in flight
+  // prologue: tiles 0..NS-2 in flight (two-stage ring: both stages)
 #pragma unroll
-  for (int p = 0; p < NS - 1; ++p)
+  for (int p = 0; p < (NS == 2 ? 2 : NS - 1); ++p)
     if (p < nkt) issue(p, p);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -266,6 +266,25 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
     constexpr int st = decltype(ST)::value;
     constexpr int st1 = st == NS - 1 ? 0 : st + 1;
     constexpr int stn = st == 0 ? NS - 1 : st - 1;     // stage of tile kt-1 == stage of tile kt+NS-1
+    if constexpr (NS == 2) {
+      // Two-stage ring (48 KiB for a 128x64 tile: THREE workgroups per CU instead of two): the rendezvous sits after
+      // group 2, when every fragment of tile kt is in registers -- its stage is then free for tile kt+2, requested a
+      // full tile ahead of its first use; tile kt+1 (requested during tile kt-1) is waited for at the same point.
+      group_with(0, TM + TN, [&](int k) { read_piece(st, 1, 1, k); });
+      group_with(1, TM + TN, [&](int k) { read_piece(st, 2, 0, k); });
+      group_with(0, TM + TN, [&](int k) { read_piece(st, 3, 1, k); });
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const bool more2 = kt + 2 < nkt, next2 = kt + 1 < nkt;
+      if (more2) issue_begin();
+      group_with(1, PA + PB + TM + TN, [&](int k) {
+        if (k < PA + PB) { if (more2) issue_piece(kt + 2, st, k); }
+        else if (next2) read_piece(st1, 0, 0, k - (PA + PB));
+      });
+      return;
+    }
     group_with(0, TM + TN, [&](int k) { read_piece(st, 1, 1, k); });
     group_with(1, TM + TN, [&](int k) { read_piece(st, 2, 0, k); });
     // ---- mid-tile rendezvous: tile kt+1 has landed everywhere; the stage of tile kt-1 is free
@@ -286,7 +305,9 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
   auto ring_round = [&](int kt, bool guarded) __attribute__((always_inline)) {
     if (!guarded || kt + 0 < nkt) body(kt + 0, std::integral_constant<int, 0>{});
     if (!guarded || kt + 1 < nkt) body(kt + 1, std::integral_constant<int, 1>{});
-    if (!guarded || kt + 2 < nkt) body(kt + 2, std::integral_constant<int, 2>{});
+    if constexpr (NS >= 3) {
+      if (!guarded || kt + 2 < nkt) body(kt + 2, std::integral_constant<int, 2>{});
+    }
     if constexpr (NS == 4) {
       if (!guarded || kt + 3 < nkt) body(kt + 3, std::integral_constant<int, 3>{});
     }
@@ -887,9 +908,25 @@ namespace {
 
 template <bool CONV, bool AMAX>
 hipError_t launch_mixed(const GemmDesc& d, hipStream_t stream, int ntm, int ntn, int m_fastest, size_t lds) {
-  const int total = ntm * ntn, slots = 2 * device_cu_count();
-  const int nbig = total / slots * slots, tail = total - nbig;
-  if (nbig <= 0 || tail <= 0 || 4 * tail > 3 * slots) return hipErrorNotReady;
+  // Ring depth: two stages (48 KiB) put three workgroups on a CU instead of two (72 KiB), which hides more of each tile's
+  // prologue / epilogue behind its neighbours' K loops -- measured +5% on conv1_2, conv2_1 and the vocabulary projection --
+  // but only once there are three tiles for every CU: below that the dispatcher stacks three on some CUs and leaves
+  // others with one (300-row decode: 495 tiles, 0.87 vs 0.78 ms), so the three-stage ring keeps those launches.
+  const int total = ntm * ntn;
+  const int stages = d.stages == 2 || d.stages == 3 ? d.stages : (total >= 3 * device_cu_count() ? 2 : 3);
+  const int wg_per_cu = stages == 2 ? 3 : 2;
+  const int slots = wg_per_cu * device_cu_count();
+  int nbig = total / slots * slots, tail = total - nbig;
+  if (nbig <= 0 || tail <= 0 || 4 * tail > 3 * slots) { nbig = total; tail = 0; }     // no ragged round worth splitting
+  if (stages == 2) {
+    const size_t lds2 = lds / 3 * 2;
+    const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_mixed_kernel<CONV, 2, AMAX>);
+    if (hipError_t e = ensure_dyn_lds(fn, lds2); e != hipSuccess) return e;
+    hipLaunchKernelGGL((mfma_gemm_v2_mixed_kernel<CONV, 2, AMAX>), dim3(nbig + 2 * tail), dim3(256), lds2, stream, d, ntm, ntn,
+                       m_fastest, nbig);
+    return hipGetLastError();
+  }
+  if (tail == 0) return hipErrorNotReady;
   const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX>);
   if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL((mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX>), dim3(nbig + 2 * tail), dim3(256), lds, stream, d, ntm, ntn,

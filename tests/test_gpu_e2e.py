@@ -682,6 +682,29 @@ def test_persistent_decode_equals_gemm_decode(model, weights):
         check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 0), "dc_debug_set")
 
 
+def test_ring_depth_is_invisible_in_decode(model, weights):
+    """dc_debug_set("v2_stages"): the 128x64-tile kernel with a two-stage LDS ring (three workgroups per CU; the default once
+    a launch has >= 3 tiles per CU, i.e. the vocabulary projection at 1000 rows) and with three stages walks K in the same
+    order: the sampled tokens must be identical whichever is forced, at row counts either side of the switch."""
+    from densecap_amd._lib import check
+    ctx = model.ctx
+    rng = np.random.default_rng(12)
+    try:
+        for n in (130, 300, 1000):
+            codes = np.maximum(rng.standard_normal((n, 4096)), 0).astype(np.float32)
+            cd = ctx.to_device(codes); td = ctx.empty((n, 15), np.int32)
+            outs = []
+            for st in (0, 2, 3):
+                check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"v2_stages", st), "dc_debug_set")
+                check(ctx.h, ctx.lib.dc_op_lm_sample(ctx.h, cd.ptr, n, td.ptr), "dc_op_lm_sample")
+                outs.append(td.numpy().copy())
+            np.testing.assert_array_equal(outs[1], outs[0]); np.testing.assert_array_equal(outs[2], outs[0])
+            assert outs[0].min() >= 1
+            cd.free(); td.free()
+    finally:
+        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"v2_stages", 0), "dc_debug_set")
+
+
 def test_webcam_regime_forward_both_decode_routes(model, weights):
     """forward_test at the webcam settings (480 px, 50 proposals, single_machine_demo.lua:25-26), single-image mode: the
     persistent decode route (decode_route = 2) against the oracle (every stage), and bit-identical to the GEMM route --

@@ -154,6 +154,36 @@ def test_streamk_last_round_all_routes(case):
         c.close()
 
 
+@pytest.mark.parametrize("case", [(64, 300, 360, 128, False),      # conv2_1 at 720x600: 1688 tiles of 128x64 -> two-stage ring by default
+                                  (64, 301, 203, 64, True),        # conv1_2-like with the pool epilogue, odd sizes, ragged last round
+                                  (64, 75, 90, 64, False)])        # few tiles: three stages by default
+def test_ring_depth_bit_identical(case):
+    """The 128x64-tile kernel with a two- or a three-stage LDS ring (dc_debug_set "v2_stages") adds the same products in
+    the same order: bit-identical outputs, whichever the tile count selects by default."""
+    from densecap_amd import ops
+    from densecap_amd._lib import check
+    Cin, H, W, Cout, pool = case
+    c = ops.Context(0)
+    try:
+        rng = np.random.default_rng(H + Cout)
+        x = np.maximum(rng.standard_normal((1, Cin, H, W)), 0).astype(np.float32)
+        w = (rng.standard_normal((Cout, Cin, 3, 3)) * (2.0 / (9 * Cin)) ** 0.5).astype(np.float32)
+        b = rng.standard_normal(Cout).astype(np.float32)
+        outs = []
+        for st in (0, 2, 3):
+            check(c.h, c.lib.dc_debug_set(c.h, b"v2_stages", st), "dc_debug_set")
+            outs.append(ops.conv3x3_relu_pool(c, x[0], w, b) if pool else ops.conv3x3(c, x, w, b, relu=True))
+        np.testing.assert_array_equal(outs[1], outs[0]); np.testing.assert_array_equal(outs[2], outs[0])
+        import torch
+        ref = torch.relu(torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(),
+                                                    torch.from_numpy(b).double(), padding=1))
+        if pool:
+            ref = torch.nn.functional.max_pool2d(ref, 2, 2, ceil_mode=True)
+        _close(outs[0].reshape(ref.shape[1:]) if pool else outs[0], ref.float().numpy()[0] if pool else ref.float().numpy(), rel=2e-5)
+    finally:
+        c.close()
+
+
 def test_streamk_dense_gemm_single_lane():
     """The same machinery on a dense contraction whose tile count leaves a partial round: (6750, 512, 4608) = 212 tiles."""
     from densecap_amd import ops

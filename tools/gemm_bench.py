@@ -14,6 +14,8 @@ lib = ctx.lib
 if "--serial" in sys.argv:          # single-image mode: tail plans (K-split last round) are active, as in `bench.py --lanes 1`
     check(ctx.h, lib.dc_set_lanes(ctx.h, 1))
 for a in sys.argv:
+    if a.startswith("--stages="):         # LDS ring depth of the 128x64-tile kernel (2 = three workgroups per CU)
+        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"v2_stages", int(a.split("=")[1])))
     if a.startswith("--tail-mode="):      # 0 stream-K (default), 1 K-split tail plan, 2 whole tiles
         check(ctx.h, lib.dc_debug_set(ctx.h, b"tail_mode", int(a.split("=")[1])))
 print("mode:", "serial (dc_set_lanes(1): partial last rounds are shared along K)" if "--serial" in sys.argv else "multi-lane planning (whole tiles)",
