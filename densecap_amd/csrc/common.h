@@ -100,6 +100,7 @@ double gemm_flops(const GemmDesc& d);
 hipError_t launch_chw_to_hwc(const float* in, float* out, int C, int H, int W, hipStream_t s);
 hipError_t launch_hwc_to_chw(const float* in, float* out, int C, int H, int W, hipStream_t s);
 hipError_t launch_pack_conv3x3(const float* w_oihw, float* w_packed, int Cout, int Cin, hipStream_t s);
+int device_cu_count();      // compute units of the current device (256 on MI355X); cached per device
 hipError_t launch_conv3x3_c3(const float* in_chw, const float* w_oihw, const float* bias, float* out_hwc, int nimg,
                              int H, int W, int Cout, int relu, hipStream_t s);
 hipError_t launch_maxpool2x2_ceil(const float* in, float* out, int nimg, int H, int W, int C, hipStream_t s);

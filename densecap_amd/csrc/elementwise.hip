@@ -57,87 +57,119 @@ __global__ void permute_fc6_kernel(const float* __restrict__ in, float* __restri
 
 // ---- conv1_1: Cin = 3 (K = 27), CHW boundary image in -> HWC out, on the matrix cores -------------------------------
 // 1.49 GFLOP against 110 MB of output: HBM-store-bound (~14 us at 8 TB/s) once the arithmetic leaves the VALU
-// (the scalar version was VALU-bound at 65 us).  A workgroup owns 4 image rows x 32 columns; the (3, 6, 34) input
-// patch is staged in LDS once (zero padding outside the image); wave w computes row w: M = 32 pixels, N = 64 channels
-// (two 32x32 accumulator blocks), K = 28 = 14 x v_mfma_f32_32x32x2_f32 with k = c*9 + kh*3 + kw (k = 27: zero weight).
+// (the scalar version was VALU-bound at 65 us).  A tile is 4 image rows x 32 columns; its (3, 6, 34) input patch is
+// staged in LDS (zero padding outside the image); wave w computes row w: M = 32 pixels, N = 64 channels (two 32x32
+// accumulator blocks), K = 28 = 14 x v_mfma_f32_32x32x2_f32 with k = c*9 + kh*3 + kw (k = 27: zero weight).
 // A fragments are single ds_read_b32 from the patch (lane = pixel, lane half = k parity), B fragments (the weights,
-// staged through LDS) live in 28 registers.  Each store instruction writes two pixels x 128 contiguous bytes.
+// staged through LDS once per workgroup) live in 28 registers.  Each store instruction writes two pixels x 128
+// contiguous bytes.  A workgroup walks `tpw` consecutive tiles of its 4-row strip: weights, bias and the patch
+// addressing are set up once, the next tile's patch is in flight (registers) while this one is computed and stored, so
+// the stores of a CU's three workgroups stream instead of arriving in bursts behind a load -> barrier -> compute chain
+// per 32 KiB of output.
 template <int COUT>
 __global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ out,
-                                                         int H, int W, int relu) {
+                                                         int H, int W, int relu, int tpw) {
   static_assert(COUT == 64, "two 32-channel accumulator blocks");
   constexpr int TR = 4, TC = 32, PR = TR + 2, PC = TC + 2, KP = 28;
-  __shared__ float patch[3 * PR * PC];
+  constexpr int NP = 3 * PR * PC, PPT = (NP + 255) / 256;
+  __shared__ float patch[2][NP];
   constexpr int OP = 72;                             // transpose-tile pitch in floats: the two lane halves write pixel rows 4
                                                      // apart, 4*72 = 32 (mod 64) banks apart -> no write conflicts (68 had 2-way)
   __shared__ float wsm[4 * 32 * OP];                 // weights (64 x 27 floats) first, then the output transpose tiles
   static_assert(4 * 32 * OP >= COUT * 27, "weights fit in the transpose buffer");
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, hsel = lane >> 5;
-  const int x0 = blockIdx.x * TC, y0 = blockIdx.y * TR;
+  const int y0 = blockIdx.y * TR;
+  const int ntx = (W + TC - 1) / TC, tx0 = blockIdx.x * tpw, tx1 = min(ntx, tx0 + tpw);
   in += (size_t)blockIdx.z * 3 * H * W;                       // image of the group
   out += (size_t)blockIdx.z * H * W * COUT;
-  for (int i = tid; i < 3 * PR * PC; i += 256) {
+  // this thread's (up to) three patch elements: row / channel part of the address once, the column moves with the tile
+  int p_ofs[PPT], p_dx[PPT];
+  bool p_row[PPT];
+#pragma unroll
+  for (int u = 0; u < PPT; ++u) {
+    const int i = tid + u * 256;
     const int c = i / (PR * PC), rem = i - c * (PR * PC), py = rem / PC, px = rem - py * PC;
-    const int y = y0 + py - 1, x = x0 + px - 1;
-    patch[i] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? in[((size_t)c * H + y) * W + x] : 0.f;
+    const int y = y0 + py - 1;
+    p_row[u] = i < NP && (unsigned)y < (unsigned)H;
+    p_dx[u] = px - 1;
+    p_ofs[u] = p_row[u] ? (c * H + y) * W + px - 1 : 0;
   }
+  float pre[PPT];
+  auto fetch = [&](int tx) {
+    const int x0 = tx * TC;
+#pragma unroll
+    for (int u = 0; u < PPT; ++u)
+      pre[u] = (p_row[u] && (unsigned)(x0 + p_dx[u]) < (unsigned)W) ? in[p_ofs[u] + x0] : 0.f;
+  };
+  fetch(tx0);
   // weights (64 x 27, 6.9 KB): one coalesced pass into LDS (a per-lane gather from global costs 28 scattered loads per
   // thread -- measured 2x the whole kernel), then lane (n = r, half hsel) takes W[n + 32 j][k = 2 s + hsel]; the odd row
   // stride 27 keeps the LDS reads conflict-free
   for (int i = tid; i < COUT * 27; i += 256) wsm[i] = w[i];
   __syncthreads();
-  float bw[2][KP / 2];
+  float bw[2][KP / 2], bv[2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < 2; ++j) {
+    bv[j] = bias[r + 32 * j];
 #pragma unroll
     for (int st = 0; st < KP / 2; ++st) {
       const int k = 2 * st + hsel;
       bw[j][st] = k < 27 ? wsm[(r + 32 * j) * 27 + k] : 0.f;
     }
-  f32x16 acc[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-  const float* prow = patch + wid * PC + r;       // pixel (row wid, column r) of the tile; tap (kh, kw) at +kh*PC + kw
-#pragma unroll
-  for (int st = 0; st < KP / 2; ++st) {
-    const int k0 = 2 * st, k1 = k0 + 1 < 27 ? k0 + 1 : 26;               // k = 27 meets a zero weight: any finite input does
-    const int o0 = (k0 / 9) * (PR * PC) + ((k0 % 9) / 3) * PC + (k0 % 3);
-    const int o1 = (k1 / 9) * (PR * PC) + ((k1 % 9) / 3) * PC + (k1 % 3);
-    const float a = prow[hsel ? o1 : o0];
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[0][st], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[1][st], acc[1], 0, 0, 0);
   }
-  // Epilogue.  C/D map of the 32x32 MFMA: col (channel) = lane&31, row (pixel) = (e&3) + 8*(e>>2) + 4*hsel.  The wave's
-  // result -- 32 consecutive pixels x 64 channels -- is ONE contiguous 8 KiB run of the channels-last output, so it is
-  // transposed through LDS ([pixel][64 + 8 pad] floats) and leaves as 16-byte stores, 1 KiB contiguous per instruction
-  // (dword stores in MFMA order reach ~2.5 TB/s on this 110 MB store-bound kernel).
-  __syncthreads();                                   // all waves are done with the patch / weights
+  __syncthreads();                                   // the weights are in registers: wsm becomes the transpose tiles
   float* ot = wsm + wid * (32 * OP);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const float bv = bias[r + 32 * j];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      float v = acc[j][e] + bv;
-      if (relu) v = v > 0.f ? v : 0.f;
-      ot[((e & 3) + 8 * (e >> 2) + 4 * hsel) * OP + r + 32 * j] = v;
-    }
-  }
-  // (same wave reads what it wrote: no barrier needed, the LDS ops of a wave complete in order)
   const int y = y0 + wid;
-  if (y >= H) return;
+  for (int tx = tx0; tx < tx1; ++tx) {
+    float* pt = patch[(tx - tx0) & 1];
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int idx = it * 64 + lane;                  // float4 index inside the wave's 32 x 64 block
-    const int px = idx >> 4, c4 = idx & 15;
-    const int x = x0 + px;
-    if (x < W) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(ot + px * OP + c4 * 4);
-      *reinterpret_cast<f32x4*>(out + ((size_t)y * W + x) * COUT + c4 * 4) = v;
+    for (int u = 0; u < PPT; ++u)
+      if (tid + u * 256 < NP) pt[tid + u * 256] = pre[u];
+    __syncthreads();     // (the other buffer is still being read by slower waves; this one was last read two tiles ago)
+    if (tx + 1 < tx1) fetch(tx + 1);
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    const float* prow = pt + wid * PC + r;          // pixel (row wid, column r) of the tile; tap (kh, kw) at +kh*PC + kw
+#pragma unroll
+    for (int st = 0; st < KP / 2; ++st) {
+      const int k0 = 2 * st, k1 = k0 + 1 < 27 ? k0 + 1 : 26;               // k = 27 meets a zero weight: any finite input does
+      const int o0 = (k0 / 9) * (PR * PC) + ((k0 % 9) / 3) * PC + (k0 % 3);
+      const int o1 = (k1 / 9) * (PR * PC) + ((k1 % 9) / 3) * PC + (k1 % 3);
+      const float a = prow[hsel ? o1 : o0];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[0][st], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[1][st], acc[1], 0, 0, 0);
+    }
+    // Epilogue.  C/D map of the 32x32 MFMA: col (channel) = lane&31, row (pixel) = (e&3) + 8*(e>>2) + 4*hsel.  The wave's
+    // result -- 32 consecutive pixels x 64 channels -- is ONE contiguous 8 KiB run of the channels-last output, so it is
+    // transposed through LDS ([pixel][64 + 8 pad] floats) and leaves as 16-byte stores, 1 KiB contiguous per instruction
+    // (dword stores in MFMA order reach ~2.5 TB/s on this 110 MB store-bound kernel).  The tile is the wave's own: its
+    // LDS operations complete in order, no barrier between the writes, the reads and the next tile's writes.
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = acc[j][e] + bv[j];
+        if (relu) v = v > 0.f ? v : 0.f;
+        ot[((e & 3) + 8 * (e >> 2) + 4 * hsel) * OP + r + 32 * j] = v;
+      }
+    if (y < H) {
+      const int x0 = tx * TC;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int idx = it * 64 + lane;                  // float4 index inside the wave's 32 x 64 block
+        const int px = idx >> 4, c4 = idx & 15;
+        const int x = x0 + px;
+        if (x < W) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(ot + px * OP + c4 * 4);
+          // (non-temporal stores: 27.7 instead of 29.9 us for this kernel alone, nothing end to end -- conv1_2 re-reads the tensor)
+          *reinterpret_cast<f32x4*>(out + ((size_t)y * W + x) * COUT + c4 * 4) = v;
+        }
+      }
     }
   }
 }
@@ -413,9 +445,16 @@ hipError_t launch_permute_fc6(const float* in, float* out, int N, int C, int HW,
 }
 hipError_t launch_conv3x3_c3(const float* in, const float* w, const float* bias, float* out, int nimg, int H, int W,
                              int Cout, int relu, hipStream_t s) {
-  if (Cout != 64 || nimg < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((conv3x3_c3_kernel<64>), dim3((W + 31) / 32, (H + 3) / 4, nimg), dim3(256), 0, s, in, w, bias, out,
-                     H, W, relu);
+  if (Cout != 64 || nimg < 1 || (size_t)3 * H * W >= 0x7fffffffull) return hipErrorInvalidValue;
+  // tiles per workgroup: ONE round of three workgroups per CU (41 KiB of LDS each) covers the image (720x600: 5 tiles each,
+  // 750 workgroups, 29.9 us = 3.7 TB/s of stores; 3 or 8 tiles per workgroup: 33-34 us; one tile per workgroup, the
+  // round-2 kernel: 40.4 us; the same walk without the MFMAs: 23.1 us)
+  const int ntx = (W + 31) / 32, nty = (H + 3) / 4;
+  const long tiles = (long)ntx * nty * nimg, slots = 3L * device_cu_count();
+  int tpw = (int)((tiles + slots - 1) / slots);
+  tpw = tpw < 1 ? 1 : (tpw > ntx ? ntx : tpw);
+  hipLaunchKernelGGL((conv3x3_c3_kernel<64>), dim3((ntx + tpw - 1) / tpw, nty, nimg), dim3(256), 0, s, in, w, bias, out,
+                     H, W, relu, tpw);
   return hipGetLastError();
 }
 hipError_t launch_maxpool2x2_ceil(const float* in, float* out, int nimg, int H, int W, int C, hipStream_t s) {

@@ -860,6 +860,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_sk_kernel(GemmDesc d, int ntn) 
   }
 }
 
+}  // namespace
+
 // compute units of the current device (256 on MI355X); cached per device
 int device_cu_count() {
   static std::mutex mu;
@@ -875,8 +877,6 @@ int device_cu_count() {
   }
   return cus[dev];
 }
-
-}  // namespace
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: a process that drives several
 // devices (N contexts in N host threads, include/densecap.h) must raise it on each of them.  (device, kernel) pairs

@@ -44,11 +44,14 @@ def test_conv3x3_matches_torch(ctx, shape):
     _close(out2, ref2)
 
 
-def test_conv1_1_c3_matches_torch(ctx):
+@pytest.mark.parametrize("hw", [(67, 83), (3, 33), (600, 720), (1203, 1601)])
+def test_conv1_1_c3_matches_torch(ctx, hw):
+    """conv1_1 walks several 4x32 tiles per workgroup once the image has more tiles than one round of workgroups
+    (720x600: 5 per workgroup, 1601x1203: 20): ragged right / bottom edges, one-tile images and both walks."""
     import torch
     from densecap_amd import ops
     g = torch.Generator().manual_seed(3)
-    x = torch.rand(1, 3, 67, 83, generator=g) * 255 - 110
+    x = torch.rand(1, 3, *hw, generator=g) * 255 - 110
     w = torch.randn(64, 3, 3, 3, generator=g) * 0.27
     b = torch.randn(64, generator=g)
     ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)).float().numpy()
