@@ -453,6 +453,9 @@ def main():
             host_enqueue_us = int(he[0])
         except Exception:
             pass
+    # --lanes 1: the per-launch events stay on (one stream for the whole invocation), but the counts that go with the timed
+    # regions are read HERE -- the sustained leg below adds launches that K * repeats does not count
+    prof_timed = model.mfma_profile(reset=0) if (on_gpu and args.lanes == 1) else None
     order = sorted(range(len(elapsed_all)), key=lambda i: elapsed_all[i])
     elapsed = elapsed_all[order[len(order) // 2]]          # median repeat
     nrep = len(elapsed_all)
@@ -485,6 +488,8 @@ def main():
         if sampler is not None:
             sustained.update(sampler.stop())
     prof = model.mfma_profile(reset=-1)
+    if prof_timed is not None:
+        prof = prof_timed
     stage = model.stage_times()
 
     # Secondary figure (not `value`): final NMS first, captions only for the surviving boxes -- bit-identical
