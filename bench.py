@@ -624,6 +624,10 @@ def main():
                     "mfma_util_pmc": sum(v.get("mfma_util", 0) * v["total_us"] for v in fam) / sum(v["total_us"] for v in fam),
                     "file": PMC_PROFILE, "profile_commit": pm.get("_commit"), "bench_commit": git_head(),
                     "unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), separate --pmc passes"}
+                if (H, W, P) == (600, 720, 1000):
+                    # the committed counter passes ran THIS workload (same command, --lanes 1): average HBM bytes of one
+                    # launch of the family, per launch like `achieved` (provenance in traffic_from_profile)
+                    roof["traffic"] = roof["traffic_from_profile"]["hbm_bytes_per_launch"]
             except Exception:
                 roof["traffic_from_profile"] = None
             out["roofline"] = roof
