@@ -523,12 +523,17 @@ constexpr int SK_SLOT_FLOATS = 128 * 128;
 constexpr unsigned SK_SPIN_LIMIT = 1u << 22;       // bounded: a partner that never shows up is reported, not waited for
 
 // One K segment [kt0, kt0+nkt) (nkt even) of the tile at (m0, n0).
-template <bool CONV>
+// HALF: the tile has at most 64 live rows (a 50-proposal batch, the last row tile of a 300-proposal one): the two upper
+// 32-row blocks are neither fetched nor multiplied -- half the MFMAs of a K-tile, the weight panel streams at the same
+// rate, so a <= 64-row fc6 moves from the matrix pipe's bound to HBM's.  Same K walk per element: a row's result does not
+// depend on which variant its tile ran.
+template <bool CONV, bool HALF = false>
 __device__ __forceinline__ void ks_segment(const GemmDesc& d, const int m0, const int n0, const int Meff, const int slice,
                                            const int kt0, const int nkt, const int mode, const int sk_wg,
                                            const int sk_npartner, float* const smem) {
   constexpr int BM = 128, BN = 128;
   constexpr int PA = BM / 32, PB = BN / 32;
+  constexpr int NI = HALF ? 2 : 4;         // live 32-row blocks of A
   constexpr int STAGE = (BM + BN) * BK;    // floats per ring stage
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -605,6 +610,7 @@ __device__ __forceinline__ void ks_segment(const GemmDesc& d, const int m0, cons
   auto issue_piece = [&](int kt, int st, int p) {
     float* sa = smem + st * STAGE + (8 * wid) * BK;
     float* sb = sa + BM * BK;
+    if (HALF && p >= NI && p < PA) return;              // rows 64..127 of the tile do not exist
     if (p < PA) {
       if constexpr (CONV) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, sa + p * 32 * BK, 16, (int)cv_vo[p], cv_soff, 0, 0);
@@ -623,6 +629,7 @@ __device__ __forceinline__ void ks_segment(const GemmDesc& d, const int m0, cons
   f32x4 fa[2][4], fb[2][4];
   auto read_piece = [&](int st, int set, int p) {     // p in [0,4): A row block, [4,8): B row block
     const float* base = smem + st * STAGE + foff;
+    if (HALF && p >= NI && p < 4) return;
     if (p < 4) fa[set][p] = *reinterpret_cast<const f32x4*>(base + p * 32 * BK);
     else fb[set][p - 4] = *reinterpret_cast<const f32x4*>(base + BM * BK + (p - 4) * 32 * BK);
   };
@@ -633,8 +640,9 @@ __device__ __forceinline__ void ks_segment(const GemmDesc& d, const int m0, cons
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  auto mfma_slot = [&](int set, int q) {               // q in [0,64): e = q/16, (i,j) = q%16
-    const int e = q >> 4, i = (q >> 2) & 3, j = q & 3;
+  constexpr int NQ = 16 * NI;                          // MFMAs of one K-tile
+  auto mfma_slot = [&](int set, int q) {               // q in [0,NQ): e = q/(4 NI), (i,j) = q%(4 NI)
+    const int e = q / (4 * NI), i = (q >> 2) % NI, j = q & 3;
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
   };
 
@@ -659,11 +667,13 @@ __device__ __forceinline__ void ks_segment(const GemmDesc& d, const int m0, cons
   for (int p = 0; p < 8; ++p) read_piece(0, 0, p);
 
   // one K-tile: 32 MFMAs, rendezvous, 32 MFMAs interleaved with the 8 LDS-DMA pieces of tile kt+2 and the
-  // 8 fragment reads of tile kt+1
+  // 8 fragment reads of tile kt+1 (HALF: 16 + 16 MFMAs, 6 pieces, 6 reads)
+  constexpr int SIDE = NI + 4;                          // live LDS-DMA pieces = live fragment reads of a K-tile
+  auto side_piece = [&](int sidx) { return sidx < NI ? sidx : sidx - NI + 4; };   // skip the dead A blocks
   auto tile_body = [&](int kt, int set) {
     const int st = kt & 1;
 #pragma unroll
-    for (int q = 0; q < 32; ++q) mfma_slot(set, q);
+    for (int q = 0; q < NQ / 2; ++q) mfma_slot(set, q);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt+1 landed (issued one tile ago)
     __builtin_amdgcn_s_barrier();                        // ... everywhere; tile kt's stage is free (already in registers)
@@ -671,14 +681,14 @@ __device__ __forceinline__ void ks_segment(const GemmDesc& d, const int m0, cons
     const bool more = kt + 2 < nkt, next = kt + 1 < nkt;
     if (more) issue_begin();
 #pragma unroll
-    for (int q = 32; q < 64; ++q) {
+    for (int q = NQ / 2; q < NQ; ++q) {
       mfma_slot(set, q);
-      const int k = q - 32;
-      if (k < 16 && (k & 1) == 0) {
-        if (more) issue_piece(kt0 + kt + 2, st, k >> 1);
-        __builtin_amdgcn_sched_barrier(0);
-      } else if (k >= 16 && (k & 1) == 0) {
-        if (next) read_piece(st ^ 1, set ^ 1, (k - 16) >> 1);
+      const int k = q - NQ / 2;                          // side operation s follows MFMA floor(s * (NQ/2) / (2 SIDE))
+#pragma unroll
+      for (int sdx = 0; sdx < 2 * SIDE; ++sdx) {
+        if ((sdx * (NQ / 2)) / (2 * SIDE) != k) continue;
+        if (sdx < SIDE) { if (more) issue_piece(kt0 + kt + 2, st, side_piece(sdx)); }
+        else if (next) read_piece(st ^ 1, set ^ 1, side_piece(sdx - SIDE));
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -722,7 +732,7 @@ __device__ __forceinline__ void ks_segment(const GemmDesc& d, const int m0, cons
     for (int k = 0; k < 16; ++k) pre[k] = *reinterpret_cast<const f32x4*>(ps + k * 1024);
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < (HALF ? 2 : 4); ++q) {
     const int qi = (q >> 1) * 2, qj = (q & 1) * 2;   // quadrant q = accumulator tiles [qi..qi+1][qj..qj+1]
     float* slot = slots + wid * 4096;
 #pragma unroll
@@ -819,6 +829,12 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
     if (m0 >= Meff) return;
   }
   const int nkt = d.K / BK / d.splitk;               // this workgroup's K range (the whole K unless split-K)
+  if constexpr (!CONV) {
+    if (Meff - m0 <= 64) {                             // a <= 64-row tile (50-proposal batch, last tile of 300 rows)
+      ks_segment<false, true>(d, m0, n0, Meff, slice, slice * nkt, nkt, KS_NORMAL, 0, 0, smem);
+      return;
+    }
+  }
   ks_segment<CONV>(d, m0, n0, Meff, slice, slice * nkt, nkt, KS_NORMAL, 0, 0, smem);
 }
 

@@ -157,6 +157,31 @@ def test_streamk_last_round_all_routes(case):
         c.close()
 
 
+def test_short_row_tiles_skip_dead_blocks(ctx):
+    """K-split kernel, row tiles with <= 64 live rows (a 50-proposal batch; the last tile of 300 rows): the two dead 32-row
+    blocks are neither fetched nor multiplied.  Against fp64, and ROW-INVARIANT: a row gives the same bits whether its
+    tile ran the short variant (M = 300: rows 256..299) or the full one (the same rows inside M = 384)."""
+    from densecap_amd import ops
+    rng = np.random.default_rng(9)
+    N, K = 512, 4096
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    x = rng.standard_normal((384, K)).astype(np.float32)
+    full = ops.linear(ctx, x, w, b, relu=True)
+    ref = np.maximum(x.astype(np.float64) @ w.astype(np.float64).T + b, 0).astype(np.float32)
+    _close(full, ref, rel=2e-5)
+    for M in (1, 33, 50, 64, 65, 172, 300):
+        out = ops.linear(ctx, x[:M], w, b, relu=True)
+        np.testing.assert_array_equal(out, full[:M], err_msg="M=%d" % M)
+    # split-K on top (few tiles, long K): fc6-like at 50 rows
+    K2 = 25088
+    w2 = (rng.standard_normal((256, K2)) / np.sqrt(K2)).astype(np.float32)
+    x2 = rng.standard_normal((128, K2)).astype(np.float32)
+    full2 = ops.linear(ctx, x2, w2, None)
+    _close(full2, (x2.astype(np.float64) @ w2.astype(np.float64).T).astype(np.float32), rel=2e-5)
+    _close(ops.linear(ctx, x2[:50], w2, None), full2[:50], rel=2e-5)      # (the split-K factor may differ with M: tolerance)
+
+
 @pytest.mark.parametrize("case", [(64, 300, 360, 128, False),      # conv2_1 at 720x600: 1688 tiles of 128x64 -> two-stage ring by default
                                   (64, 301, 203, 64, True),        # conv1_2-like with the pool epilogue, odd sizes, ragged last round
                                   (64, 75, 90, 64, False)])        # few tiles: three stages by default
