@@ -1043,12 +1043,16 @@ int mfma_gemm_splitk(const GemmDesc& d) {
   const long tiles = (long)((pm + 127) / 128) * ((d.N + 127) / 128);
   if (tiles >= 128 || d.N < 128) return 1;
   const int nkt = d.K / BK;
+  // the largest factor that still leaves every workgroup an even run of K-tiles: >= 16 of them when the chip can be
+  // filled that way, down to 6 for problems of a handful of tiles (480x320: conv5_x 20 tiles, RPN conv 10 -- 9 x 16
+  // K-tiles used 180 / 90 CUs: 55 / 52 us; 12 x 12 and 24 x 6 fill 240: measured below)
   int best = 1;
-  for (int sp = 2; sp <= 16; ++sp) {
+  for (int sp = 2; sp <= 32; ++sp) {
     if (tiles * sp > 256) break;
     if (nkt % sp) continue;
     const int per = nkt / sp;
-    if ((per & 1) || per < 16) continue;
+    if ((per & 1) || per < 6) continue;
+    if (per < 16 && tiles * best >= 192) continue;     // the chip is (nearly) full already: do not shorten the K runs
     best = sp;
   }
   return best;

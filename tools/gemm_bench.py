@@ -37,6 +37,14 @@ LIN = [("fc6", 1000, 4096, 25088), ("fc7", 1000, 4096, 4096), ("lm_enc", 1000, 5
 CONV = [("conv1_2", 600, 720, 64, 64), ("conv2_1", 300, 360, 64, 128), ("conv2_2", 300, 360, 128, 128),
         ("conv3_1", 150, 180, 128, 256), ("conv3_2", 150, 180, 256, 256), ("conv4_1", 75, 90, 256, 512),
         ("conv4_2", 75, 90, 512, 512), ("conv5_1", 38, 45, 512, 512), ("rpn_conv", 38, 45, 512, 256)]
+for a in sys.argv:
+    if a.startswith("--hw="):             # another image size, e.g. --hw=320,480 (webcam regime): the conv list follows the ceil-mode pools
+        H0, W0 = (int(v) for v in a.split("=")[1].split(","))
+        hs = [(H0, W0)]
+        for _ in range(4): hs.append(((hs[-1][0] + 1) // 2, (hs[-1][1] + 1) // 2))
+        CONV = [("conv1_2", *hs[0], 64, 64), ("conv2_1", *hs[1], 64, 128), ("conv2_2", *hs[1], 128, 128),
+                ("conv3_1", *hs[2], 128, 256), ("conv3_2", *hs[2], 256, 256), ("conv4_1", *hs[3], 256, 512),
+                ("conv4_2", *hs[3], 512, 512), ("conv5_1", *hs[4], 512, 512), ("rpn_conv", *hs[4], 512, 256)]
 POOLED = {"conv1_2", "conv2_2", "conv3_2", "conv4_2"}       # (conv3_3 / conv4_3 have conv3_2 / conv4_2's shapes) also timed with the fused 2x2 ceil-mode pool epilogue (as the trunk runs them)
 if CUSTOM:
     LIN = [("%dx%dx%d" % c,) + c for c in CUSTOM]
