@@ -34,7 +34,12 @@
 namespace {
 
 constexpr int BK = 32;
-constexpr int KS_MIN_KTILES = 32;     // K-tiles from which the K-split 128x128 kernel pays (its cross-wave reduction must be amortised)
+// K-tiles from which the K-split 128x128 kernel (one workgroup per CU) beats the 128x64 kernel.  32 while the latter ran two
+// workgroups per CU; with the two-stage ring's three (round 3) the crossover moved past K = 2304: conv2_2 (K = 1152)
+// 340 -> 285 us, conv3_1 185 -> 152, conv3_2 / conv3_3 (K = 2304) 332 -> 285 / 315 -> 277 in the multi-lane planning,
+// 312 -> 284 / 299 -> 272 in single-image mode; K = 4608 (conv4_2.., conv5_x) still belongs to the K-split kernel
+// (single-image conv4_2 299 vs 309 us, conv5_1 98 vs 104).
+constexpr int KS_MIN_KTILES = 96;
 constexpr unsigned CV_PAD = 0xffffe000u;   // conv padding marker: voffset (+ up to 8 KiB of channel offset) past any descriptor range
 
 // Implicit-GEMM row m -> input pixel (y, x) and its byte offset in the channels-last activation.  Plain convs walk the
@@ -1012,7 +1017,7 @@ hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
     if (blocks(128, 64) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
     return launch_cfg<1, 1, CONV>(d, stream);
   }
-  if (d.K < 32 * BK && d.N > 64 && blocks(128, 128) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
+  if (d.K < KS_MIN_KTILES * BK && d.N > 64 && blocks(128, 128) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
   if (d.N > 64 && blocks(128, 128) >= 384) return launch_cfg<2, 2, CONV>(d, stream);
   if (d.N <= 64 && blocks(128, 64) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
   if (d.N > 64 && blocks(128, 128) >= 200 && blocks(128, 128) <= 256) return launch_cfg<2, 2, CONV>(d, stream);
@@ -1027,7 +1032,7 @@ int mfma_gemm_ntiles_n(const GemmDesc& d) {
   const int pm = d.plan_M > 0 ? d.plan_M : d.M;
   auto blocks = [&](int bm, int bn) { return (long)((pm + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
   int bn;
-  if (d.N > 64 && blocks(128, 128) >= 384) bn = d.K < 32 * BK ? 64 : 128;   // mirrors launch_pick
+  if (d.N > 64 && blocks(128, 128) >= 384) bn = d.K < KS_MIN_KTILES * BK ? 64 : 128;   // mirrors launch_pick
   else if (d.N <= 64 && blocks(128, 64) >= 384) bn = 64;
   else if (d.N > 64 && blocks(128, 128) >= 200 && blocks(128, 128) <= 256) bn = 128;
   else bn = 64;
