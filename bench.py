@@ -577,9 +577,10 @@ def main():
             roof = {
                 "bound": "mfma",
                 "kernel": "fp32 MFMA contraction family (v_mfma_f32_32x32x2_f32): mfma_gemm_ks_kernel<CONV> (K-split "
-                          "128x128: conv2_2..5_3, RPN conv, fc6, fc7, LM encoder; mfma_gemm_sk_kernel = stream-K over a partial last "
-                          "round in single-image mode), mfma_gemm_v2[_mixed]_kernel<..> (128x64 tiles with a 64x64 last round: "
-                          "conv1_2, conv2_1, decode step = vocabulary arg-max + h.Wh; 64x64: RPN heads, LSTM gates of the image step)",
+                          "128x128, K >= 3072: conv4_2..5_3, RPN conv, fc6, fc7, LM encoder; mfma_gemm_sk_kernel = stream-K over a "
+                          "partial last round in single-image mode), mfma_gemm_v2[_mixed]_kernel<..> (128x64 tiles, two-stage LDS ring = "
+                          "three workgroups per CU, 64x64 last round: conv1_2..conv3_3, decode step = vocabulary arg-max + h.Wh; "
+                          "128x128: conv4_1; 64x64: RPN heads, LSTM gates of the image step)",
                 "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                 "launches_per_image": prof["launches"] / float(max(nprof, 1)),
