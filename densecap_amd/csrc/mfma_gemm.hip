@@ -496,7 +496,9 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_mixed_kernel(GemmDesc d, int
     if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
     else           { tile_n = bid % ntn; tile_m = bid / ntn; }
     if (tile_m * 128 >= Meff) return;
-    v2_tile<2, 1, CONV, NS, AMAX>(d, tile_m * 128, tile_n * 64, tile_n, Meff, smem);
+    // a row tile with <= 64 live rows (the last 44 of a 300-proposal decode): the 64x64 variant does half the MFMAs
+    if (Meff - tile_m * 128 <= 64) v2_tile<1, 1, CONV, NS, AMAX>(d, tile_m * 128, tile_n * 64, tile_n, Meff, smem);
+    else v2_tile<2, 1, CONV, NS, AMAX>(d, tile_m * 128, tile_n * 64, tile_n, Meff, smem);
   } else {
     const int r = b - nbig, bid = nbig + (r >> 1), half = r & 1;
     int tile_m, tile_n;
@@ -923,8 +925,9 @@ hipError_t ensure_dyn_lds(const void* fn, size_t bytes) {
   return e;
 }
 
-// 128x64 launches: whole rounds as 128x64 tiles, the ragged last round as twice as many 64x64 tiles (see the mixed kernel).
-// Returns hipErrorNotReady when the plain launch should be used (no ragged round worth splitting).
+// 128x64 launches: whole rounds as 128x64 tiles, the ragged last round as twice as many 64x64 tiles (see the mixed kernel;
+// without a ragged round worth splitting every tile is a "whole round" tile -- the same kernel, so that a row tile with
+// <= 64 live rows always finds its 64x64 variant).
 namespace {
 
 template <bool CONV, bool AMAX>
@@ -947,7 +950,6 @@ hipError_t launch_mixed(const GemmDesc& d, hipStream_t stream, int ntm, int ntn,
                        m_fastest, nbig);
     return hipGetLastError();
   }
-  if (tail == 0) return hipErrorNotReady;
   const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX>);
   if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL((mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX>), dim3(nbig + 2 * tail), dim3(256), lds, stream, d, ntm, ntn,
@@ -982,9 +984,7 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
       if (d.amax_cols % BN != 0 || (d.amax_cols > 0 && (d.C == nullptr || d.amax_n > d.amax_cols || d.amax_cols > d.N)))
         return hipErrorInvalidValue;
       const size_t lds3 = (size_t)3 * (BM + BN) * BK * sizeof(float);
-      if constexpr (TM == 2) {
-        if (hipError_t e = launch_mixed<false, true>(d, stream, ntm, ntn, m_fastest, lds3); e != hipErrorNotReady) return e;
-      }
+      if constexpr (TM == 2) return launch_mixed<false, true>(d, stream, ntm, ntn, m_fastest, lds3);
       const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, false, 3, true>);
       if (hipError_t e = ensure_dyn_lds(fn, lds3); e != hipSuccess) return e;
       hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, false, 3, true>), dim3(ntm * ntn), dim3(256), lds3, stream, d, ntm,
@@ -994,9 +994,7 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   }
   if (d.amax_val != nullptr) return hipErrorInvalidValue;
   const size_t lds = (size_t)3 * (BM + BN) * BK * sizeof(float);
-  if constexpr (TM == 2 && TN == 1) {
-    if (hipError_t e = launch_mixed<CONV, false>(d, stream, ntm, ntn, m_fastest, lds); e != hipErrorNotReady) return e;
-  }
+  if constexpr (TM == 2 && TN == 1) return launch_mixed<CONV, false>(d, stream, ntm, ntn, m_fastest, lds);
   const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, CONV, 3>);
   if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, CONV, 3>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn,

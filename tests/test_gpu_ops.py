@@ -173,6 +173,14 @@ def test_short_row_tiles_skip_dead_blocks(ctx):
     for M in (1, 33, 50, 64, 65, 172, 300):
         out = ops.linear(ctx, x[:M], w, b, relu=True)
         np.testing.assert_array_equal(out, full[:M], err_msg="M=%d" % M)
+    # the 128x64 kernel (short K, many tiles): a last row tile with 44 live rows runs its 64x64 variant -- same bits as inside a full tile
+    Mb, Kb = 128 * 96 + 128, 512
+    wb = (rng.standard_normal((N, Kb)) / np.sqrt(Kb)).astype(np.float32)
+    xb = rng.standard_normal((Mb, Kb)).astype(np.float32)
+    fullb = ops.linear(ctx, xb, wb, b)
+    _close(fullb, (xb.astype(np.float64) @ wb.astype(np.float64).T + b).astype(np.float32), rel=2e-5)
+    for M in (128 * 96 + 44, 128 * 96 + 64, 128 * 96 + 65):
+        np.testing.assert_array_equal(ops.linear(ctx, xb[:M], wb, b), fullb[:M], err_msg="M=%d" % M)
     # split-K on top (few tiles, long K): fc6-like at 50 rows
     K2 = 25088
     w2 = (rng.standard_normal((256, K2)) / np.sqrt(K2)).astype(np.float32)
