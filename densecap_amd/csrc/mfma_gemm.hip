@@ -984,22 +984,28 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
       if (d.amax_cols % BN != 0 || (d.amax_cols > 0 && (d.C == nullptr || d.amax_n > d.amax_cols || d.amax_cols > d.N)))
         return hipErrorInvalidValue;
       const size_t lds3 = (size_t)3 * (BM + BN) * BK * sizeof(float);
-      if constexpr (TM == 2) return launch_mixed<false, true>(d, stream, ntm, ntn, m_fastest, lds3);
-      const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, false, 3, true>);
-      if (hipError_t e = ensure_dyn_lds(fn, lds3); e != hipSuccess) return e;
-      hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, false, 3, true>), dim3(ntm * ntn), dim3(256), lds3, stream, d, ntm,
-                         ntn, m_fastest);
-      return hipGetLastError();
+      if constexpr (TM == 2) {
+        return launch_mixed<false, true>(d, stream, ntm, ntn, m_fastest, lds3);
+      } else {
+        const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, false, 3, true>);
+        if (hipError_t e = ensure_dyn_lds(fn, lds3); e != hipSuccess) return e;
+        hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, false, 3, true>), dim3(ntm * ntn), dim3(256), lds3, stream, d, ntm,
+                           ntn, m_fastest);
+        return hipGetLastError();
+      }
     }
   }
   if (d.amax_val != nullptr) return hipErrorInvalidValue;
   const size_t lds = (size_t)3 * (BM + BN) * BK * sizeof(float);
-  if constexpr (TM == 2 && TN == 1) return launch_mixed<CONV, false>(d, stream, ntm, ntn, m_fastest, lds);
-  const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, CONV, 3>);
-  if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, CONV, 3>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn,
-                     m_fastest);
-  return hipGetLastError();
+  if constexpr (TM == 2 && TN == 1) {
+    return launch_mixed<CONV, false>(d, stream, ntm, ntn, m_fastest, lds);
+  } else {
+    const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<TM, TN, CONV, 3>);
+    if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL((mfma_gemm_v2_kernel<TM, TN, CONV, 3>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn,
+                       m_fastest);
+    return hipGetLastError();
+  }
 }
 
 template <bool CONV>
