@@ -78,7 +78,7 @@ hipError_t launch_splitk_reduce_pool(const float* ws, int S, const float* bias, 
 // can this conv problem take GemmDesc::pool (operands within the kernels' 32-bit buffer offsets)?
 bool mfma_gemm_can_pool(const GemmDesc& d);
 // split factor launch_mfma_gemm would like for this problem (1 = none)
-int mfma_gemm_splitk(const GemmDesc& d);
+int mfma_gemm_splitk(const GemmDesc& d, size_t ws_floats);      // ws_floats: capacity of the partial-output workspace
 // Tail plan for problems whose 128x128 tile count is not a multiple of the 256 CUs: rows [0, m_split) run as
 // whole tiles (full rounds), rows [m_split, M) are split `tail_splitk` ways along K so the last partial round
 // fills the chip.  Returns false when it does not pay.

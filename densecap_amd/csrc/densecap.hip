@@ -190,7 +190,7 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, float* ws = nullp
   hipError_t e = hipSuccess;
   const bool ws_ok = ws != nullptr && d.ldc % 4 == 0 && d.N % 4 == 0;
   int m_split = 0, tail_sp = 1;
-  const int sp = ws_ok ? mfma_gemm_splitk(d) : 1;
+  const int sp = ws_ok ? mfma_gemm_splitk(d, ws_floats) : 1;
   if (sp > 1 && (size_t)sp * d.M * d.N <= ws_floats) {
     // few tiles, long K: every tile is shared by `sp` workgroups
     d.splitk = sp; d.splitk_ws = ws;

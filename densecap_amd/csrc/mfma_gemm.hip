@@ -1045,13 +1045,15 @@ int mfma_gemm_ntiles_n(const GemmDesc& d) {
 
 // Few 128x128 tiles and a long K: split K so that ~224-256 workgroups exist (one round on 256 CUs).  Every slice
 // keeps an even number (>= 16) of K-tiles for the K-split kernel.
-int mfma_gemm_splitk(const GemmDesc& d) {
+int mfma_gemm_splitk(const GemmDesc& d, size_t ws_floats) {
   if ((size_t)128 * d.K * 4 >= 0xfffffff0ull || (d.conv && (size_t)d.M * d.Cin * 4 >= CV_PAD)) return 1;
   if (d.amax_val != nullptr || d.rowterm != nullptr || d.m_dev != nullptr) return 1;
   const int pm = d.plan_M > 0 ? d.plan_M : d.M;       // one image's tiles: the split factor fixes the summation order
   const long tiles = (long)((pm + 127) / 128) * ((d.N + 127) / 128);
-  if (tiles >= 128 || d.N < 128) return 1;
   const int nkt = d.K / BK;
+  // (problems of 128..255 tiles leave up to half the chip idle in their single round: inside the K-split kernel's domain
+  // they are costed below like the smaller ones -- 500 proposals' fc6: 128 tiles x 2; outside it the 128x64 kernel has them)
+  if (tiles >= 256 || d.N < 128 || (tiles >= 128 && nkt < KS_MIN_KTILES)) return 1;
   // the largest factor that still leaves every workgroup an even run of K-tiles: >= 16 of them when the chip can be
   // filled that way, down to 6 for problems of a handful of tiles (480x320: conv5_x 20 tiles, RPN conv 10 -- 9 x 16
   // K-tiles used 180 / 90 CUs: 55 / 52 us; 12 x 12 and 24 x 6 fill 240: measured below)
@@ -1064,7 +1066,24 @@ int mfma_gemm_splitk(const GemmDesc& d) {
     if (per < 16 && tiles * best >= 192) continue;     // the chip is (nearly) full already: do not shorten the K runs
     best = sp;
   }
-  return best;
+  // Several rounds of shorter K runs, when one round leaves a quarter of the chip idle behind very long runs (fc6 at 300
+  // rows: 96 tiles x 2 = 192 workgroups of 392 K-tiles, 764 us; x 8 = three rounds of 98).  Cost model in us: a round is
+  // its K run at the K-split kernel's 2.08 us per K-tile + ~10 us of prologue and reduction phases; the reduce launch
+  // reads `sp` partial outputs at ~3 TB/s.  Taken only when it beats the one-round choice by 10 %.
+  auto est = [&](int sp) {
+    const long rounds = (tiles * sp + 255) / 256;
+    const double reduce = sp > 1 ? 4.0 + (double)sp * pm * d.N * 4.0 / 3.0e6 : 0.0;
+    return (double)rounds * ((double)(nkt / sp) * 2.08 + 10.0) + reduce;
+  };
+  int multi = best;
+  double t_multi = est(best);
+  for (int sp = best + 1; sp <= 32 && nkt >= KS_MIN_KTILES; ++sp) {
+    if (tiles * sp <= 256 || nkt % sp) continue;
+    const int per = nkt / sp;
+    if ((per & 1) || per < 16 || (size_t)sp * d.M * d.N > ws_floats) continue;
+    if (est(sp) < t_multi) { multi = sp; t_multi = est(sp); }
+  }
+  return t_multi <= 0.9 * est(best) ? multi : best;
 }
 
 // 4096 cycles per K-tile at ~2.1 GHz: the unit of the tail cost model below

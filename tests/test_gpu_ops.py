@@ -68,6 +68,9 @@ def test_maxpool_ceil(ctx, hw):
 
 
 @pytest.mark.parametrize("mnk", [(1000, 4096, 512), (1000, 72, 256), (37, 5, 4096), (300, 10498, 512),
+                                 (300, 4096, 25088),       # fc6 at 300 proposals: split-K 8 over three rounds of workgroups
+                                 (500, 4096, 12544),       # 128 tiles: split-K 2 fills the chip in one round
+                                 (640, 4096, 6272),        # 160 tiles: split-K over several rounds instead of one round on 160 CUs
                                  (1710, 64, 64), (129, 257, 96), (1, 1, 32)])
 def test_linear_matches_fp64(ctx, mnk):
     from densecap_amd import ops
