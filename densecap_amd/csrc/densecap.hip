@@ -290,7 +290,7 @@ int conv3x3_pool(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, co
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 // num_proposals = -1 (LocalizationLayer.lua:322-324: uncapped RPN NMS): capacity = every anchor of this image size
 int effective_proposals(const dc_ctx* ctx, int H, int W);
-constexpr size_t kSplitkWsFloats = (size_t)640 * 128 * 128;   // 40 MiB: split-K (<= 256 tiles) and tail plans (<= 3 x ~200 tiles)
+constexpr size_t kSplitkWsFloats = (size_t)1600 * 128 * 128;  // 100 MiB per lane: split-K partial outputs (up to 8 x a two-image group's 384 x 4096 fc6 rows), tail plans, stream-K slots
 
 int effective_proposals(const dc_ctx* ctx, int H, int W) {
   if (ctx->num_proposals != -1) return ctx->num_proposals;

@@ -1057,10 +1057,13 @@ int mfma_gemm_splitk(const GemmDesc& d, size_t ws_floats) {
   // the largest factor that still leaves every workgroup an even run of K-tiles: >= 16 of them when the chip can be
   // filled that way, down to 6 for problems of a handful of tiles (480x320: conv5_x 20 tiles, RPN conv 10 -- 9 x 16
   // K-tiles used 180 / 90 CUs: 55 / 52 us; 12 x 12 and 24 x 6 fill 240: measured below)
+  // every choice is a function of ONE image's problem (plan_M): a group of two images must get the factor each image gets
+  // alone, so the workspace test assumes the largest group the ABI allows (dc_set_group: 2)
+  auto fits = [&](int sp) { return (size_t)sp * 2 * pm * d.N <= ws_floats; };
   int best = 1;
   for (int sp = 2; sp <= 32; ++sp) {
     if (tiles * sp > 256) break;
-    if (nkt % sp) continue;
+    if (nkt % sp || !fits(sp)) continue;
     const int per = nkt / sp;
     if ((per & 1) || per < 6) continue;
     if (per < 16 && tiles * best >= 192) continue;     // the chip is (nearly) full already: do not shorten the K runs
@@ -1080,7 +1083,7 @@ int mfma_gemm_splitk(const GemmDesc& d, size_t ws_floats) {
   for (int sp = best + 1; sp <= 32 && nkt >= KS_MIN_KTILES; ++sp) {
     if (tiles * sp <= 256 || nkt % sp) continue;
     const int per = nkt / sp;
-    if ((per & 1) || per < 16 || (size_t)sp * d.M * d.N > ws_floats) continue;
+    if ((per & 1) || per < 16 || !fits(sp)) continue;
     if (est(sp) < t_multi) { multi = sp; t_multi = est(sp); }
   }
   return t_multi <= 0.9 * est(best) ? multi : best;

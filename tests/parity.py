@@ -292,10 +292,10 @@ def _strict_check_stages(model, weights, img, P, rpn_thr, final_thr, T, O, torch
     tf = O.nms(np.concatenate([xyxy[vrows], p[vrows, None]], 1), rpn_thr, None if P == -1 else P)
     np.testing.assert_array_equal(idx[:B], vrows[tf], err_msg="RPN NMS picks differ from the oracle run on the same inputs")
     opicks = rows[st["rpn_nms_idx"]]
-    assert B == len(opicks)
     report["rpn_picks"] = B
-    report["rpn_picks_same_rank"] = int((idx[:B] == opicks).sum())
-    same_rois = bool((idx[:B] == opicks).all())
+    nmin = min(B, len(opicks))         # (an uncapped NMS may also end with another COUNT when a near-threshold decision flips)
+    report["rpn_picks_same_rank"] = int((idx[:nmin] == opicks[:nmin]).sum())
+    same_rois = B == len(opicks) and bool((idx[:B] == opicks).all())
     if not same_rois:
         # fed the oracle's own p/boxes the pick list differs: replay the oracle's NMS, taking from the HIP values only
         # the decisions whose oracle margin is within FLIP_K x the discrepancy observed for their operands
@@ -303,7 +303,8 @@ def _strict_check_stages(model, weights, img, P, rpn_thr, final_thr, T, O, torch
         b5h = np.concatenate([xyxy[rows], p[rows, None]], 1)
         rp, flips = hybrid_nms(b5o, b5h, rpn_thr, None if P == -1 else P)
         assert len(rp) == B and (rows[rp] == idx[:B]).all(), (
-            "RPN pick lists differ at rank %d and the flip replay does not reproduce the HIP list" % int(np.argmin(idx[:B] == opicks)))
+            "RPN pick lists differ at rank %d and the flip replay does not reproduce the HIP list"
+            % (int(np.argmin(idx[:nmin] == opicks[:nmin])) if not (idx[:nmin] == opicks[:nmin]).all() else nmin))
         assert flips, "RPN pick lists differ, yet no decision was within reach of the observed discrepancy"
         report["rpn_flips"] = flips
     roi, _ = model.debug_fetch("roi_boxes", (Pcap, 4))
