@@ -86,8 +86,9 @@ __device__ __forceinline__ float pool_window(const GemmDesc& d, int win, float v
 }
 
 // =========================================================================================
-// v2: LDS-DMA (buffer_load ... lds) 3-stage ring, fragment double-buffering, ONE barrier per
-// K-tile placed in the MIDDLE of the tile's MFMA sequence.
+// v2: LDS-DMA (buffer_load ... lds) ring of three stages (two for the 128x64 tiles of launches with >= 3 tiles per CU:
+// three workgroups per CU), fragment double-buffering, ONE barrier per K-tile placed in the MIDDLE of the tile's MFMA
+// sequence (two-stage ring: behind its third group).
 //
 //  * operands go HBM/L2 -> LDS directly (no staging VGPRs, no ds_write); conv zero padding
 //    comes for free from the buffer descriptor's out-of-range rule (offset >= num_records
@@ -474,9 +475,9 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
   v2_tile<TM, TN, CONV, NS, AMAX>(d, m0, tile_n * (64 * TN), tile_n, Meff, smem);
 }
 
-// 128x64-tile launches with a FINER LAST ROUND (the decode-step GEMM, conv1_2, conv2_1).  The 128x64 tiles of one launch
+// 128x64-tile launches with a FINER LAST ROUND (the decode-step GEMM, conv1_2 .. conv3_3).  The 128x64 tiles of one launch
 // (decode step: 1576 at 1000 rows x 12,608 columns) do not
-// fill a whole number of rounds on the chip's 2 x 256 workgroup slots; the leftover tiles used to run one per CU while the
+// fill a whole number of rounds on the chip's 2 or 3 x 256 workgroup slots; the leftover tiles used to run one per CU while the
 // rest of the chip idled (the critical CU does 7 tiles against a mean of 6.16).  Here the first `nbig` tiles (whole rounds)
 // are 128x64 and each leftover tile is cut into two 64x64 tiles on the SAME launch -- twice the workgroups at half the
 // duration in the ragged round.  An element's K order does not depend on the tile it falls in (same fragment/lane walk
@@ -1014,8 +1015,8 @@ hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
   // Tile choice: largest tile that still yields >= ~1.5 workgroups per CU (256 CUs) -- for ONE image of a group (plan_M)
   const int pm = d.plan_M > 0 ? d.plan_M : d.M;
   auto blocks = [&](int bm, int bn) { return (long)((pm + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
-  // fused arg-max: 128x64 tiles (72 KiB LDS, two workgroups per CU) overlap one tile's LDS-transpose epilogue
-  // with the other's K loop -- measured 2.43 vs 2.51 ms for the 15 decode steps at 1000 x 10498
+  // fused arg-max: 128x64 tiles (two or three workgroups per CU, see launch_mixed) overlap one tile's epilogue
+  // with the others' K loops -- measured 2.43 vs 2.51 ms for the 15 decode steps at 1000 x 10498 with two
   // and the same holds for every K loop too short for the K-split kernel (conv2_1: 214 -> 178 us)
   if (d.amax_val != nullptr) {           // arg-max epilogue: 64-column tiles only (the partial rows are indexed by tile_n)
     if (blocks(128, 64) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
