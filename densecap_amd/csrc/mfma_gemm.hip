@@ -935,14 +935,25 @@ template <bool CONV, bool AMAX>
 hipError_t launch_mixed(const GemmDesc& d, hipStream_t stream, int ntm, int ntn, int m_fastest, size_t lds) {
   // Ring depth: two stages (48 KiB) put three workgroups on a CU instead of two (72 KiB), which hides more of each tile's
   // prologue / epilogue behind its neighbours' K loops -- measured +5% on conv1_2, conv2_1 and the vocabulary projection --
-  // but only once there are three tiles for every CU: below that the dispatcher stacks three on some CUs and leaves
-  // others with one (300-row decode: 495 tiles, 0.87 vs 0.78 ms), so the three-stage ring keeps those launches.
-  const int total = ntm * ntn;
-  const int stages = d.stages == 2 || d.stages == 3 ? d.stages : (total >= 3 * device_cu_count() ? 2 : 3);
+  // but only once there are (nearly) three tiles for every CU: at equal co-residency the deeper ring wins (300-row
+  // decode: 495 tiles, 0.87 vs 0.78 ms), so the three-stage ring keeps those launches.
+  // Which of the two wins also depends on how the tile count falls into rounds (720x480 conv2_2, 1350 tiles: 1.76 rounds of
+  // 768 slots with an unsplit 582-tile remainder, 242 us, against 2 rounds of 512 + a split remainder, 229 us), so both are
+  // costed in tile times: whole rounds x workgroups per CU + the last round (64x64 halves count 1/2), over the loop
+  // efficiency measured at that co-residency (0.80 with three, 0.76 with two).
+  const int total = ntm * ntn, cus = device_cu_count();
+  auto split_tail = [](int full_rounds, int tail, int slots) { return full_rounds > 0 && tail > 0 && 4 * tail <= 3 * slots; };
+  auto cost = [&](int st) {
+    const int per_cu = st == 2 ? 3 : 2, slots = per_cu * cus, full = total / slots, tail = total - full * slots;
+    double units = (double)full * per_cu;
+    if (tail > 0) units += split_tail(full, tail, slots) ? 0.5 * ((2 * tail + cus - 1) / cus) : (double)((tail + cus - 1) / cus);
+    return units / (st == 2 ? 0.80 : 0.76);
+  };
+  const int stages = d.stages == 2 || d.stages == 3 ? d.stages : (2 * total >= 5 * cus && cost(2) < cost(3) ? 2 : 3);
   const int wg_per_cu = stages == 2 ? 3 : 2;
-  const int slots = wg_per_cu * device_cu_count();
+  const int slots = wg_per_cu * cus;
   int nbig = total / slots * slots, tail = total - nbig;
-  if (nbig <= 0 || tail <= 0 || 4 * tail > 3 * slots) { nbig = total; tail = 0; }     // no ragged round worth splitting
+  if (!split_tail(nbig / slots, tail, slots)) { nbig = total; tail = 0; }     // no ragged round worth splitting
   if (stages == 2) {
     const size_t lds2 = lds / 3 * 2;
     const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_mixed_kernel<CONV, 2, AMAX>);
