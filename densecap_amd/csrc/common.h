@@ -91,7 +91,6 @@ hipError_t launch_mfma_gemm_sk(const GemmDesc& d, int wgs, int np, float* ws, hi
 // force the K-split 128x128 kernel (honours m_begin / a_rows / splitk)
 hipError_t launch_mfma_gemm_ks(const GemmDesc& d, hipStream_t stream);
 // number of N-tiles launch_mfma_gemm will use for this problem (size of the arg-max partial rows)
-int mfma_gemm_ntiles_n(const GemmDesc& d);
 // Launches the fp32 MFMA kernel on `stream`; returns hipSuccess or the launch error.
 hipError_t launch_mfma_gemm(const GemmDesc& d, hipStream_t stream);
 double gemm_flops(const GemmDesc& d);

@@ -931,29 +931,33 @@ hipError_t ensure_dyn_lds(const void* fn, size_t bytes) {
 // <= 64 live rows always finds its 64x64 variant).
 namespace {
 
+// Round model of a 128x64 launch, in tile times: whole rounds x workgroups per CU + the last round (split 64x64 halves count
+// 1/2), over the loop efficiency measured at that co-residency (0.80 with three workgroups per CU, 0.76 with two).  Which
+// ring depth wins depends on how the tile count falls into rounds (720x480 conv2_2, 1350 tiles: 1.76 rounds of 768 slots
+// with an unsplit 582-tile remainder, 242 us, against 2 rounds of 512 + a split remainder, 229 us).
+inline bool v2_split_tail(int full_rounds, int tail, int slots) { return full_rounds > 0 && tail > 0 && 4 * tail <= 3 * slots; }
+inline double v2_cost_units(int total, int stages, int cus) {
+  const int per_cu = stages == 2 ? 3 : 2, slots = per_cu * cus, full = total / slots, tail = total - full * slots;
+  double units = (double)full * per_cu;
+  if (tail > 0) units += v2_split_tail(full, tail, slots) ? 0.5 * ((2 * tail + cus - 1) / cus) : (double)((tail + cus - 1) / cus);
+  return units / (stages == 2 ? 0.80 : 0.76);
+}
+inline int v2_pick_stages(int total, int cus) {
+  return 2 * total >= 5 * cus && v2_cost_units(total, 2, cus) < v2_cost_units(total, 3, cus) ? 2 : 3;
+}
+
 template <bool CONV, bool AMAX>
 hipError_t launch_mixed(const GemmDesc& d, hipStream_t stream, int ntm, int ntn, int m_fastest, size_t lds) {
   // Ring depth: two stages (48 KiB) put three workgroups on a CU instead of two (72 KiB), which hides more of each tile's
   // prologue / epilogue behind its neighbours' K loops -- measured +5% on conv1_2, conv2_1 and the vocabulary projection --
   // but only once there are (nearly) three tiles for every CU: at equal co-residency the deeper ring wins (300-row
   // decode: 495 tiles, 0.87 vs 0.78 ms), so the three-stage ring keeps those launches.
-  // Which of the two wins also depends on how the tile count falls into rounds (720x480 conv2_2, 1350 tiles: 1.76 rounds of
-  // 768 slots with an unsplit 582-tile remainder, 242 us, against 2 rounds of 512 + a split remainder, 229 us), so both are
-  // costed in tile times: whole rounds x workgroups per CU + the last round (64x64 halves count 1/2), over the loop
-  // efficiency measured at that co-residency (0.80 with three, 0.76 with two).
   const int total = ntm * ntn, cus = device_cu_count();
-  auto split_tail = [](int full_rounds, int tail, int slots) { return full_rounds > 0 && tail > 0 && 4 * tail <= 3 * slots; };
-  auto cost = [&](int st) {
-    const int per_cu = st == 2 ? 3 : 2, slots = per_cu * cus, full = total / slots, tail = total - full * slots;
-    double units = (double)full * per_cu;
-    if (tail > 0) units += split_tail(full, tail, slots) ? 0.5 * ((2 * tail + cus - 1) / cus) : (double)((tail + cus - 1) / cus);
-    return units / (st == 2 ? 0.80 : 0.76);
-  };
-  const int stages = d.stages == 2 || d.stages == 3 ? d.stages : (2 * total >= 5 * cus && cost(2) < cost(3) ? 2 : 3);
+  const int stages = d.stages == 2 || d.stages == 3 ? d.stages : v2_pick_stages(total, cus);
   const int wg_per_cu = stages == 2 ? 3 : 2;
   const int slots = wg_per_cu * cus;
   int nbig = total / slots * slots, tail = total - nbig;
-  if (!split_tail(nbig / slots, tail, slots)) { nbig = total; tail = 0; }     // no ragged round worth splitting
+  if (!v2_split_tail(nbig / slots, tail, slots)) { nbig = total; tail = 0; }     // no ragged round worth splitting
   if (stages == 2) {
     const size_t lds2 = lds / 3 * 2;
     const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_mixed_kernel<CONV, 2, AMAX>);
@@ -1034,7 +1038,17 @@ hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
     return launch_cfg<1, 1, CONV>(d, stream);
   }
   if (d.K < KS_MIN_KTILES * BK && d.N > 64 && blocks(128, 128) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
-  if (d.N > 64 && blocks(128, 128) >= 384) return launch_cfg<2, 2, CONV>(d, stream);
+  if (d.N > 64 && blocks(128, 128) >= 384) {
+    // long K, many tiles: the K-split kernel (one workgroup per CU: rounds x (2.08 us x K-tiles + 10 us), calibrated on
+    // fc6 / fc7 / conv2_2 .. conv4_2) unless its rounds fall so badly that the 128x64 kernel's finer rounds win by 5 %
+    // (1080x720 conv4_3: 384 tiles = 1.5 rounds, 587 us, against 768 tiles of 128x64, 473 us measured on its 380-tile twin)
+    const int cus = device_cu_count(), nkt = d.K / BK;
+    const long t128 = blocks(128, 128), t64 = blocks(128, 64);
+    const double t_ks = (double)((t128 + cus - 1) / cus) * (2.08 * nkt + 10.0);
+    const double t_v2 = v2_cost_units((int)t64, v2_pick_stages((int)t64, cus), cus) * 0.853 * nkt;
+    if (t64 < (1 << 30) && t_v2 < 0.95 * t_ks) return launch_cfg<2, 1, CONV>(d, stream);
+    return launch_cfg<2, 2, CONV>(d, stream);
+  }
   if (d.N <= 64 && blocks(128, 64) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
   if (d.N > 64 && blocks(128, 128) >= 200 && blocks(128, 128) <= 256) return launch_cfg<2, 2, CONV>(d, stream);
   if (blocks(128, 64) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
@@ -1042,18 +1056,6 @@ hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
 }
 
 }  // namespace
-
-int mfma_gemm_ntiles_n(const GemmDesc& d) {
-  if (d.amax_val != nullptr) return (d.N + 63) / 64;        // mirrors launch_pick: the arg-max variants use BN = 64
-  const int pm = d.plan_M > 0 ? d.plan_M : d.M;
-  auto blocks = [&](int bm, int bn) { return (long)((pm + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
-  int bn;
-  if (d.N > 64 && blocks(128, 128) >= 384) bn = d.K < KS_MIN_KTILES * BK ? 64 : 128;   // mirrors launch_pick
-  else if (d.N <= 64 && blocks(128, 64) >= 384) bn = 64;
-  else if (d.N > 64 && blocks(128, 128) >= 200 && blocks(128, 128) <= 256) bn = 128;
-  else bn = 64;
-  return (d.N + bn - 1) / bn;
-}
 
 // Few 128x128 tiles and a long K: split K so that ~224-256 workgroups exist (one round on 256 CUs).  Every slice
 // keeps an even number (>= 16) of K-tiles for the K-split kernel.

@@ -248,6 +248,7 @@ def test_streamk_dense_gemm_single_lane():
                                   (128, 300, 360, 128, 1),          # conv2_2 at 720x600: tail plan (single-lane mode)
                                   (256, 150, 180, 256, 1),          # conv3_3: tail plan
                                   (512, 75, 90, 512, 1),            # conv4_3: 212 tiles, odd height
+                                  (512, 90, 136, 512, 3),           # conv4_3 at 1080x720: 384 tiles of 1.5 rounds -> costed onto 128x64 tiles
                                   (512, 19, 23, 512, 1)])           # few tiles: split-K + pooled reduce
 def test_conv_relu_pool_fused_equals_conv_then_pool(case):
     """The pool taken in the conv epilogue (pool-window-ordered implicit GEMM rows) must be bit-identical to the conv
