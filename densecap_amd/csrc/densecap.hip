@@ -471,9 +471,9 @@ int lm_sample_parts(dc_ctx* ctx, Lane& L, const float* codes, const LmPart* part
 
 // <= 64 rows (webcam regime): ONE persistent launch for the T+1 LSTM steps with [Wout; Wh^T] resident in LDS
 // (lm_persistent.hip) after the encoder and the image step on the usual kernels.  Bit-identical tokens to the GEMM route.
-// Measured (profiles/r03_persistent_decode.md): at <= 64 rows BOTH routes are bounded by the same thing -- the 256-long
-// chain of dependent v_mfma_f32_32x32x2_f32 on one accumulator block per wave (10.8 us a step; the K order is part of the
-// result, so the chain cannot be cut without changing tokens) -- and the persistent launch then pays two cross-XCD
+// Measured (profiles/r03_persistent_decode.md): at <= 64 rows BOTH routes are bounded by the same thing -- one wave per
+// SIMD issuing the 256 v_mfma_f32_32x32x2_f32 of its single accumulator block with its own operand reads in line
+// (10.8 us a step; two accumulation chains per block change nothing) -- and the persistent launch then pays two cross-XCD
 // hand-offs a step (~9 us) where the GEMM route pays two kernel boundaries (~6 us): 0.71 vs 0.66 ms per 50-row decode.
 // The persistent route is therefore OPT-IN (dc_debug_set "decode_route" = 2); the default stays the GEMM route.
 bool lm_use_persistent(const dc_ctx* ctx, int n) {

@@ -15,8 +15,8 @@ rows = [int(a) for a in sys.argv[2:] if a.lstrip("-").isdigit()] or [1000, 300, 
 W = make_synthetic_weights(seed=1234)
 m = DenseCapModel(W, device=0)
 ctx = m.ctx
-if "--gemm-route" in sys.argv:          # force the GEMM decode also at <= 64 rows
-    check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 1), "dc_debug_set")
+if "--persistent" in sys.argv:          # the persistent LDS-resident decode at <= 64 rows (the default is the GEMM decode)
+    check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 2), "dc_debug_set")
 rng = np.random.default_rng(0)
 beam = 0
 for a in sys.argv:
