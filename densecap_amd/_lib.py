@@ -61,6 +61,7 @@ _SIGS = {
                                   C.POINTER(C.c_double)]),
     "dc_debug_fetch": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
     "dc_debug_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "dc_debug_plan_gemm": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, c_int32_p]),
     "dc_comm_unique_id": (C.c_int, [C.c_void_p]),
     "dc_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "dc_comm_destroy": (None, [C.c_void_p]),

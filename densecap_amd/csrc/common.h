@@ -90,7 +90,19 @@ size_t mfma_gemm_sk_ws_floats(int wgs);
 hipError_t launch_mfma_gemm_sk(const GemmDesc& d, int wgs, int np, float* ws, hipStream_t stream);
 // force the K-split 128x128 kernel (honours m_begin / a_rows / splitk)
 hipError_t launch_mfma_gemm_ks(const GemmDesc& d, hipStream_t stream);
-// number of N-tiles launch_mfma_gemm will use for this problem (size of the arg-max partial rows)
+// How a contraction is carried out (mfma_gemm_plan): kind = what run_gemm does around the launch, route = the kernel family.
+enum { GEMM_PLAN_PLAIN = 0, GEMM_PLAN_SPLITK = 1, GEMM_PLAN_STREAMK = 2, GEMM_PLAN_TAIL = 3 };
+enum { GEMM_ROUTE_KS = 0, GEMM_ROUTE_V2_128x64 = 1, GEMM_ROUTE_V2_128x128 = 2, GEMM_ROUTE_V2_64x64 = 3 };
+struct GemmPlan {
+  int kind = GEMM_PLAN_PLAIN, route = GEMM_ROUTE_KS;
+  int stages = 0;            // LDS ring depth of a 128x64 launch (2 or 3), 0 otherwise
+  int splitk = 1;            // GEMM_PLAN_SPLITK
+  int m_split = 0;           // GEMM_PLAN_STREAMK / GEMM_PLAN_TAIL: rows [0, m_split) run as whole tiles
+  int sk_wgs = 0, sk_np = 0; // GEMM_PLAN_STREAMK
+  int tail_splitk = 1;       // GEMM_PLAN_TAIL
+};
+// Pure function of the problem, the scheduling mode and the workspace size (no device needed beyond its CU count).
+void mfma_gemm_plan(const GemmDesc& d, bool serial_mode, int tail_mode, size_t ws_floats, GemmPlan* plan);
 // Launches the fp32 MFMA kernel on `stream`; returns hipSuccess or the launch error.
 hipError_t launch_mfma_gemm(const GemmDesc& d, hipStream_t stream);
 double gemm_flops(const GemmDesc& d);

@@ -188,19 +188,17 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, float* ws = nullp
     (void)hipEventRecord(pe.a, s);
   }
   hipError_t e = hipSuccess;
-  const bool ws_ok = ws != nullptr && d.ldc % 4 == 0 && d.N % 4 == 0;
-  int m_split = 0, tail_sp = 1;
-  const int sp = ws_ok ? mfma_gemm_splitk(d, ws_floats) : 1;
-  if (sp > 1 && (size_t)sp * d.M * d.N <= ws_floats) {
-    // few tiles, long K: every tile is shared by `sp` workgroups
-    d.splitk = sp; d.splitk_ws = ws;
+  GemmPlan pl;                                                // mfma_gemm_plan decides; this function only acts on it
+  mfma_gemm_plan(d, ctx->serial_mode, ctx->tail_mode, ws != nullptr ? ws_floats : 0, &pl);
+  const int m_split = pl.m_split;
+  if (pl.kind == GEMM_PLAN_SPLITK) {
+    // few tiles, long K: every tile is shared by `splitk` workgroups
+    d.splitk = pl.splitk; d.splitk_ws = ws;
     e = launch_mfma_gemm(d, s);
     if (e == hipSuccess)
-      e = d.pool ? launch_splitk_reduce_pool(ws, sp, d.bias, d.C, 0, d.M, d.N, d.ldc, d.H, d.Wd, d.relu, s)
-                 : launch_splitk_reduce(ws, sp, d.bias, d.C, d.M, d.N, d.ldc, d.relu, s);
-  } else if (int sk_wgs = 0, sk_np = 0; ws_ok && ctx->serial_mode && ctx->tail_mode == 0 &&
-                                          mfma_gemm_sk_plan(d, &m_split, &sk_wgs, &sk_np) &&
-                                          mfma_gemm_sk_ws_floats(sk_wgs) <= ws_floats) {
+      e = d.pool ? launch_splitk_reduce_pool(ws, pl.splitk, d.bias, d.C, 0, d.M, d.N, d.ldc, d.H, d.Wd, d.relu, s)
+                 : launch_splitk_reduce(ws, pl.splitk, d.bias, d.C, d.M, d.N, d.ldc, d.relu, s);
+  } else if (pl.kind == GEMM_PLAN_STREAMK) {
     // tile count not a multiple of the CU count: whole tiles for the full rounds, the last partial round shared evenly
     // along K by all CUs (stream-K with in-kernel fix-up: no reduce launch, one partial tile per cut)
     if (m_split > 0) {
@@ -216,11 +214,11 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, float* ws = nullp
         (void)hipMemset(ctx->fault_dev, 0, 64);
       }
       b.sk_fault = ctx->fault_dev;
-      e = launch_mfma_gemm_sk(b, sk_wgs, sk_np, ws, s);
+      e = launch_mfma_gemm_sk(b, pl.sk_wgs, pl.sk_np, ws, s);
     }
-  } else if (ws_ok && ctx->serial_mode && ctx->tail_mode <= 1 && mfma_gemm_tail_plan(d, &m_split, &tail_sp) &&
-             (size_t)tail_sp * (d.M - m_split) * d.N <= ws_floats) {
+  } else if (pl.kind == GEMM_PLAN_TAIL) {
     // tile count not a multiple of the CU count: whole tiles for the full rounds, K-split for the last one
+    const int tail_sp = pl.tail_splitk;
     if (m_split > 0) {
       GemmDesc a = d;
       a.M = m_split; a.a_rows = d.M;
@@ -1271,6 +1269,23 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
     }
   }
   return ctx->fail(DC_E_INVALID, "dc_debug_fetch: unknown name '%s'", name);
+}
+
+int dc_debug_plan_gemm(int64_t M, int64_t N, int64_t K, int64_t plan_M, int conv_cin, int argmax, int serial_mode,
+                       int32_t* out8) {
+  if (!out8 || M <= 0 || N <= 0 || K <= 0 || K % 32 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX || plan_M < 0 ||
+      plan_M > M || (conv_cin != 0 && (conv_cin % 32 || K != 9 * (int64_t)conv_cin)))
+    return DC_E_INVALID;
+  GemmDesc d;
+  static float dummy;                                        // only the POINTER's presence matters to the planner
+  d.M = (int)M; d.N = (int)N; d.K = (int)K; d.ldc = (int)N; d.plan_M = (int)plan_M;
+  if (conv_cin) { d.conv = 1; d.Cin = conv_cin; }
+  if (argmax) d.amax_val = &dummy;
+  GemmPlan pl;
+  mfma_gemm_plan(d, serial_mode != 0, 0, kSplitkWsFloats, &pl);
+  const int32_t v[8] = {pl.kind, pl.route, pl.stages, pl.splitk, pl.m_split, pl.sk_wgs, pl.sk_np, pl.tail_splitk};
+  memcpy(out8, v, sizeof(v));
+  return DC_OK;
 }
 
 int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value) {

@@ -973,6 +973,8 @@ hipError_t launch_mixed(const GemmDesc& d, hipStream_t stream, int ntm, int ntn,
   return hipGetLastError();
 }
 
+bool cfg128_uses_ks(const GemmDesc& d);
+
 template <int TM, int TN, bool CONV>
 hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -982,9 +984,8 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   const bool fits = CONV ? ((size_t)(d.a_rows > d.M ? d.a_rows : d.M) * d.Cin * 4 < CV_PAD && d.Cin <= 2048) : ((size_t)BM * d.K * 4 < 0xfffffff0ull);
   if (!fits || (size_t)BN * d.K * 4 >= 0xfffffff0ull) return hipErrorInvalidValue;
   if constexpr (TM == 2 && TN == 2) {
-    const bool forced = d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0;
     if (d.amax_val != nullptr) return hipErrorInvalidValue;    // the arg-max epilogue lives in the 64-column v2 variant
-    if ((d.K % (2 * BK * d.splitk)) == 0 && (forced || d.K >= KS_MIN_KTILES * BK)) {   // short K loops do not amortise the 4-phase reduction
+    if (cfg128_uses_ks(d)) {                                   // short K loops do not amortise the 4-phase reduction
       // 64 KiB operand ring, reused as the 4 x 16 KiB reduction slots; leaves 96 KiB of the CU's LDS to co-resident workgroups
       const size_t lds_ks = (size_t)2 * (BM + BN) * BK * sizeof(float);
       const void* fn = reinterpret_cast<const void*>(&mfma_gemm_ks_kernel<CONV>);
@@ -1024,20 +1025,19 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   }
 }
 
-template <bool CONV>
-hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
-  if (d.splitk > 1) return launch_cfg<2, 2, CONV>(d, stream);
-  // Tile choice: largest tile that still yields >= ~1.5 workgroups per CU (256 CUs) -- for ONE image of a group (plan_M)
+// Tile configuration of a plain launch: the largest tile that still yields >= ~1.5 workgroups per CU (256 CUs) -- for ONE
+// image of a group (plan_M), with the measured exceptions below.  Pure function of the problem (mfma_gemm_plan reports it).
+enum TileCfg { CFG_128x128 = 0, CFG_128x64 = 1, CFG_64x64 = 2 };
+TileCfg pick_cfg(const GemmDesc& d) {
+  if (d.splitk > 1) return CFG_128x128;
   const int pm = d.plan_M > 0 ? d.plan_M : d.M;
   auto blocks = [&](int bm, int bn) { return (long)((pm + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
   // fused arg-max: 128x64 tiles (two or three workgroups per CU, see launch_mixed) overlap one tile's epilogue
   // with the others' K loops -- measured 2.43 vs 2.51 ms for the 15 decode steps at 1000 x 10498 with two
   // and the same holds for every K loop too short for the K-split kernel (conv2_1: 214 -> 178 us)
-  if (d.amax_val != nullptr) {           // arg-max epilogue: 64-column tiles only (the partial rows are indexed by tile_n)
-    if (blocks(128, 64) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
-    return launch_cfg<1, 1, CONV>(d, stream);
-  }
-  if (d.K < KS_MIN_KTILES * BK && d.N > 64 && blocks(128, 128) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
+  if (d.amax_val != nullptr)             // arg-max epilogue: 64-column tiles only (the partial rows are indexed by tile_n)
+    return blocks(128, 64) >= 384 ? CFG_128x64 : CFG_64x64;
+  if (d.K < KS_MIN_KTILES * BK && d.N > 64 && blocks(128, 128) >= 384) return CFG_128x64;
   if (d.N > 64 && blocks(128, 128) >= 384) {
     // long K, many tiles: the K-split kernel (one workgroup per CU: rounds x (2.08 us x K-tiles + 10 us), calibrated on
     // fc6 / fc7 / conv2_2 .. conv4_2) unless its rounds fall so badly that the 128x64 kernel's finer rounds win by 5 %
@@ -1046,13 +1046,26 @@ hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
     const long t128 = blocks(128, 128), t64 = blocks(128, 64);
     const double t_ks = (double)((t128 + cus - 1) / cus) * (2.08 * nkt + 10.0);
     const double t_v2 = v2_cost_units((int)t64, v2_pick_stages((int)t64, cus), cus) * 0.853 * nkt;
-    if (t64 < (1 << 30) && t_v2 < 0.95 * t_ks) return launch_cfg<2, 1, CONV>(d, stream);
-    return launch_cfg<2, 2, CONV>(d, stream);
+    return t64 < (1 << 30) && t_v2 < 0.95 * t_ks ? CFG_128x64 : CFG_128x128;
   }
-  if (d.N <= 64 && blocks(128, 64) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
-  if (d.N > 64 && blocks(128, 128) >= 200 && blocks(128, 128) <= 256) return launch_cfg<2, 2, CONV>(d, stream);
-  if (blocks(128, 64) >= 384) return launch_cfg<2, 1, CONV>(d, stream);
-  return launch_cfg<1, 1, CONV>(d, stream);
+  if (d.N <= 64 && blocks(128, 64) >= 384) return CFG_128x64;
+  if (d.N > 64 && blocks(128, 128) >= 200 && blocks(128, 128) <= 256) return CFG_128x128;
+  if (blocks(128, 64) >= 384) return CFG_128x64;
+  return CFG_64x64;
+}
+// a 128x128 launch runs the K-split kernel when its K loop is long enough (or the caller's row window / split-K needs it)
+bool cfg128_uses_ks(const GemmDesc& d) {
+  const bool forced = d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0;
+  return d.amax_val == nullptr && (d.K % (2 * BK * d.splitk)) == 0 && (forced || d.K >= KS_MIN_KTILES * BK);
+}
+
+template <bool CONV>
+hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
+  switch (pick_cfg(d)) {
+    case CFG_128x128: return launch_cfg<2, 2, CONV>(d, stream);
+    case CFG_128x64: return launch_cfg<2, 1, CONV>(d, stream);
+    default: return launch_cfg<1, 1, CONV>(d, stream);
+  }
 }
 
 }  // namespace
@@ -1242,6 +1255,38 @@ double gemm_flops(const GemmDesc& d) {
 bool mfma_gemm_can_pool(const GemmDesc& d) {
   return d.conv && (size_t)d.M * d.Cin * 4 < CV_PAD && d.Cin <= 2048 && (size_t)128 * d.K * 4 < 0xfffffff0ull &&
          d.N % 4 == 0 && d.ldc % 4 == 0;
+}
+
+// How one contraction will be carried out -- the ONE place that decides (run_gemm in densecap.hip acts on it, and
+// dc_debug_plan_gemm reports it so that the policy can be pinned by tests without a GPU).
+void mfma_gemm_plan(const GemmDesc& d, bool serial_mode, int tail_mode, size_t ws_floats, GemmPlan* p) {
+  *p = GemmPlan();
+  const bool ws_ok = ws_floats > 0 && d.ldc % 4 == 0 && d.N % 4 == 0;
+  GemmDesc q = d;                                            // the launch that follows the choice (its split factor fixes the route)
+  const int sp = ws_ok ? mfma_gemm_splitk(d, ws_floats) : 1;
+  if (sp > 1 && (size_t)sp * d.M * d.N <= ws_floats) {
+    p->kind = GEMM_PLAN_SPLITK; p->splitk = sp; q.splitk = sp;
+  } else if (ws_ok && serial_mode && tail_mode == 0 && mfma_gemm_sk_plan(d, &p->m_split, &p->sk_wgs, &p->sk_np) &&
+             mfma_gemm_sk_ws_floats(p->sk_wgs) <= ws_floats) {
+    p->kind = GEMM_PLAN_STREAMK; p->route = GEMM_ROUTE_KS;
+    return;
+  } else if (ws_ok && serial_mode && tail_mode <= 1 && mfma_gemm_tail_plan(d, &p->m_split, &p->tail_splitk) &&
+             (size_t)p->tail_splitk * (d.M - p->m_split) * d.N <= ws_floats) {
+    p->kind = GEMM_PLAN_TAIL; p->route = GEMM_ROUTE_KS; p->sk_wgs = p->sk_np = 0;
+    return;
+  } else {
+    p->m_split = 0; p->sk_wgs = p->sk_np = 0; p->tail_splitk = 1;
+  }
+  switch (pick_cfg(q)) {
+    case CFG_128x128: p->route = cfg128_uses_ks(q) ? GEMM_ROUTE_KS : GEMM_ROUTE_V2_128x128; break;
+    case CFG_128x64: {
+      const int pm = d.M, total = ((pm + 127) / 128) * ((d.N + 63) / 64);
+      p->route = GEMM_ROUTE_V2_128x64;
+      p->stages = d.stages == 2 || d.stages == 3 ? d.stages : v2_pick_stages(total, device_cu_count());
+      break;
+    }
+    default: p->route = GEMM_ROUTE_V2_64x64;
+  }
 }
 
 hipError_t launch_mfma_gemm(const GemmDesc& d, hipStream_t stream) {

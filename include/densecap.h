@@ -193,6 +193,16 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
  *                        Same K order either way: bit-identical results.
  * Returns DC_OK or DC_E_INVALID for an unknown name / bad value. */
 int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value);
+/* Planning query -- pure (no context, no GPU: a missing device counts as 256 CUs): how the contraction engine carries out
+ * C[M,N] = A[M,K] . W[N,K]^T (conv_cin != 0: the implicit GEMM of a 3x3 convolution with that many input channels,
+ * K = 9*conv_cin; argmax != 0: the vocabulary projection with its fused row arg-max; plan_M = rows of ONE image when M
+ * holds a group of images, 0 = M; serial_mode = the dc_set_lanes(1) scheduling).  out8 = {kind, route, stages, splitk,
+ * m_split, sk_workgroups, sk_units, tail_splitk}: kind 0 plain launch, 1 split-K + reduce, 2 stream-K over the last
+ * round, 3 K-split tail plan; route 0 K-split 128x128, 1 128x64 tiles, 2 128x128 tiles, 3 64x64 tiles; stages = LDS ring
+ * depth of a 128x64 launch.  Exists so that the policy (and its invariance under image groups) is pinned by tests that
+ * need no GPU.  Returns DC_OK or DC_E_INVALID. */
+int dc_debug_plan_gemm(int64_t M, int64_t N, int64_t K, int64_t plan_M, int conv_cin, int argmax, int serial_mode,
+                       int32_t* out8);
 
 /* ---- multi-GPU: image shards + ONE gather ------------------------------------ */
 /* The reference binds one device (densecap/utils.lua:22-36) and loops over images on it

@@ -1,0 +1,138 @@
+"""The contraction engine's PLANNING (which kernel family, ring depth, split-K factor, stream-K / tail plan) is a pure
+function exported through the C ABI (dc_debug_plan_gemm): pinned here without a GPU.
+
+* the table of the BASELINE workloads (a policy change must be a conscious edit of this file);
+* image groups: a launch over two images' rows (dc_set_group(2)) must be planned exactly like one image alone wherever
+  the plan fixes the fp32 summation order -- this is what makes grouped results bit-identical (a 300-proposal fc6 once
+  got another split factor in a group because of a workspace test on the group's rows);
+* split-K factors cut K into equal, even runs of K-tiles."""
+import ctypes as C
+
+import pytest
+
+from densecap_amd._lib import lib
+
+KIND = ["plain", "splitk", "streamk", "tail"]
+ROUTE = ["ks", "v2_128x64", "v2_128x128", "v2_64x64"]
+VOCAB_STEP = 10560 + 2048            # [Wout padded to 64 | Wh^T]: the decode step's merged projection
+
+
+def plan(M, N, K, plan_M=0, cin=0, amax=0, serial=0):
+    o = (C.c_int32 * 8)()
+    rc = lib().dc_debug_plan_gemm(M, N, K, plan_M, cin, amax, serial, o)
+    assert rc == 0, (rc, M, N, K)
+    v = list(o)
+    return dict(kind=KIND[v[0]], route=ROUTE[v[1]], stages=v[2], splitk=v[3], m_split=v[4], sk_wgs=v[5], sk_np=v[6],
+                tail_splitk=v[7])
+
+
+def order_class(p):
+    """What decides an element's fp32 summation order: the K-split kernel (and how K is cut) or the v2 walk (every v2 tile
+    shape and ring depth adds in the same order)."""
+    if p["kind"] == "splitk":
+        return ("ks", p["splitk"])
+    if p["kind"] in ("streamk", "tail"):
+        return (p["kind"],)
+    return ("ks", 1) if p["route"] == "ks" else ("v2",)
+
+
+def conv_rows(H, W, level):
+    for _ in range(level):
+        H, W = (H + 1) // 2, (W + 1) // 2
+    return H * W
+
+
+# (name, M, N, K, conv Cin, arg-max, multi-lane plan, single-image plan) at 720x600 / 1000 proposals
+TABLE_720x600 = [
+    ("conv1_2", 432000, 64, 576, 64, 0, ("plain", "v2_128x64", 2, 1), ("plain", "v2_128x64", 2, 1)),
+    ("conv2_1", 108000, 128, 576, 64, 0, ("plain", "v2_128x64", 2, 1), ("plain", "v2_128x64", 2, 1)),
+    ("conv2_2", 108000, 128, 1152, 128, 0, ("plain", "v2_128x64", 2, 1), ("plain", "v2_128x64", 2, 1)),
+    ("conv3_1", 27000, 256, 1152, 128, 0, ("plain", "v2_128x64", 2, 1), ("plain", "v2_128x64", 2, 1)),
+    ("conv3_2", 27000, 256, 2304, 256, 0, ("plain", "v2_128x64", 2, 1), ("plain", "v2_128x64", 2, 1)),
+    ("conv4_1", 6750, 512, 2304, 256, 0, ("plain", "v2_128x128", 0, 1), ("plain", "v2_128x128", 0, 1)),
+    ("conv4_2", 6750, 512, 4608, 512, 0, ("plain", "ks", 0, 1), ("streamk", "ks", 0, 1)),
+    ("conv5_x", 1710, 512, 4608, 512, 0, ("splitk", "ks", 0, 4), ("splitk", "ks", 0, 4)),
+    ("rpn_conv", 1710, 256, 4608, 512, 0, ("splitk", "ks", 0, 9), ("splitk", "ks", 0, 9)),
+    ("rpn_heads", 1710, 72, 256, 0, 0, ("plain", "v2_64x64", 0, 1), ("plain", "v2_64x64", 0, 1)),
+    ("fc6", 1000, 4096, 25088, 0, 0, ("plain", "ks", 0, 1), ("plain", "ks", 0, 1)),
+    ("fc7", 1000, 4096, 4096, 0, 0, ("plain", "ks", 0, 1), ("plain", "ks", 0, 1)),
+    ("lm_encoder", 1000, 512, 4096, 0, 0, ("splitk", "ks", 0, 8), ("splitk", "ks", 0, 8)),
+    ("step0_gates", 1000, 2048, 512, 0, 0, ("plain", "v2_64x64", 0, 1), ("plain", "v2_64x64", 0, 1)),
+    ("decode_step", 1000, VOCAB_STEP, 512, 0, 1, ("plain", "v2_128x64", 2, 1), ("plain", "v2_128x64", 2, 1)),
+    ("last_step", 1000, 10498, 512, 0, 1, ("plain", "v2_128x64", 2, 1), ("plain", "v2_128x64", 2, 1)),
+]
+
+
+@pytest.mark.parametrize("row", TABLE_720x600, ids=[r[0] for r in TABLE_720x600])
+def test_plan_of_the_headline_workload(row):
+    name, M, N, K, cin, amax, multi, single = row
+    for serial, want in ((0, multi), (1, single)):
+        p = plan(M, N, K, 0, cin, amax, serial)
+        assert (p["kind"], p["route"], p["stages"], p["splitk"]) == want, (name, serial, p)
+
+
+def test_plans_of_the_other_baseline_workloads():
+    # 300 proposals (configs[2]): fc6's 96 tiles are cut 8 ways over three rounds; the decode keeps the three-stage ring
+    assert plan(300, 4096, 25088)["splitk"] == 8 and plan(300, 4096, 25088)["kind"] == "splitk"
+    assert plan(300, 4096, 4096)["splitk"] == 2
+    p = plan(300, VOCAB_STEP, 512, amax=1)
+    assert (p["route"], p["stages"]) == ("v2_128x64", 3)
+    # webcam regime, 50 proposals at 480x320: 64x64 decode tiles, fc6 cut 8 ways, tiny convs cut down to 6-K-tile runs
+    assert plan(50, VOCAB_STEP, 512, amax=1)["route"] == "v2_64x64"
+    assert plan(50, 4096, 25088)["splitk"] == 8
+    assert plan(conv_rows(320, 480, 4), 512, 4608, cin=512)["splitk"] == 12           # conv5_x: 20 tiles
+    assert plan(conv_rows(320, 480, 4), 256, 4608, cin=512)["splitk"] == 24           # RPN conv: 10 tiles
+    # 1080x720 (configs[4]): conv4_3's 384 tiles of 1.5 K-split rounds are costed onto 128x64 tiles; 2000-row fc6 stays
+    assert plan(4 * 45 * 68, 512, 4608, cin=512)["route"] == "v2_128x64"
+    assert plan(2000, 4096, 25088)["route"] == "ks" and plan(2000, 4096, 25088)["kind"] == "plain"
+    # 500 proposals: 128 tiles would leave half the chip idle -> two workgroups per tile
+    assert plan(500, 4096, 25088)["splitk"] == 2
+
+
+def test_groups_of_two_images_are_planned_like_one_image():
+    """dc_set_group(2): the launch covers 2 x rows, planned with plan_M = rows.  Wherever the plan fixes the summation
+    order it must be the single image's (multi-lane scheduling: groups are not used in single-image mode)."""
+    bad = []
+    dense = [(4096, 25088), (4096, 4096), (512, 4096), (2048, 512), (72, 256), (5, 4096)]
+    for P in list(range(1, 130)) + list(range(130, 2100, 13)) + [256, 300, 384, 385, 500, 512, 640, 1000, 1024, 2000]:
+        for N, K in dense:
+            a, b = plan(P, N, K), plan(2 * P, N, K, plan_M=P)
+            if order_class(a) != order_class(b):
+                bad.append(("dense", P, N, K, a, b))
+        a, b = plan(P, VOCAB_STEP, 512, amax=1), plan(2 * P, VOCAB_STEP, 512, plan_M=P, amax=1)
+        if order_class(a) != order_class(b):
+            bad.append(("decode", P, a, b))
+    convs = [(64, 64, 0), (64, 128, 1), (128, 128, 1), (128, 256, 2), (256, 256, 2), (256, 512, 3), (512, 512, 3),
+             (512, 512, 4), (512, 256, 4)]
+    for (H, W) in [(600, 720), (480, 720), (320, 480), (720, 1080), (224, 288), (203, 301), (1200, 1600), (64, 64),
+                   (97, 333), (600, 900)]:
+        for cin, cout, level in convs:
+            rows = conv_rows(H, W, level)
+            a, b = plan(rows, cout, 9 * cin, cin=cin), plan(2 * rows, cout, 9 * cin, plan_M=rows, cin=cin)
+            if order_class(a) != order_class(b):
+                bad.append(("conv", H, W, cin, cout, level, a, b))
+    assert not bad, bad[:5]
+
+
+def test_split_factors_cut_k_into_equal_even_runs_and_fit_the_workspace():
+    ws_floats = 1600 * 128 * 128
+    for M in (1, 50, 64, 128, 200, 300, 384, 500, 640, 1000, 1710, 2400):
+        for N, K in [(4096, 25088), (4096, 4096), (512, 4096), (512, 4608), (256, 4608), (512, 2304), (1024, 6272)]:
+            for serial in (0, 1):
+                p = plan(M, N, K, serial=serial)
+                sp = p["splitk"] if p["kind"] == "splitk" else (p["tail_splitk"] if p["kind"] == "tail" else 1)
+                nkt = K // 32
+                assert nkt % sp == 0 and (sp == 1 or (nkt // sp) % 2 == 0), (M, N, K, p)
+                if p["kind"] == "splitk":
+                    assert sp * 2 * M * N <= ws_floats, (M, N, K, p)          # also for a group of two such images
+                    assert p["route"] == "ks"
+
+
+def test_bad_arguments_are_refused():
+    o = (C.c_int32 * 8)()
+    L = lib()
+    assert L.dc_debug_plan_gemm(0, 64, 64, 0, 0, 0, 0, o) < 0
+    assert L.dc_debug_plan_gemm(64, 64, 33, 0, 0, 0, 0, o) < 0                 # K must be a multiple of the 32-wide K-tile
+    assert L.dc_debug_plan_gemm(64, 64, 576, 0, 32, 0, 0, o) < 0               # K != 9 * Cin
+    assert L.dc_debug_plan_gemm(64, 64, 64, 65, 0, 0, 0, o) < 0                # plan_M > M
+    assert L.dc_debug_plan_gemm(64, 64, 64, 0, 0, 0, 0, None) < 0
