@@ -58,6 +58,7 @@ struct GemmDesc {
   // sk_wgs partial tiles of 128x128 floats; sk_flags[0..sk_wgs) zeroed before the launch; sk_fault = sticky device word
   // raised when an owner gives up waiting for a partner (checked by the host with the results)
   int stages = 0;             // LDS ring depth of the 128x64-tile kernel: 0 = by tile count, 3 (two workgroups per CU) or 2 (three per CU)
+  int force_cfg = 0;          // measurement hook (dc_debug_set "force_cfg"): 0 = planned, 1 = 128x128, 2 = 128x64, 3 = 64x64 tiles; 4 = planned tiles, no split-K
   const int* sk_lo = nullptr;
   int sk_np = 0;
   float* sk_slots = nullptr;

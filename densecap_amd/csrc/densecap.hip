@@ -96,6 +96,7 @@ struct dc_ctx {
   int64_t beam_chunk_floats = (int64_t)1 << 28;   // cap of the beam search's full-logits buffer (dc_debug_set)
   int decode_route = 0;      // 0 / 1 GEMM decode (default), 2 persistent LDS-resident decode at <= 64 rows (dc_debug_set)
   uint32_t* fault_dev = nullptr;   // sticky device word: a stream-K owner gave up waiting for its partner (checked with the results)
+  int force_cfg = 0;         // measurement hook: tile configuration of plain launches (dc_debug_set "force_cfg")
   int v2_stages = 0;         // LDS ring depth of the 128x64-tile kernel (dc_debug_set "v2_stages": 0 by tile count, 2 or 3 forced)
   int tail_mode = 0;         // partial last round in single-image mode: 0 stream-K, 1 K-split tail plan, 2 whole tiles (dc_debug_set)
   bool serial_mode = false;  // lanes == 1: idle CUs in a layer's last round are worth a tail split-K (dc_set_lanes)
@@ -182,6 +183,7 @@ hipEvent_t prof_event(dc_ctx* ctx) {
 int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, float* ws = nullptr, size_t ws_floats = 0) {
   GemmDesc d = d_in;
   d.stages = ctx->v2_stages;
+  d.force_cfg = ctx->force_cfg;
   ProfEvt pe{nullptr, nullptr, gemm_flops(d)};
   if (ctx->prof) {
     pe.a = prof_event(ctx); pe.b = prof_event(ctx);
@@ -1303,6 +1305,11 @@ int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value) {
   if (strcmp(name, "v2_stages") == 0) {
     if (value != 0 && value != 2 && value != 3) return ctx->fail(DC_E_INVALID, "dc_debug_set: v2_stages must be 0, 2 or 3");
     ctx->v2_stages = (int)value;
+    return DC_OK;
+  }
+  if (strcmp(name, "force_cfg") == 0) {
+    if (value < 0 || value > 4) return ctx->fail(DC_E_INVALID, "dc_debug_set: force_cfg must be 0..4");
+    ctx->force_cfg = (int)value;
     return DC_OK;
   }
   if (strcmp(name, "tail_mode") == 0) {

@@ -942,6 +942,11 @@ inline double v2_cost_units(int total, int stages, int cus) {
   if (tail > 0) units += v2_split_tail(full, tail, slots) ? 0.5 * ((2 * tail + cus - 1) / cus) : (double)((tail + cus - 1) / cus);
   return units / (stages == 2 ? 0.80 : 0.76);
 }
+// the same for 64x64 tiles (three workgroups per CU, half a 128x64 tile's work each, loop efficiency 0.72)
+inline double v2_cost_units64(int total, int cus) {
+  const int slots = 3 * cus, full = total / slots, tail = total - full * slots;
+  return 0.5 * ((double)full * 3 + (double)((tail + cus - 1) / cus)) / 0.72;
+}
 inline int v2_pick_stages(int total, int cus) {
   return 2 * total >= 5 * cus && v2_cost_units(total, 2, cus) < v2_cost_units(total, 3, cus) ? 2 : 3;
 }
@@ -1030,6 +1035,7 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
 enum TileCfg { CFG_128x128 = 0, CFG_128x64 = 1, CFG_64x64 = 2 };
 TileCfg pick_cfg(const GemmDesc& d) {
   if (d.splitk > 1) return CFG_128x128;
+  if (d.force_cfg >= 1 && d.force_cfg <= 3 && !(d.amax_val != nullptr && d.force_cfg == 1)) return (TileCfg)(d.force_cfg - 1);
   const int pm = d.plan_M > 0 ? d.plan_M : d.M;
   auto blocks = [&](int bm, int bn) { return (long)((pm + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
   // fused arg-max: 128x64 tiles (two or three workgroups per CU, see launch_mixed) overlap one tile's epilogue
@@ -1050,7 +1056,13 @@ TileCfg pick_cfg(const GemmDesc& d) {
   }
   if (d.N <= 64 && blocks(128, 64) >= 384) return CFG_128x64;
   if (d.N > 64 && blocks(128, 128) >= 200 && blocks(128, 128) <= 256) return CFG_128x128;
-  if (blocks(128, 64) >= 384) return CFG_128x64;
+  if (blocks(128, 64) >= 384) {
+    // a round and a half of 128x64 tiles, or finer 64x64 tiles?  (700-row fc7: 384 tiles of 128x64 on 512 slots, 244 us,
+    // against 704 of 64x64, 189 us; 480x320 conv2_2: 600 vs 1200 tiles, 105 vs 102 us) -- the round model decides
+    const int cus = device_cu_count();
+    const int t64 = (int)blocks(128, 64), t6464 = (int)blocks(64, 64);
+    return v2_cost_units(t64, v2_pick_stages(t64, cus), cus) <= v2_cost_units64(t6464, cus) ? CFG_128x64 : CFG_64x64;
+  }
   return CFG_64x64;
 }
 // a 128x128 launch runs the K-split kernel when its K loop is long enough (or the caller's row window / split-K needs it)
@@ -1105,6 +1117,13 @@ int mfma_gemm_splitk(const GemmDesc& d, size_t ws_floats) {
     const double reduce = sp > 1 ? 4.0 + (double)sp * pm * d.N * 4.0 / 3.0e6 : 0.0;
     return (double)rounds * ((double)(nkt / sp) * 2.08 + 10.0) + reduce;
   };
+  // (`est` describes the K-split kernel: with no one-round factor the comparison only holds if the UNSPLIT launch is that
+  // kernel too -- 720x480 conv4_2, 172 tiles, runs 64x64 tiles in 212 us unsplit where 4 x 3 rounds took 253 us)
+  if (best == 1) {
+    GemmDesc q = d;
+    q.force_cfg = 0;
+    if (pick_cfg(q) != CFG_128x128 || !cfg128_uses_ks(q)) return 1;
+  }
   int multi = best;
   double t_multi = est(best);
   for (int sp = best + 1; sp <= 32 && nkt >= KS_MIN_KTILES; ++sp) {
@@ -1263,7 +1282,7 @@ void mfma_gemm_plan(const GemmDesc& d, bool serial_mode, int tail_mode, size_t w
   *p = GemmPlan();
   const bool ws_ok = ws_floats > 0 && d.ldc % 4 == 0 && d.N % 4 == 0;
   GemmDesc q = d;                                            // the launch that follows the choice (its split factor fixes the route)
-  const int sp = ws_ok ? mfma_gemm_splitk(d, ws_floats) : 1;
+  const int sp = ws_ok && d.force_cfg == 0 ? mfma_gemm_splitk(d, ws_floats) : 1;
   if (sp > 1 && (size_t)sp * d.M * d.N <= ws_floats) {
     p->kind = GEMM_PLAN_SPLITK; p->splitk = sp; q.splitk = sp;
   } else if (ws_ok && serial_mode && tail_mode == 0 && mfma_gemm_sk_plan(d, &p->m_split, &p->sk_wgs, &p->sk_np) &&

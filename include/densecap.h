@@ -188,6 +188,9 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
  *                        count: 0 = per layer, whichever of stream-K over the last round / K-split tail plan / whole tiles
  *                        was measured fastest for that shape class (default), 1 = never stream-K, 2 = whole tiles only.
  *                        The routes differ in the fp32 summation order of the affected rows (each one deterministic).
+ *   "force_cfg"          measurement hook for tools/route_sweep.py: 0 = planned (default), 1 / 2 / 3 = plain launches use
+ *                        128x128 / 128x64 / 64x64 tiles and no split-K, 4 = planned tiles, no split-K.  Changes the fp32
+ *                        summation order with the kernel family; never set by the product path.
  *   "v2_stages"          LDS ring depth of the 128x64-tile contraction kernel: 0 = by tile count (default: two stages, three
  *                        workgroups per CU, once a launch has >= 3 tiles per CU; three stages otherwise), 2 or 3 forced.
  *                        Same K order either way: bit-identical results.

@@ -87,6 +87,11 @@ def test_plans_of_the_other_baseline_workloads():
     assert plan(2000, 4096, 25088)["route"] == "ks" and plan(2000, 4096, 25088)["kind"] == "plain"
     # 500 proposals: 128 tiles would leave half the chip idle -> two workgroups per tile
     assert plan(500, 4096, 25088)["splitk"] == 2
+    # no one-round factor and an unsplit launch that is NOT the K-split kernel: the split-K cost model does not apply
+    # (measured: 700-row fc7 189 us on 64x64 tiles vs 238 us split 4 ways; 720x480 conv4_2 212 vs 253 us)
+    for M, N, K, cin in [(700, 4096, 4096, 0), (700, 4096, 25088, 0), (30 * 45 * 4, 512, 4608, 512)]:
+        p = plan(M, N, K, cin=cin)
+        assert (p["kind"], p["route"]) == ("plain", "v2_64x64"), (M, N, K, p)
 
 
 def test_groups_of_two_images_are_planned_like_one_image():

@@ -22,6 +22,8 @@ beam = 0
 for a in sys.argv:
     if a.startswith("--stages="):         # LDS ring depth of the 128x64-tile kernel (2 = three workgroups per CU)
         check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"v2_stages", int(a.split("=")[1])))
+    if a.startswith("--force-cfg="):      # measurement hook: 2 = 128x64 tiles, 3 = 64x64 tiles for the step GEMM
+        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"force_cfg", int(a.split("=")[1])))
     if a.startswith("--beam="):          # LM:beamsearch with that many beams instead of the greedy LM:sample
         beam = int(a.split("=")[1])
         m.setBeamSize(beam)
