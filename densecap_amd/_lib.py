@@ -1,4 +1,5 @@
-"""ctypes binding of libdensecap_hip.so (the C ABI declared in include/densecap.h).
+"""ctypes binding of libdensecap_hip.so (the C ABI declared in include/densecap.h; measurement / test hooks in
+include/densecap_debug.h).
 
 There is deliberately NO fallback: if the shared library has not been built
 (`python -c "import __graft_entry__ as g; g.build()"` or `make -C densecap_amd/csrc`)
@@ -44,6 +45,7 @@ _SIGS = {
     "dc_last_error": (C.c_char_p, [C.c_void_p]),
     "dc_load_weights": (C.c_int, [C.c_void_p, C.POINTER(DcWeights)]),
     "dc_set_test_args": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_int]),
+    "dc_set_localization_test_args": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int]),
     "dc_set_lanes": (C.c_int, [C.c_void_p, C.c_int]),
     "dc_set_caption_order": (C.c_int, [C.c_void_p, C.c_int]),
     "dc_set_beam_size": (C.c_int, [C.c_void_p, C.c_int]),

@@ -140,7 +140,7 @@ __global__ void rpn_decode_kernel(const float* __restrict__ heads, int h, int w,
                                   const float* __restrict__ anchors, float x0, float y0, float sx, float sy,
                                   float img_h, float img_w, float* __restrict__ boxes, float* __restrict__ anc_out,
                                   float* __restrict__ trans_out, float* __restrict__ xyxy, float* __restrict__ p_out,
-                                  uint8_t* __restrict__ valid) {
+                                  uint8_t* __restrict__ valid, int clip) {
   const int total = k * h * w;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= total) return;
@@ -156,8 +156,10 @@ __global__ void rpn_decode_kernel(const float* __restrict__ heads, int h, int w,
   bx[1] = __fadd_rn(__fmul_rn(t[1], ha), ya);
   bx[2] = __fmul_rn(expf(t[2]), wa);
   bx[3] = __fmul_rn(expf(t[3]), ha);
-  f32x4 cb;
-  const bool v = clip_one(bx, 1.f, 1.f, img_w, img_h, cb);
+  // "Maybe clip boxes to image boundary" (LocalizationLayer.lua:272-300): with test_clip_boxes = false the boxes stay as
+  // transformed and every row is a candidate
+  f32x4 cb = bx;
+  const bool v = clip ? clip_one(bx, 1.f, 1.f, img_w, img_h, cb) : true;
   if (boxes) *reinterpret_cast<f32x4*>(boxes + (size_t)b * 4) = cb;
   if (anc_out) *reinterpret_cast<f32x4*>(anc_out + (size_t)b * 4) = f32x4{xa, ya, wa, ha};
   if (trans_out) *reinterpret_cast<f32x4*>(trans_out + (size_t)b * 4) = t;
@@ -570,9 +572,9 @@ hipError_t launch_box_iou(const float* b1, const float* b2, float* out, int B1, 
 }
 hipError_t launch_rpn_decode(const float* heads, int h, int w, int k, const float* anchors, float x0, float y0,
                              float sx, float sy, int img_h, int img_w, float* boxes, float* anchors_out,
-                             float* trans, float* x1y1x2y2, float* p, uint8_t* valid, hipStream_t s) {
+                             float* trans, float* x1y1x2y2, float* p, uint8_t* valid, int clip, hipStream_t s) {
   LAUNCH1D(rpn_decode_kernel, k * h * w, s, heads, h, w, k, anchors, x0, y0, sx, sy, (float)img_h, (float)img_w,
-           boxes, anchors_out, trans, x1y1x2y2, p, valid);
+           boxes, anchors_out, trans, x1y1x2y2, p, valid, clip);
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }

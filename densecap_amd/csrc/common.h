@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../include/densecap.h"
+#include "../../include/densecap_debug.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -139,30 +140,6 @@ hipError_t launch_recog_heads(const float* codes, const float* w5 /*(5,D): obj, 
                               const float* roi_boxes, float* obj, float* trans, float* final_boxes, int n, int D,
                               hipStream_t s);
 
-// ---- persistent LDS-resident greedy decode for <= 64 rows (lm_persistent.hip; LanguageModel.lua:293-348) ------------
-struct LmPersistArgs {
-  const float* dec_w = nullptr;   // (V1pad + 4Hd, Hd): vocabulary rows, zero pad, then Wh^T (gate-major)
-  const float* out_b = nullptr;   // (V1)
-  const float* xg = nullptr;      // (V+2, 4Hd): b + Emb.Wx per token
-  const float* h0 = nullptr;      // (n, Hd) hidden state after the image step
-  const float* c0 = nullptr;      // (n, Hd) cell state after the image step
-  int32_t* seq = nullptr;         // (n, T) tokens out, 1-based
-  const int32_t* n_dev = nullptr; // optional device-side row count (<= n)
-  int n = 0, T = 0, V1 = 0, V1pad = 0;
-  // filled by the launcher from its scratch buffer
-  float* hbuf = nullptr;          // [2][64][Hd] h of the odd / even steps
-  unsigned long long* best = nullptr;   // [T+1][8][64] packed (logit key, ~column) arg-max per step, XCD shard and row
-  unsigned* sync = nullptr;       // [0] fault word, [16..) arrival counters
-  unsigned long long* trace = nullptr;  // [2][32][8] phase time stamps of one vocabulary / one gate workgroup (PD_TRACE builds)
-  int nvocab_wg = 0, ngate_wg = 0;
-};
-size_t lm_persistent_scratch_bytes(int Hd, int T);
-bool lm_persistent_supported(int Hd, int V1pad, int n);
-// scratch: lm_persistent_scratch_bytes(Hd, T) device bytes (zeroed by the launcher where needed).  After the launch
-// scratch-relative word lm_persistent_fault_offset(...) is non-zero if the workgroups failed to rendezvous.
-hipError_t launch_lm_decode_persistent(LmPersistArgs a, int Hd, void* scratch, hipStream_t s);
-size_t lm_persistent_fault_offset(int Hd, int T);
-size_t lm_persistent_trace_offset(int Hd, int T);
 // hipFuncAttributeMaxDynamicSharedMemorySize per (device, kernel) -- mfma_gemm.hip
 hipError_t ensure_dyn_lds(const void* fn, size_t bytes);
 
@@ -191,7 +168,7 @@ hipError_t launch_box_iou(const float* b1, const float* b2, float* out, int B1, 
                           hipStream_t s);
 hipError_t launch_rpn_decode(const float* heads, int h, int w, int k, const float* anchors, float x0, float y0,
                              float sx, float sy, int img_h, int img_w, float* boxes, float* anchors_out,
-                             float* trans, float* x1y1x2y2, float* p, uint8_t* valid, hipStream_t s);
+                             float* trans, float* x1y1x2y2, float* p, uint8_t* valid, int clip, hipStream_t s);
 struct NmsWorkspace {
   // device scratch, sized for n_cap boxes (see boxes.hip)
   int n_cap = 0;

@@ -66,13 +66,11 @@ struct Lane {
   bool have_times = false;
   // beam search scratch (allocated on first use; beam_chunk() proposals x beam rows at a time)
   void* beam_base = nullptr;
-  int beam_rows = 0;
+  int beam_rows = 0, beam_chunk = 0, beam_width = 0;   // what the scratch was carved for (rows = chunk x beam)
   float *bm_enc = nullptr, *bm_gates = nullptr, *bm_h[2] = {nullptr, nullptr}, *bm_c[2] = {nullptr, nullptr};
   float *bm_logits = nullptr, *bm_top_lp = nullptr, *bm_lp[2] = {nullptr, nullptr};
   int32_t *bm_top_idx = nullptr, *bm_beams[2] = {nullptr, nullptr}, *bm_parent = nullptr, *bm_tok = nullptr;
   uint8_t* bm_fin = nullptr;
-  void* pd_scratch = nullptr;           // persistent LDS-resident decode (<= 64 rows): h ping-pong, arg-max keys, counters
-  bool pd_used = false;                 // the in-flight forward took the persistent decode route (its fault word is checked)
   hipStream_t aux = nullptr;            // single-image mode: second half of the decode rows runs here
   hipStream_t aux2 = nullptr;           // single-image mode: the final NMS runs here, beside the decode
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
@@ -94,13 +92,13 @@ struct dc_ctx {
   double host_enqueue_ms = 0;  // host ms per image spent enqueueing in the last dc_forward_batch
   int beam_size = 0;         // 0 = greedy LM:sample; > 0 = LM:beamsearch (LanguageModel.lua:129-131)
   int64_t beam_chunk_floats = (int64_t)1 << 28;   // cap of the beam search's full-logits buffer (dc_debug_set)
-  int decode_route = 0;      // 0 / 1 GEMM decode (default), 2 persistent LDS-resident decode at <= 64 rows (dc_debug_set)
   uint32_t* fault_dev = nullptr;   // sticky device word: a stream-K owner gave up waiting for its partner (checked with the results)
   int force_cfg = 0;         // measurement hook: tile configuration of plain launches (dc_debug_set "force_cfg")
   int v2_stages = 0;         // LDS ring depth of the 128x64-tile kernel (dc_debug_set "v2_stages": 0 by tile count, 2 or 3 forced)
   int tail_mode = 0;         // partial last round in single-image mode: 0 stream-K, 1 K-split tail plan, 2 whole tiles (dc_debug_set)
   bool serial_mode = false;  // lanes == 1: idle CUs in a layer's last round are worth a tail split-K (dc_set_lanes)
   int num_proposals = 300;  // LocalizationLayer default (LocalizationLayer.lua:237); run_model sets 1000
+  bool clip_boxes = true;   // LocalizationLayer.test_clip_boxes (LocalizationLayer.lua:235)
   // dims
   int k = 0, R = 0, V = 0, T = 0, E = 0, Hd = 0, D = 0;
   float fc[4] = {0, 0, 0, 0};
@@ -469,56 +467,13 @@ int lm_sample_parts(dc_ctx* ctx, Lane& L, const float* codes, const LmPart* part
   return DC_OK;
 }
 
-// <= 64 rows (webcam regime): ONE persistent launch for the T+1 LSTM steps with [Wout; Wh^T] resident in LDS
-// (lm_persistent.hip) after the encoder and the image step on the usual kernels.  Bit-identical tokens to the GEMM route.
-// Measured (profiles/r03_persistent_decode.md): at <= 64 rows BOTH routes are bounded by the same thing -- one wave per
-// SIMD issuing the 256 v_mfma_f32_32x32x2_f32 of its single accumulator block with its own operand reads in line
-// (10.8 us a step; two accumulation chains per block change nothing) -- and the persistent launch then pays two cross-XCD
-// hand-offs a step (~9 us) where the GEMM route pays two kernel boundaries (~6 us): 0.71 vs 0.66 ms per 50-row decode.
-// The persistent route is therefore OPT-IN (dc_debug_set "decode_route" = 2); the default stays the GEMM route.
-bool lm_use_persistent(const dc_ctx* ctx, int n) {
-  if (ctx->beam_size != 0 || ctx->decode_route != 2 || n > 64) return false;
-  return lm_persistent_supported(ctx->Hd, ctx->V1pad, n);
-}
-int lm_sample_persistent(dc_ctx* ctx, Lane& L, const float* codes, int r0, int n, const int32_t* n_dev, int32_t* seq_out,
-                         hipStream_t s, float* ws, size_t ws_floats) {
-  const int E = ctx->E, Hd = ctx->Hd, T = ctx->T, D = ctx->D;
-  if (L.pd_scratch == nullptr) HIPCHK(hipMalloc(&L.pd_scratch, lm_persistent_scratch_bytes(Hd, T)));
-  float* gates = L.gates + (size_t)r0 * 4 * Hd;
-  float* hstate = L.hstate + (size_t)r0 * Hd;
-  float* cstate = L.cstate + (size_t)r0 * Hd;
-  {  // image_encoder: Linear(4096,E)+ReLU (:27-30)
-    GemmDesc g;
-    g.A = codes + (size_t)r0 * D; g.W = ctx->enc_w; g.bias = ctx->enc_b; g.C = L.enc + (size_t)r0 * E;
-    g.M = n; g.N = E; g.K = D; g.ldc = E; g.relu = 1; g.m_dev = n_dev;
-    DCCHK(run_gemm(ctx, g, s, ws, ws ? ws_floats : 0));
-  }
-  {  // step 0: gates = (b + enc.Wx) + 0.Wh ; c0 = 0
-    GemmDesc g;
-    g.A = L.enc + (size_t)r0 * E; g.W = ctx->wxT; g.bias = ctx->lstm_b; g.C = gates;
-    g.M = n; g.N = 4 * Hd; g.K = E; g.ldc = 4 * Hd; g.m_dev = n_dev;
-    DCCHK(run_gemm(ctx, g, s));
-  }
-  KCHK(launch_lstm_step_tail(nullptr, nullptr, 0, 0, 0, nullptr, gates, cstate, hstate, n, n_dev, Hd, 1, nullptr, T, 0, s));
-  LmPersistArgs a;
-  a.dec_w = ctx->dec_w; a.out_b = ctx->out_b; a.xg = ctx->xg; a.h0 = hstate; a.c0 = cstate;
-  a.seq = seq_out + (size_t)r0 * T; a.n_dev = n_dev; a.n = n; a.T = T; a.V1 = ctx->V + 1; a.V1pad = ctx->V1pad;
-  KCHK(launch_lm_decode_persistent(a, Hd, L.pd_scratch, s));
-  L.pd_used = true;
-  return DC_OK;
-}
-
 // `plan`: rows of one image when n covers a group (0 = n); see GemmDesc::plan_M
 int lm_sample(dc_ctx* ctx, Lane& L, const float* codes, int n, int plan, const int32_t* n_dev, int32_t* seq_out) {
-  if (lm_use_persistent(ctx, n))
-    return lm_sample_persistent(ctx, L, codes, 0, n, n_dev, seq_out, L.stream, L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0);
   const LmPart whole{L.stream, 0, n, L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0};
   return lm_sample_parts(ctx, L, codes, &whole, 1, n_dev, seq_out, plan);
 }
 // decode rows [r0, r0+n) of the lane's buffers (codes / seq_out are the BASE pointers); n_dev: device row count
 int lm_sample_rows(dc_ctx* ctx, Lane& L, const float* codes, int r0, int n, const int32_t* n_dev, int32_t* seq_out) {
-  if (lm_use_persistent(ctx, n))
-    return lm_sample_persistent(ctx, L, codes, r0, n, n_dev, seq_out, L.stream, L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0);
   const LmPart part{L.stream, r0, n, L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0};
   return lm_sample_parts(ctx, L, codes, &part, 1, n_dev, seq_out, 0);
 }
@@ -536,9 +491,12 @@ int beam_chunk(const dc_ctx* ctx, int n) {
 }
 int beam_prepare(dc_ctx* ctx, Lane& L, int chunk) {
   const int beam = ctx->beam_size, rows = chunk * beam;
-  if (L.beam_base && L.beam_rows >= rows) return DC_OK;
+  // bm_enc is sized by the chunk, bm_top_lp / bm_top_idx by rows x beam: the scratch is reusable only when NONE of the
+  // three grew (beam 2 x 1000 proposals and beam 20 x 100 have the same row count but not the same carve)
+  if (L.beam_base && L.beam_rows >= rows && L.beam_chunk >= chunk && L.beam_width >= beam) return DC_OK;
   if (L.beam_base) { HIPCHK(hipStreamSynchronize(L.stream)); HIPCHK(hipFree(L.beam_base)); L.beam_base = nullptr; }
   const int E = ctx->E, Hd = ctx->Hd, V1 = ctx->V + 1, T = ctx->T;
+  L.beam_base = nullptr; L.beam_rows = L.beam_chunk = L.beam_width = 0;
   struct Carve { void** p; size_t bytes; };
   std::vector<Carve> cv = {
       {(void**)&L.bm_enc, (size_t)chunk * E * 4},      {(void**)&L.bm_gates, (size_t)rows * 4 * Hd * 4},
@@ -555,7 +513,7 @@ int beam_prepare(dc_ctx* ctx, Lane& L, int chunk) {
   HIPCHK(hipMalloc(&L.beam_base, total));
   char* p = static_cast<char*>(L.beam_base);
   for (auto& c : cv) { *c.p = p; p += al(c.bytes); }
-  L.beam_rows = rows;
+  L.beam_rows = rows; L.beam_chunk = chunk; L.beam_width = beam;
   return DC_OK;
 }
 
@@ -634,7 +592,6 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
   if (img_on_device) HIPCHK(hipMemcpyAsync(L.img, img, g * img_elems * 4, hipMemcpyDeviceToDevice, s));
   else HIPCHK(hipMemcpyAsync(L.img, img, g * img_elems * 4, hipMemcpyHostToDevice, s));
   L.g = g;
-  L.pd_used = false;
   HIPCHK(hipEventRecord(L.ev[0], s));
   // ---- VGG-16 trunk (DenseCapModel.lua:73-76) -------------------------------------------
   int h = H, w = W, cur = 0;
@@ -662,7 +619,8 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
   for (int i = 0; i < g; ++i)
     KCHK(launch_rpn_decode(L.heads + (size_t)i * h * w * 6 * ctx->k, h, w, ctx->k, ctx->anchors, ctx->fc[0], ctx->fc[1],
                            ctx->fc[2], ctx->fc[3], H, W, L.rpn_boxes + (size_t)i * L.A * 4, nullptr, nullptr,
-                           L.rpn_xyxy + (size_t)i * L.A * 4, L.rpn_p + (size_t)i * L.A, L.rpn_valid + (size_t)i * L.A, s));
+                           L.rpn_xyxy + (size_t)i * L.A * 4, L.rpn_p + (size_t)i * L.A, L.rpn_valid + (size_t)i * L.A,
+                           ctx->clip_boxes ? 1 : 0, s));
   HIPCHK(hipEventRecord(L.ev[2], s));
   // ---- RPN NMS (LocalizationLayer.lua:318-338) ------------------------------------------------
   for (int i = 0; i < g; ++i) {
@@ -746,12 +704,8 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
     char* hs = static_cast<char*>(L.host_stage) + i * stride;
     const size_t r0 = (size_t)i * P;
     HIPCHK(hipMemcpyAsync(hs, L.count2 + i * 64, 4, hipMemcpyDeviceToHost, s));
-    *reinterpret_cast<uint32_t*>(hs + 64) = 0;
     *reinterpret_cast<uint32_t*>(hs + 68) = 0;
     if (ctx->fault_dev != nullptr) HIPCHK(hipMemcpyAsync(hs + 68, ctx->fault_dev, 4, hipMemcpyDeviceToHost, s));
-    if (L.pd_used)     // the persistent decode's fault word (bounded spins: a failed rendezvous is reported, not waited for)
-      HIPCHK(hipMemcpyAsync(hs + 64, static_cast<char*>(L.pd_scratch) + lm_persistent_fault_offset(ctx->Hd, ctx->T), 4,
-                            hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hs + 256, L.out_boxes + r0 * 4, (size_t)P * 16, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hs + 256 + (size_t)P * 16, L.out_scores + r0, (size_t)P * 4, hipMemcpyDeviceToHost, s));
     if (features_only)
@@ -785,12 +739,6 @@ int harvest(dc_ctx* ctx, Lane& L) {
       L.pending = nullptr;
       return ctx->fail(DC_E_HIP, "stream-K: a workgroup's partner never published its partial tile within the spin bound (GPU "
                                  "shared with another job?); this ctx now uses the K-split tail plan -- repeat the call");
-    }
-    if (*reinterpret_cast<const uint32_t*>(hs + 64) != 0u) {
-      ctx->decode_route = 1;        // do not take the route again on this ctx
-      L.pending = nullptr;
-      return ctx->fail(DC_E_HIP, "persistent decode: its workgroups failed to rendezvous within the spin bound (GPU shared "
-                                 "with another job?); the GEMM decode will be used from now on -- repeat the call");
     }
     int K = *reinterpret_cast<const int32_t*>(hs);
     if (L.pending_feats) {
@@ -868,7 +816,6 @@ void dc_destroy(dc_ctx* ctx) {
     Lane& L = *lp;
     if (L.arena.p) hipFree(L.arena.p);
     if (L.beam_base) hipFree(L.beam_base);
-    if (L.pd_scratch) hipFree(L.pd_scratch);
     if (L.host_stage) hipHostFree(L.host_stage);
     for (auto& ev : L.ev) if (ev) hipEventDestroy(ev);
     if (L.ev_fork) hipEventDestroy(L.ev_fork);
@@ -886,13 +833,22 @@ void dc_destroy(dc_ctx* ctx) {
 
 const char* dc_last_error(const dc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
+// LocalizationLayer:setTestArgs (LocalizationLayer.lua:233-238)
+int dc_set_localization_test_args(dc_ctx* ctx, int clip_boxes, float nms_thresh, int max_proposals) {
+  if (!ctx) return DC_E_INVALID;
+  if (max_proposals != -1 && (max_proposals <= 0 || max_proposals > (1 << 20)))
+    return ctx->fail(DC_E_UNSUPPORTED, "num_proposals must be -1 (uncapped) or in [1,1048576] (got %d)", max_proposals);
+  ctx->clip_boxes = clip_boxes != 0;
+  ctx->rpn_nms_thresh = nms_thresh;
+  ctx->num_proposals = max_proposals;
+  return DC_OK;
+}
+
+// DenseCapModel:setTestArgs (DenseCapModel.lua:185-191): the layer's setTestArgs WITHOUT a clip_boxes key (-> true) + opt.final_nms_thresh
 int dc_set_test_args(dc_ctx* ctx, float rpn_nms_thresh, float final_nms_thresh, int num_proposals) {
   if (!ctx) return DC_E_INVALID;
-  if (num_proposals != -1 && (num_proposals <= 0 || num_proposals > (1 << 20)))
-    return ctx->fail(DC_E_UNSUPPORTED, "num_proposals must be -1 (uncapped) or in [1,1048576] (got %d)", num_proposals);
-  ctx->rpn_nms_thresh = rpn_nms_thresh;
+  DCCHK(dc_set_localization_test_args(ctx, 1, rpn_nms_thresh, num_proposals));
   ctx->final_nms_thresh = final_nms_thresh;
-  ctx->num_proposals = num_proposals;
   return DC_OK;
 }
 
@@ -1220,13 +1176,6 @@ int dc_mfma_profile(dc_ctx* ctx, int reset, int64_t* launches, double* total_ms,
 
 int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t capacity_bytes) {
   if (!ctx || !name || !host_buf) return DC_E_INVALID;
-  if (strcmp(name, "pd_trace") == 0) {       // phase time stamps of the last persistent decode (PD_TRACE builds only; else zeros)
-    if (ctx->lanes.empty()) return ctx->fail(DC_E_STATE, "no decode has run yet");
-    Lane& L0 = *ctx->lanes[0];
-    if (capacity_bytes < 2 * 32 * 8 * 8 || L0.pd_scratch == nullptr) return ctx->fail(DC_E_INVALID, "dc_debug_fetch: pd_trace needs 4096 bytes and a persistent decode");
-    HIPCHK(hipMemcpy(host_buf, static_cast<char*>(L0.pd_scratch) + lm_persistent_trace_offset(ctx->Hd, ctx->T), 2 * 32 * 8 * 8, hipMemcpyDeviceToHost));
-    return 2 * 32 * 8;
-  }
   if (ctx->lanes.empty() || !ctx->lanes[0]->arena.p) return ctx->fail(DC_E_STATE, "no forward has run yet");
   Lane& L = *ctx->lanes[0];
   const int P = L.P;
@@ -1295,11 +1244,6 @@ int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value) {
   if (strcmp(name, "beam_chunk_floats") == 0) {
     if (value < 1) return ctx->fail(DC_E_INVALID, "dc_debug_set: beam_chunk_floats must be >= 1");
     ctx->beam_chunk_floats = value;
-    return DC_OK;
-  }
-  if (strcmp(name, "decode_route") == 0) {
-    if (value < 0 || value > 2) return ctx->fail(DC_E_INVALID, "dc_debug_set: decode_route must be 0, 1 or 2");
-    ctx->decode_route = (int)value;
     return DC_OK;
   }
   if (strcmp(name, "v2_stages") == 0) {
@@ -1457,7 +1401,7 @@ int dc_op_rpn_decode(dc_ctx* ctx, const float* heads, int h, int w, int k, const
                      float* trans, float* x1y1x2y2, float* p, uint8_t* valid) {
   OP_PROLOGUE();
   KCHK(launch_rpn_decode(heads, h, w, k, anchors_dev, x0, y0, sx, sy, img_h, img_w, boxes, anchors_out, trans,
-                         x1y1x2y2, p, valid, s));
+                         x1y1x2y2, p, valid, 1, s));
   OP_EPILOGUE();
 }
 int dc_op_nms(dc_ctx* ctx, const float* boxes, const float* scores, const uint8_t* valid, int n, float thresh,
@@ -1502,22 +1446,13 @@ int dc_op_lm_sample(dc_ctx* ctx, const float* codes, int n, int32_t* tokens) {
   L.cstate = (float*)p; p += al((size_t)n * Hd * 4);
   L.logits = (float*)p; p += al((size_t)n * V1 * 4);
   L.tok = (int32_t*)p;
-  L.pd_used = false;
   int rc = ctx->beam_size > 0 ? lm_beamsearch(ctx, L, codes, n, tokens, s) : lm_sample(ctx, L, codes, n, 0, nullptr, tokens);
   hipError_t e2 = hipStreamSynchronize(s);
-  uint32_t pd_fault = 0;
-  if (rc == DC_OK && e2 == hipSuccess && L.pd_used)
-    e2 = hipMemcpy(&pd_fault, static_cast<char*>(L.pd_scratch) + lm_persistent_fault_offset(ctx->Hd, ctx->T), 4, hipMemcpyDeviceToHost);
   L.enc = sv.enc; L.gates = sv.gates; L.hstate = sv.h; L.cstate = sv.c; L.logits = sv.logits; L.tok = sv.tok;
   hipFree(base);
   prof_collect(ctx);
   if (rc != DC_OK) return rc;
   if (e2 != hipSuccess) return ctx->fail(DC_E_HIP, "lm_sample sync: %s", hipGetErrorString(e2));
-  if (pd_fault != 0u) {
-    ctx->decode_route = 1;
-    return ctx->fail(DC_E_HIP, "persistent decode: its workgroups failed to rendezvous within the spin bound; the GEMM decode "
-                               "will be used from now on -- repeat the call");
-  }
   return DC_OK;
 }
 

@@ -37,8 +37,9 @@ __global__ __launch_bounds__(256) void bilinear_roi_pool_kernel(const float* __r
   for (int v = blockIdx.x; v < B * split; v += gridDim.x) {
     const int b = v / split, part = v - b * split;
     const bool live = b < b_live;
-    if (!live) continue;          // boxes past the RPN NMS count: nothing downstream reads their rows (every consumer is
-                                  // bounded by the same device-side count), so they are neither sampled nor zero-filled
+    // boxes past the RPN NMS count are not sampled but their rows ARE zero-filled: fc6 / fc7, the heads and the decode
+    // run over all B rows in the reference caption order (only the NMS and the gathers are bounded by the device-side
+    // count), so a dead row must hold defined values -- zeros, as the gathers before it write (advisor finding, round 3)
     __syncthreads();
     if (live && threadIdx.x < npts) {
       const int i = threadIdx.x / WW, j = threadIdx.x - i * WW;

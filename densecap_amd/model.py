@@ -47,13 +47,54 @@ def decode_sequence(seq, idx_to_token, vocab_size):
     return caps
 
 
+def getopt(opt, key, default_value=None):
+    """utils.getopt (densecap/utils.lua:67-75): opt[key], or the default when the key is absent / nil (None here);
+    a missing key without a default is an error, as in the reference."""
+    v = None if opt is None else opt.get(key)
+    if v is None:
+        if default_value is None:
+            raise KeyError("error: required key %s was not provided in an opt." % key)
+        return default_value
+    return v
+
+
+class LocalizationLayerTestArgs:
+    """`model.nets.localization_layer` as far as the test-time path reads it: the three fields that
+    LocalizationLayer:setTestArgs writes (LocalizationLayer.lua:233-238) and _forward_test reads (:250-256).  A call
+    re-derives ALL three -- an omitted key goes back to its default (true / 0.7 / 300), it is not retained."""
+
+    def __init__(self, stored=None):
+        self.setTestArgs()                               # LocalizationLayer.lua:155: the constructor's own call
+        for k in ("test_clip_boxes", "test_nms_thresh", "test_max_proposals"):
+            if stored and stored.get(k) is not None:     # the deserialised object's fields (a checkpoint stores them)
+                setattr(self, k, stored[k])
+
+    def setTestArgs(self, args=None, **kw):
+        args = dict(args or {}, **kw)
+        self.test_clip_boxes = bool(getopt(args, "clip_boxes", True))
+        self.test_nms_thresh = float(getopt(args, "nms_thresh", 0.7))
+        self.test_max_proposals = int(getopt(args, "max_proposals", 300))
+        return self
+
+
+class _Nets:
+    def __init__(self, localization_layer):
+        self.localization_layer = localization_layer
+
+
 class DenseCapModel:
     def __init__(self, weights, device=0, ctx=None):
         """weights: dict in checkpoint layouts (see densecap_amd/weights.py); device: HIP index
-        (utils.setup_gpus(gpu) with gpu >= 0; there is no `-gpu -1` CPU mode here)."""
+        (utils.setup_gpus(gpu) with gpu >= 0; there is no `-gpu -1` CPU mode here).
+        weights["test_args"] (optional; t7.weights_from_checkpoint fills it): the test-time state the checkpoint OBJECT
+        carries -- localization_layer.test_clip_boxes / test_nms_thresh / test_max_proposals and opt.final_nms_thresh --
+        which is what the model runs with until somebody calls setTestArgs."""
         self.ctx = ctx or Context(device)
         self.lib = self.ctx.lib
-        self.opt = dict(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=300)
+        stored = dict(weights.get("test_args") or {})
+        self.nets = _Nets(LocalizationLayerTestArgs(stored))
+        # DenseCapModel.lua:31: opt.final_nms_thresh defaults to 0.3 at construction; forward reads self.opt at call time
+        self.opt = dict(final_nms_thresh=float(getopt(stored, "final_nms_thresh", 0.3)))
         self.vocab_size = int(weights["vocab_size"])
         self.seq_length = int(weights["seq_length"])
         self.idx_to_token = weights.get("idx_to_token")
@@ -86,20 +127,34 @@ class DenseCapModel:
         self.fc_dim = w.fc_dim
         check(self.ctx.h, self.lib.dc_load_weights(self.ctx.h, C.byref(w)), "dc_load_weights")
         self._keep = []
-        self.setTestArgs()
+        self._push_test_args()
 
     # ---- reference API ---------------------------------------------------------------------
     def setTestArgs(self, args=None, **kw):
-        """DenseCapModel:setTestArgs{rpn_nms_thresh=,final_nms_thresh=,num_proposals=}."""
-        args = dict(args or {}, **kw)
-        for k in args:
-            if k not in ("rpn_nms_thresh", "final_nms_thresh", "num_proposals"):
-                raise KeyError("unknown test arg %r" % k)
-        self.opt.update(args)
-        check(self.ctx.h, self.lib.dc_set_test_args(self.ctx.h, float(self.opt["rpn_nms_thresh"]),
-                                                    float(self.opt["final_nms_thresh"]),
-                                                    int(self.opt["num_proposals"])), "dc_set_test_args")
+        """DenseCapModel:setTestArgs{rpn_nms_thresh=, final_nms_thresh=, num_proposals=} (DenseCapModel.lua:185-191), as
+        written: EVERY call re-derives all three values -- rpn 0.7, num_proposals 1000, final 0.3 for the keys that are
+        absent -- and, because it calls the layer's setTestArgs without a `clip_boxes` key, turns box clipping back on.
+        Keys it does not know are ignored (evaluate_model.lua:39-43 passes `max_proposals=`, which the reference never
+        reads: that caller runs with 1000 proposals)."""
+        kwargs = dict(args or {}, **kw)
+        self.nets.localization_layer.setTestArgs(nms_thresh=getopt(kwargs, "rpn_nms_thresh", 0.7),
+                                                 max_proposals=getopt(kwargs, "num_proposals", 1000))
+        self.opt["final_nms_thresh"] = float(getopt(kwargs, "final_nms_thresh", 0.3))
+        self._push_test_args()
         return self
+
+    def _push_test_args(self):
+        """The reference reads localization_layer.test_* and opt.final_nms_thresh when forward runs
+        (LocalizationLayer.lua:250-256, DenseCapModel.lua:261) -- callers such as train.lua:139-143 write them directly --
+        so the current values travel to the library before every forward."""
+        ll = self.nets.localization_layer
+        check(self.ctx.h, self.lib.dc_set_test_args(self.ctx.h, float(ll.test_nms_thresh),
+                                                    float(self.opt["final_nms_thresh"]),
+                                                    int(ll.test_max_proposals)), "dc_set_test_args")
+        if not ll.test_clip_boxes:
+            check(self.ctx.h, self.lib.dc_set_localization_test_args(self.ctx.h, 0, float(ll.test_nms_thresh),
+                                                                     int(ll.test_max_proposals)),
+                  "dc_set_localization_test_args")
 
     def setLanes(self, lanes):
         """Streams dc_forward_batch pipelines images over (1 = serial kernels)."""
@@ -170,7 +225,7 @@ class DenseCapModel:
         return r, boxes, scores, tokens
 
     def _capacity(self, H, W):
-        P = int(self.opt["num_proposals"])
+        P = int(self.nets.localization_layer.test_max_proposals)
         if P != -1:
             return P
         for _ in range(4):                       # four ceil-mode 2x2 pools (conv5_3 map)
@@ -179,6 +234,7 @@ class DenseCapModel:
 
     def forward_raw(self, img):
         """forward_test without string decoding: (boxes (K,4) xcycwh, scores (K,), tokens (K,T))."""
+        self._push_test_args()
         img = self._check_input(img)
         P = self._capacity(img.shape[1], img.shape[2])
         r, boxes, scores, tokens = self._new_result(P)
@@ -195,6 +251,7 @@ class DenseCapModel:
     def forward_batch_device(self, imgs_dev_ptr, n, H, W):
         """run_model.lua's image loop over n device-resident images of one size; returns a list of
         (boxes, scores, tokens).  imgs_dev_ptr: device pointer to (n,3,H,W) fp32."""
+        self._push_test_args()
         P = self._capacity(H, W)
         arr = (DcResult * n)()
         keep = []
@@ -206,6 +263,7 @@ class DenseCapModel:
         return [(b[:arr[i].K], s[:arr[i].K], t[:arr[i].K]) for i, (b, s, t) in enumerate(keep)]
 
     def forward_batch(self, imgs):
+        self._push_test_args()
         imgs = np.ascontiguousarray(imgs, dtype=np.float32)
         n, c, H, W = imgs.shape
         assert c == 3
@@ -222,6 +280,7 @@ class DenseCapModel:
     def forward_images(self, imgs):
         """run_model.lua's loop over a list of images of DIFFERENT sizes, pipelined over the lanes (dc_forward_images);
         imgs: sequence of (3,H,W) / (1,3,H,W) arrays.  Returns a list of (boxes, scores, tokens)."""
+        self._push_test_args()
         arrs = [self._check_input(im) for im in imgs]
         n = len(arrs)
         if n == 0:
@@ -240,6 +299,7 @@ class DenseCapModel:
 
     def extractFeatures(self, img):
         """DenseCapModel:extractFeatures -> (boxes_xcycwh (K,4), feats (K,fc_dim))."""
+        self._push_test_args()
         img = self._check_input(img)
         P = self._capacity(img.shape[1], img.shape[2])
         boxes = np.zeros((P, 4), np.float32); feats = np.zeros((P, self.fc_dim), np.float32)
@@ -251,6 +311,7 @@ class DenseCapModel:
 
     def extractFeatures_images(self, imgs):
         """extract_features.lua's loop over images (any sizes), pipelined over the lanes: list of (boxes, feats)."""
+        self._push_test_args()
         arrs = [self._check_input(im) for im in imgs]
         n = len(arrs)
         if n == 0:

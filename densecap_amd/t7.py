@@ -358,6 +358,19 @@ def weights_from_checkpoint(ckpt):
     W["seq_length"] = int(lm["seq_length"])
     itt = lm.get("idx_to_token") or {}
     W["idx_to_token"] = {int(k): v for k, v in itt.items()}
+    # Test-time state the deserialised OBJECT carries (what the model runs with until setTestArgs is called):
+    # LocalizationLayer.test_clip_boxes / test_nms_thresh / test_max_proposals (LocalizationLayer.lua:155,233-238) and
+    # DenseCapModel.opt.final_nms_thresh (DenseCapModel.lua:31,261).  Absent fields stay None -> constructor defaults.
+    ll = nets["localization_layer"]
+    opt = model.get("opt") if hasattr(model, "get") else None
+    ta = {}
+    for k in ("test_clip_boxes", "test_nms_thresh", "test_max_proposals"):
+        v = ll.get(k) if hasattr(ll, "get") else None
+        if v is not None:
+            ta[k] = bool(v) if k == "test_clip_boxes" else (int(v) if k == "test_max_proposals" else float(v))
+    if isinstance(opt, dict) and opt.get("final_nms_thresh") is not None:
+        ta["final_nms_thresh"] = float(opt["final_nms_thresh"])
+    W["test_args"] = ta
     return W
 
 
@@ -379,6 +392,7 @@ def checkpoint_from_weights(W):
     def lin(w, b):
         return TorchObject("nn.Linear", dict(weight=T(w), bias=T(b)))
 
+    ta = dict(W.get("test_args") or {})
     relu = TorchObject("nn.ReLU", {})
     pool = TorchObject("nn.SpatialMaxPooling", dict(kW=2, kH=2, dW=2, dH=2, ceil_mode=True))
     cw, cb = W["conv_w"], W["conv_b"]
@@ -410,8 +424,11 @@ def checkpoint_from_weights(W):
         rnn=seq([TorchObject("nn.LSTM", dict(weight=T(W["lstm_w"]), bias=T(W["lstm_b"]))),
                  TorchObject("nn.View", {}), lin(W["lm_out_w"], W["lm_out_b"]), TorchObject("nn.View", {})])))
     nets = dict(conv_net1=seq(net1), conv_net2=seq(net2),
-                localization_layer=TorchObject("nn.LocalizationLayer", dict(nets=dict(rpn=rpn))),
+                localization_layer=TorchObject("nn.LocalizationLayer", dict(
+                    nets=dict(rpn=rpn), test_clip_boxes=bool(ta.get("test_clip_boxes", True)),
+                    test_nms_thresh=float(ta.get("test_nms_thresh", 0.7)),
+                    test_max_proposals=int(ta.get("test_max_proposals", 300)))),
                 recog_base=recog_base, objectness_branch=lin(W["obj_w"], W["obj_b"]),
                 box_reg_branch=lin(W["boxreg_w"], W["boxreg_b"]), language_model=lm)
-    model = TorchObject("nn.DenseCapModel", dict(nets=nets, opt=dict(final_nms_thresh=0.3)))
+    model = TorchObject("nn.DenseCapModel", dict(nets=nets, opt=dict(final_nms_thresh=float(ta.get("final_nms_thresh", 0.3)))))
     return dict(model=model, iter=0)

@@ -112,6 +112,12 @@ int dc_load_weights(dc_ctx* ctx, const dc_weights* w);
  * (DenseCapModel.lua:185-191). num_proposals = -1 = uncapped RPN NMS (capacity = all anchors of the image,
  * LocalizationLayer.lua:322-324); final_nms_thresh <= 0 = no final NMS (DenseCapModel.lua:261). */
 int dc_set_test_args(dc_ctx* ctx, float rpn_nms_thresh, float final_nms_thresh, int num_proposals);
+/* LocalizationLayer:setTestArgs{clip_boxes=, nms_thresh=, max_proposals=} (LocalizationLayer.lua:233-238), which
+ * train.lua:139-142 calls directly.  clip_boxes = 0: the RPN boxes are neither clipped to the image nor masked
+ * (LocalizationLayer.lua:272-300 is skipped) -- every anchor stays a candidate of the RPN NMS.
+ * dc_set_test_args IS this call with clip_boxes = 1 plus the final threshold: the reference's DenseCapModel:setTestArgs
+ * passes no `clip_boxes` key, so every call of it turns clipping back on. */
+int dc_set_localization_test_args(dc_ctx* ctx, int clip_boxes, float nms_thresh, int max_proposals);
 
 /* ---- the hot path ------------------------------------------------------- */
 /* DenseCapModel:forward_test(input) (DenseCapModel.lua:319-327) for one image
@@ -166,47 +172,6 @@ int dc_extract_features_images(dc_ctx* ctx, const float* const* imgs, const int*
  * LocalizationLayer.lua:219-230).  names[i] are static strings.  Returns the
  * number of stages written (<= max_stages). */
 int dc_stage_times(dc_ctx* ctx, const char** names, float* ms, int max_stages);
-/* Accumulated [contraction count, total ms, total algorithmic FLOPs] of the MFMA contraction kernel family
- * (HIP events around every contraction, including its split-K finish).  reset = 1 (re)starts the
- * measurement, reset = -1 stops it, 0 just reads.  Used by bench.py for the live roofline figure. */
-int dc_mfma_profile(dc_ctx* ctx, int reset, int64_t* launches, double* total_ms, double* total_flops);
-/* Copy an intermediate of the most recent forward to the host for stage-wise parity:
- * name in {"feat_hwc","rpn_heads","rpn_boxes","rpn_x1y1x2y2","rpn_p","rpn_valid",
- * "rpn_nms_idx","rpn_nms_count","roi_boxes","roi_feats","codes","obj","final_trans","final_boxes",
- * "seq","final_nms_idx","final_nms_count"} (lane 0; "seq" is only filled in the reference caption order), or
- * "arena_allocs" (int32: how many times a lane workspace has been (re)allocated -- it only grows), or
- * "host_enqueue_us" (int32: host microseconds per image spent enqueueing in the last dc_forward_batch).
- * Returns the number of elements copied (or <0). */
-int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t capacity_bytes);
-/* Test hooks (never needed for correct results; every setting gives the same outputs bit for bit):
- *   "beam_chunk_floats"  cap, in floats, of the beam search's full-logits buffer (default 2^28): proposals advance in
- *                        chunks of max(64, cap / (beam * (V+1))) -- lets a test walk the chunk loop with few rows;
- *   "decode_route"       0 / 1 = the GEMM decode (default), 2 = the persistent LDS-resident decode (one launch for all
- *                        T+1 LSTM steps, [Wout; Wh^T] resident in LDS) wherever it applies: greedy decode of <= 64 rows,
- *                        rnn_size 512.  Tokens are bit-identical on both routes; measured no faster.
- *   "tail_mode"          single-image mode (dc_set_lanes(1)), layers whose 128x128 tile count is not a multiple of the CU
- *                        count: 0 = per layer, whichever of stream-K over the last round / K-split tail plan / whole tiles
- *                        was measured fastest for that shape class (default), 1 = never stream-K, 2 = whole tiles only.
- *                        The routes differ in the fp32 summation order of the affected rows (each one deterministic).
- *   "force_cfg"          measurement hook for tools/route_sweep.py: 0 = planned (default), 1 / 2 / 3 = plain launches use
- *                        128x128 / 128x64 / 64x64 tiles and no split-K, 4 = planned tiles, no split-K.  Changes the fp32
- *                        summation order with the kernel family; never set by the product path.
- *   "v2_stages"          LDS ring depth of the 128x64-tile contraction kernel: 0 = by tile count (default: two stages, three
- *                        workgroups per CU, once a launch has >= 3 tiles per CU; three stages otherwise), 2 or 3 forced.
- *                        Same K order either way: bit-identical results.
- * Returns DC_OK or DC_E_INVALID for an unknown name / bad value. */
-int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value);
-/* Planning query -- pure (no context, no GPU: a missing device counts as 256 CUs): how the contraction engine carries out
- * C[M,N] = A[M,K] . W[N,K]^T (conv_cin != 0: the implicit GEMM of a 3x3 convolution with that many input channels,
- * K = 9*conv_cin; argmax != 0: the vocabulary projection with its fused row arg-max; plan_M = rows of ONE image when M
- * holds a group of images, 0 = M; serial_mode = the dc_set_lanes(1) scheduling).  out8 = {kind, route, stages, splitk,
- * m_split, sk_workgroups, sk_units, tail_splitk}: kind 0 plain launch, 1 split-K + reduce, 2 stream-K over the last
- * round, 3 K-split tail plan; route 0 K-split 128x128, 1 128x64 tiles, 2 128x128 tiles, 3 64x64 tiles; stages = LDS ring
- * depth of a 128x64 launch.  Exists so that the policy (and its invariance under image groups) is pinned by tests that
- * need no GPU.  Returns DC_OK or DC_E_INVALID. */
-int dc_debug_plan_gemm(int64_t M, int64_t N, int64_t K, int64_t plan_M, int conv_cin, int argmax, int serial_mode,
-                       int32_t* out8);
-
 /* ---- multi-GPU: image shards + ONE gather ------------------------------------ */
 /* The reference binds one device (densecap/utils.lua:22-36) and loops over images on it
  * (run_model.lua:160-180).  Here images shard by index over ranks (one process or thread and one

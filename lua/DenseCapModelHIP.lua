@@ -22,6 +22,17 @@ local C = hip.C
 local Model = {}
 Model.__index = Model
 
+-- utils.getopt (densecap/utils.lua:67-75): opt[key], or the default when the key is absent (nil)
+local function getopt(opt, key, default_value)
+  if default_value == nil and (opt == nil or opt[key] == nil) then
+    error('error: required key ' .. key .. ' was not provided in an opt.')
+  end
+  if opt == nil then return default_value end
+  local v = opt[key]
+  if v == nil then v = default_value end
+  return v
+end
+
 local function fptr(t)  -- FloatTensor -> const float*
   assert(t:type() == 'torch.FloatTensor' and t:isContiguous())
   return ffi.cast('const float*', torch.data(t))
@@ -90,7 +101,21 @@ function Model.fromCheckpoint(ref, gpu)
   w.enc_size, w.rnn_size, w.fc_dim = lm.input_encoding_size, lm.rnn_size, fcs[2].weight:size(1)
   hip.check(self.ctx, C.dc_load_weights(self.ctx, w), 'dc_load_weights')
   keep = nil
-  self.opt = {rpn_nms_thresh = 0.7, final_nms_thresh = 0.3, num_proposals = 300}
+  -- Test-time state: what the deserialised objects carry (LocalizationLayer.lua:155,233-238 writes the three layer
+  -- fields, DenseCapModel.lua:31 opt.final_nms_thresh; train.lua:139-143 sets all four before torch.save) is what the
+  -- model runs with until somebody calls setTestArgs.  forward reads these fields at call time, as the reference does.
+  local rll = ref.nets.localization_layer
+  local ll = {}
+  function ll.setTestArgs(layer, args)                     -- LocalizationLayer:setTestArgs, as written: all three re-derived
+    layer.test_clip_boxes = getopt(args, 'clip_boxes', true)
+    layer.test_nms_thresh = getopt(args, 'nms_thresh', 0.7)
+    layer.test_max_proposals = getopt(args, 'max_proposals', 300)
+  end
+  ll:setTestArgs()
+  if rll.test_clip_boxes ~= nil then ll.test_clip_boxes = rll.test_clip_boxes end
+  if rll.test_nms_thresh ~= nil then ll.test_nms_thresh = rll.test_nms_thresh end
+  if rll.test_max_proposals ~= nil then ll.test_max_proposals = rll.test_max_proposals end
+  self.opt = {final_nms_thresh = getopt(ref.opt, 'final_nms_thresh', 0.3)}
   self.vocab_size, self.seq_length, self.fc_dim = lm.vocab_size, lm.seq_length, fcs[2].weight:size(1)
   self.num_anchors = make_anchors.anchors:size(2)
   self.idx_to_token = lm.idx_to_token
@@ -107,20 +132,37 @@ function Model.fromCheckpoint(ref, gpu)
         rawset(t, k, v)
       end
     end})
-  self.nets = {language_model = lm_proxy}
-  self:setTestArgs{}
+  self.nets = {language_model = lm_proxy, localization_layer = ll}
+  self:_push_test_args()
   return self
 end
 
+-- DenseCapModel:setTestArgs (DenseCapModel.lua:185-191), as written: EVERY call re-derives all three values (absent keys
+-- -> 0.7 / 1000 / 0.3), unknown keys are ignored (evaluate_model.lua:39-43 passes `max_proposals=`: that caller runs
+-- with 1000 proposals), and -- the layer's setTestArgs being called without `clip_boxes` -- box clipping is back on.
 function Model:setTestArgs(kwargs)
-  for k, v in pairs(kwargs or {}) do self.opt[k] = v end
-  hip.check(self.ctx, C.dc_set_test_args(self.ctx, self.opt.rpn_nms_thresh, self.opt.final_nms_thresh,
-                                         self.opt.num_proposals), 'dc_set_test_args')
+  self.nets.localization_layer:setTestArgs{
+    nms_thresh = getopt(kwargs, 'rpn_nms_thresh', 0.7),
+    max_proposals = getopt(kwargs, 'num_proposals', 1000)
+  }
+  self.opt.final_nms_thresh = getopt(kwargs, 'final_nms_thresh', 0.3)
+  self:_push_test_args()
+end
+-- the current values travel to the library before every forward (LocalizationLayer.lua:250-256 and DenseCapModel.lua:261
+-- read the fields at call time; train.lua:139-143 writes them directly)
+function Model:_push_test_args()
+  local ll = self.nets.localization_layer
+  hip.check(self.ctx, C.dc_set_test_args(self.ctx, ll.test_nms_thresh, self.opt.final_nms_thresh,
+                                         ll.test_max_proposals), 'dc_set_test_args')
+  if not ll.test_clip_boxes then
+    hip.check(self.ctx, C.dc_set_localization_test_args(self.ctx, 0, ll.test_nms_thresh, ll.test_max_proposals),
+              'dc_set_localization_test_args')
+  end
 end
 -- rows the result buffers need: num_proposals, or every anchor of the image when it is -1 (uncapped RPN NMS,
 -- LocalizationLayer.lua:322-324): k * ceil(H/16) * ceil(W/16) after the four ceil-mode pools
 function Model:_capacity(H, W)
-  local P = self.opt.num_proposals
+  local P = self.nets.localization_layer.test_max_proposals
   if P ~= -1 then return P end
   for _ = 1, 4 do H, W = math.floor((H + 1) / 2), math.floor((W + 1) / 2) end
   return self.num_anchors * H * W
@@ -150,6 +192,7 @@ function Model:decodeSequence(seq)   -- LanguageModel.lua:86-103
 end
 
 function Model:forward_test(input)
+  self:_push_test_args()
   assert(input:dim() == 4 and input:size(1) == 1 and input:size(2) == 3)  -- DenseCapModel.lua:244
   local img = input:float():contiguous()
   local H, W, T = img:size(3), img:size(4), self.seq_length
@@ -168,6 +211,7 @@ function Model:forward_test(input)
 end
 
 function Model:extractFeatures(input)
+  self:_push_test_args()
   local img = input:float():contiguous()
   local H, W = img:size(3), img:size(4)
   local P = self:_capacity(H, W)
@@ -195,6 +239,7 @@ function Model:commInit(id, rank, world)
 end
 -- forward_test without string decoding: returns a dc_result (and the tensors that own its buffers)
 function Model:forward_raw(input)
+  self:_push_test_args()
   local img = input:float():contiguous()
   local H, W, T = img:size(3), img:size(4), self.seq_length
   local P = self:_capacity(H, W)

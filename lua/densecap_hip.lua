@@ -34,6 +34,7 @@ void dc_destroy(dc_ctx* ctx);
 const char* dc_last_error(const dc_ctx* ctx);
 int dc_load_weights(dc_ctx* ctx, const dc_weights* w);
 int dc_set_test_args(dc_ctx* ctx, float rpn_nms_thresh, float final_nms_thresh, int num_proposals);
+int dc_set_localization_test_args(dc_ctx* ctx, int clip_boxes, float nms_thresh, int max_proposals);
 int dc_set_lanes(dc_ctx* ctx, int lanes);
 int dc_set_caption_order(dc_ctx* ctx, int after_final_nms);
 int dc_set_beam_size(dc_ctx* ctx, int beam_size);

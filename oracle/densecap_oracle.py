@@ -382,9 +382,11 @@ def rpn_heads(feat, Wt):
 
 
 def rpn_decode(box_head, score_head, img_h, img_w, anchors=DEFAULT_ANCHORS,
-               field_centers=VGG16_FIELD_CENTERS):
+               field_centers=VGG16_FIELD_CENTERS, clip_boxes=True):
     """LocalizationLayer._forward_test lines 265-308 after the convs:
     anchors+transform, clip, mask-compaction, corners, p(pos).
+    clip_boxes=False (self.test_clip_boxes, LocalizationLayer.lua:235,272): lines 272-300 are skipped -- the boxes
+    stay as transformed and every row survives.
     Returns dict with compacted arrays (A',.) and the original row ids."""
     k = anchors.shape[1]
     x0, y0, sx, sy = field_centers
@@ -393,7 +395,10 @@ def rpn_decode(box_head, score_head, img_h, img_w, anchors=DEFAULT_ANCHORS,
     trans = reshape_box_features(box_head, k)
     scores2 = reshape_box_features(score_head, k)
     boxes = apply_box_transform(anc, trans)
-    clipped, valid = clip_boxes_xcycwh(boxes, 1, 1, img_w, img_h)
+    if clip_boxes:
+        clipped, valid = clip_boxes_xcycwh(boxes, 1, 1, img_w, img_h)
+    else:
+        clipped, valid = boxes, np.ones(boxes.shape[0], bool)
     keep = np.nonzero(valid)[0]
     boxes_c = clipped[keep]; anc_c = anc[keep]; trans_c = trans[keep]; sc_c = scores2[keep]
     x1y1x2y2 = xcycwh_to_x1y1x2y2(boxes_c)
@@ -604,7 +609,7 @@ def preprocess(img_rgb01_chw, image_size):
 
 
 def forward_test(img, Wt, rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=1000,
-                 T=15, stages=None, beam_size=None):
+                 T=15, stages=None, beam_size=None, clip_boxes=True):
     """DenseCapModel:forward_test numerics (DenseCapModel.lua:242-275,319-327 via
     LocalizationLayer.lua:250-363).  img: numpy/torch (3,H,W) BGR mean-subtracted.
     Returns (boxes_xcycwh (K,4), scores (K,), tokens (K,T) int64 1-based).
@@ -618,7 +623,7 @@ def forward_test(img, Wt, rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposal
     st["feat"] = feat[0].numpy()
     box_head, score_head = rpn_heads(feat, Wt)
     st["box_head"] = box_head; st["score_head"] = score_head
-    d = rpn_decode(box_head, score_head, H, W)
+    d = rpn_decode(box_head, score_head, H, W, clip_boxes=clip_boxes)
     st["rpn"] = d
     b5 = np.concatenate([d["x1y1x2y2"], d["p"][:, None]], 1)
     idx = nms(b5, rpn_nms_thresh, None if num_proposals == -1 else num_proposals)

@@ -159,9 +159,11 @@ def _np(a):
     return np.ascontiguousarray(a, np.float32)
 
 
-def assemble_densecap_checkpoint(path, W, with_grads=("rpn_conv", "obj")):
+def assemble_densecap_checkpoint(path, W, with_grads=("rpn_conv", "obj"), test_args=None):
     """Write a checkpoint-shaped `.t7` holding the weights dict W (densecap_amd.weights layout).  Returns the number of
-    serialized objects."""
+    serialized objects.  test_args: the test-time fields of the saved objects (localization_layer.test_clip_boxes /
+    test_nms_thresh / test_max_proposals, opt.final_nms_thresh); default = what train.lua:139-143 sets before saving."""
+    test_args = dict(test_args or {})
     cw = [_np(w) for w in W["conv_w"]]; cb = [_np(b) for b in W["conv_b"]]
     V, T = int(W["vocab_size"]), int(W["seq_length"])
     anchors = _np(W["anchors"])
@@ -273,7 +275,11 @@ def assemble_densecap_checkpoint(path, W, with_grads=("rpn_conv", "obj")):
                     ("obj_crit_neg", simple("nn.OurCrossEntropyCriterion")),
                     ("box_reg_crit", simple("nn.SmoothL1Criterion", [("sizeAverage", True)]))])),
                 ("roi_boxes", a.empty_tensor), ("rpn_out", None), ("image_height", None), ("image_width", None),
-                ("nms_thresh", 0.7), ("max_proposals", 300), ("timing", False), ("dump_vars", False),
+                # test-time state as train.lua:139-143 leaves it before torch.save (train_opts.lua:76-81 defaults)
+                ("test_clip_boxes", bool(test_args.get("test_clip_boxes", True))),
+                ("test_nms_thresh", float(test_args.get("test_nms_thresh", 0.7))),
+                ("test_max_proposals", int(test_args.get("test_max_proposals", 1000))),
+                ("timing", False), ("dump_vars", False),
                 ("timer_hook", lambda: a.lua_function(RECUR_FUNCTION, lambda: a.table([
                     (1, lambda: a.table([("name", "_ENV")])), (2, lambda: a.table([("name", "self"), ("value", 3)]))]))),
                 ("old_hook", lambda: a.lua_function(FUNCTION, lambda: a.table([]))),
@@ -371,7 +377,7 @@ def assemble_densecap_checkpoint(path, W, with_grads=("rpn_conv", "obj")):
             return emit
 
         model_opt = [("cnn_name", "vgg-16"), ("backend", "cudnn"), ("path_offset", ""), ("dtype", "torch.CudaTensor"),
-                     ("vocab_size", V), ("std", 0.01), ("final_nms_thresh", 0.3), ("mid_box_reg_weight", 0.05),
+                     ("vocab_size", V), ("std", 0.01), ("final_nms_thresh", float(test_args.get("final_nms_thresh", 0.3))), ("mid_box_reg_weight", 0.05),
                      ("mid_objectness_weight", 0.1), ("end_box_reg_weight", 0.1), ("end_objectness_weight", 0.1),
                      ("captioning_weight", 1.0), ("seq_length", T), ("rnn_encoding_size", E), ("rnn_size", Hd),
                      ("input_dim", 512), ("output_height", 7), ("output_width", 7),

@@ -233,17 +233,21 @@ def final_or_replay(model, oracle_mod, weights, img, hip, ora, st, P, final_thr=
         return strict_check(model, weights, img, P, final_thr=final_thr, T=T)
 
 
-def strict_check(model, weights, img, P, rpn_thr=0.7, final_thr=0.3, T=None, stages=True):
-    """Run one image through the HIP path and the oracle; assert (1)-(3).  Returns a report dict."""
+def strict_check(model, weights, img, P, rpn_thr=0.7, final_thr=0.3, T=None, stages=True, clip_boxes=True):
+    """Run one image through the HIP path and the oracle; assert (1)-(3).  Returns a report dict.
+    clip_boxes=False: localization_layer.test_clip_boxes = false (LocalizationLayer.lua:235,272), set the way train.lua
+    does it -- through the layer's own setTestArgs -- after the model's."""
     import torch
     from oracle import densecap_oracle as O
     oracle_threads()
     T = T or int(weights["seq_length"])
     report = {}
     model.setTestArgs(rpn_nms_thresh=rpn_thr, final_nms_thresh=final_thr, num_proposals=P)
+    if not clip_boxes:
+        model.nets.localization_layer.setTestArgs(clip_boxes=False, nms_thresh=rpn_thr, max_proposals=P)
     hip = model.forward_raw(img)
     st = {}
-    ora = O.forward_test(img, weights, rpn_thr, final_thr, P, T, stages=st)
+    ora = O.forward_test(img, weights, rpn_thr, final_thr, P, T, stages=st, clip_boxes=clip_boxes)
     if not stages:
         try:
             return compare_final(O, weights, hip, ora, st, final_thr, T, report)

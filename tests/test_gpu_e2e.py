@@ -650,38 +650,6 @@ def test_large_image_beyond_65536_anchors(model, weights):
     assert r["K"] > 0 and r["matched"] == r["K_oracle"]
 
 
-def test_persistent_decode_equals_gemm_decode(model, weights):
-    """dc_debug_set("decode_route", 2): <= 64 rows take the persistent LDS-resident decode (lm_persistent.hip: one launch for
-    all T+1 steps, [Wout; Wh^T] resident in LDS, device-wide hand-offs per step); 1 (or the default 0) = the GEMM route.  Same MFMA
-    chain per element, same association, same tie rule: the two routes must give IDENTICAL tokens -- at every row count
-    around the 32-row block boundary, call after call (the polled words are re-zeroed per launch)."""
-    import ctypes as C
-    from densecap_amd._lib import check
-    ctx = model.ctx
-    rng = np.random.default_rng(3)
-    try:
-        for n in (1, 7, 32, 33, 50, 64):
-            codes = np.maximum(rng.standard_normal((n, 4096)), 0).astype(np.float32)
-            cd = ctx.to_device(codes); td = ctx.empty((n, 15), np.int32)
-            outs = {}
-            for route in (1, 2, 2, 2):
-                check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", route), "dc_debug_set")
-                check(ctx.h, ctx.lib.dc_op_lm_sample(ctx.h, cd.ptr, n, td.ptr), "dc_op_lm_sample")
-                outs.setdefault(route, []).append(td.numpy().copy())
-            for t in outs[2]:
-                np.testing.assert_array_equal(t, outs[1][0], err_msg="persistent decode != GEMM decode at %d rows" % n)
-            assert outs[1][0].min() >= 1 and outs[1][0].max() <= weights["vocab_size"] + 1
-            cd.free(); td.free()
-        # 65 rows: beyond the persistent kernel's block -> the GEMM route whatever the setting
-        codes = np.maximum(rng.standard_normal((65, 4096)), 0).astype(np.float32)
-        cd = ctx.to_device(codes); td = ctx.empty((65, 15), np.int32)
-        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 2), "dc_debug_set")
-        check(ctx.h, ctx.lib.dc_op_lm_sample(ctx.h, cd.ptr, 65, td.ptr), "dc_op_lm_sample")
-        assert td.numpy().min() >= 1
-    finally:
-        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 0), "dc_debug_set")
-
-
 def test_ring_depth_is_invisible_in_decode(model, weights):
     """dc_debug_set("v2_stages"): the 128x64-tile kernel with a two-stage LDS ring (three workgroups per CU; the default once
     a launch has >= 3 tiles per CU, i.e. the vocabulary projection at 1000 rows) and with three stages walks K in the same
@@ -705,36 +673,30 @@ def test_ring_depth_is_invisible_in_decode(model, weights):
         check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"v2_stages", 0), "dc_debug_set")
 
 
-def test_webcam_regime_forward_both_decode_routes(model, weights):
-    """forward_test at the webcam settings (480 px, 50 proposals, single_machine_demo.lua:25-26), single-image mode: the
-    persistent decode route (decode_route = 2) against the oracle (every stage), and bit-identical to the GEMM route --
-    also with captions after the final NMS (device-side row count) and for a pair of images in one group."""
-    from densecap_amd._lib import check
+def test_webcam_regime_forward(model, weights):
+    """forward_test at the webcam settings (480 px, 50 proposals, single_machine_demo.lua:25-26), single-image mode, against
+    the oracle (every stage) -- also with captions after the final NMS (device-side row count) and for a pair of images in
+    one group."""
     from densecap_amd.weights import make_synthetic_image
     from tests import parity
-    ctx = model.ctx
     img = make_synthetic_image(320, 480, 31)
     try:
         model.setLanes(1)
-        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 2), "dc_debug_set")
         r = parity.strict_check(model, weights, img, 50)
         assert r["K"] > 0 and r["matched"] == r["K_oracle"]
+        outs = []
         for order in (False, True):
             model.setCaptionOrder(order)
             model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=50)
-            check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 2), "dc_debug_set")
-            a = model.forward_raw(img)
-            check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 1), "dc_debug_set")
-            b = model.forward_raw(img)
-            for x, y in zip(a, b):
-                np.testing.assert_array_equal(x, y)
-            assert len(a[0]) > 0
+            outs.append(model.forward_raw(img))
+        for x, y in zip(outs[0], outs[1]):
+            np.testing.assert_array_equal(x, y)
+        assert len(outs[0][0]) > 0
         model.setCaptionOrder(False)
-        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 2), "dc_debug_set")
         model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=30)
         imgs = np.stack([make_synthetic_image(320, 480, 40 + s) for s in range(2)])
         model.setLanes(3)                                   # (group invariance is a multi-lane property: single-image mode re-plans the last tile round)
-        model.setGroup(2)                                   # 2 x 30 rows in one persistent launch
+        model.setGroup(2)
         pair = model.forward_batch(imgs)
         model.setGroup(0)
         for i in range(2):
@@ -742,5 +704,64 @@ def test_webcam_regime_forward_both_decode_routes(model, weights):
             for x, y in zip(pair[i], single):
                 np.testing.assert_array_equal(x, y)
     finally:
-        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 0), "dc_debug_set")
         model.setCaptionOrder(False); model.setGroup(0); model.setLanes(3)
+
+
+def test_clip_boxes_false_matches_oracle(model, weights):
+    """localization_layer.test_clip_boxes = false (LocalizationLayer.lua:235,272-300 skipped: no clipping, no valid mask),
+    set through the layer's own setTestArgs as train.lua:139 does: every stage against the oracle run the same way; the
+    model's setTestArgs then turns clipping back on (it passes no clip_boxes key, DenseCapModel.lua:185-191)."""
+    from densecap_amd.weights import make_synthetic_image
+    from tests import parity
+    img = make_synthetic_image(224, 288, 5)
+    r = parity.strict_check(model, weights, img, 100, clip_boxes=False)
+    assert r["K"] > 0 and r["matched"] == r["K_oracle"]
+    A = 12 * 14 * 18
+    valid, _ = model.debug_fetch("rpn_valid", (A,), np.uint8)
+    assert valid.all()
+    rb, _ = model.debug_fetch("rpn_boxes", (A, 4))
+    assert (rb[:, 0] - rb[:, 2] / 2 < 0).any() or (rb[:, 0] + rb[:, 2] / 2 > 288).any()   # boxes do leave the image
+    unclipped = model.forward_raw(img)
+    r2 = parity.strict_check(model, weights, img, 100)          # clipping is back on with the model's setTestArgs
+    assert model.nets.localization_layer.test_clip_boxes is True
+    valid, _ = model.debug_fetch("rpn_valid", (A,), np.uint8)
+    assert r2["matched"] == r2["K_oracle"] and len(unclipped[0]) > 0
+
+
+def test_beam_scratch_is_recarved_when_beam_or_chunk_grows():
+    """Advisor finding (round 3): the beam scratch was reused whenever rows = chunk x beam did not grow, although bm_enc is
+    sized by the chunk and bm_top_lp / bm_top_idx by rows x beam.  beam 2 x 1000 proposals then beam 20 x 100 (same 2000
+    rows, 10x the top-k candidates); beam 5 x 300 then beam 1 x 1000 (fewer rows, 3.3x the encoder rows): the second call of
+    each pair must give what a fresh context gives."""
+    import torch
+    from densecap_amd import DenseCapModel
+    from densecap_amd._lib import check
+    from densecap_amd.weights import make_synthetic_weights
+    W = make_synthetic_weights(seed=5, vocab_size=300, seq_length=7)
+    rng = np.random.default_rng(77)
+    codes = np.maximum(rng.standard_normal((1000, 4096)), 0).astype(np.float32)
+
+    def run(m, beam, n):
+        m.setBeamSize(beam)
+        cd = m.ctx.to_device(codes[:n]); td = m.ctx.empty((n, 7), np.int32)
+        check(m.ctx.h, m.ctx.lib.dc_op_lm_sample(m.ctx.h, cd.ptr, n, td.ptr), "dc_op_lm_sample")
+        out = td.numpy().copy()
+        cd.free(); td.free()
+        return out
+
+    for (b1, n1), (b2, n2) in (((2, 1000), (20, 100)), ((5, 300), (1, 1000))):
+        fresh = DenseCapModel(W, device=0)
+        try:
+            want = run(fresh, b2, n2)
+        finally:
+            fresh.ctx.close()
+        m = DenseCapModel(W, device=0)
+        try:
+            run(m, b1, n1)
+            got = run(m, b2, n2)
+            again = run(m, b2, n2)
+        finally:
+            m.ctx.close()
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(again, want)
+        assert want.min() >= 1 and want.max() <= 301

@@ -38,7 +38,6 @@ python tools/gemm_bench.py 5 --serial > "$OUT/gemm_bench_serial.txt" 2>/dev/null
 python tools/gemm_bench.py 5 > "$OUT/gemm_bench_multilane.txt" 2>/dev/null
 python tools/decode_bench.py 20 1000 300 50 > "$OUT/decode_bench.txt" 2>/dev/null
 python tools/decode_bench.py 5 1000 50 --beam=5 >> "$OUT/decode_bench.txt" 2>/dev/null
-python tools/decode_bench.py 20 50 --persistent >> "$OUT/decode_bench.txt" 2>/dev/null
 PARITY_EXTRA=8 python tests/parity_report.py > "$OUT/parity_report.log" 2>&1
 cp gpurun_out/parity_report.json "$OUT/parity_report.json" 2>/dev/null
 ls -la "$OUT"

@@ -15,8 +15,6 @@ rows = [int(a) for a in sys.argv[2:] if a.lstrip("-").isdigit()] or [1000, 300, 
 W = make_synthetic_weights(seed=1234)
 m = DenseCapModel(W, device=0)
 ctx = m.ctx
-if "--persistent" in sys.argv:          # the persistent LDS-resident decode at <= 64 rows (the default is the GEMM decode)
-    check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_route", 2), "dc_debug_set")
 rng = np.random.default_rng(0)
 beam = 0
 for a in sys.argv:
@@ -46,19 +44,3 @@ for n in rows:
     print("rows=%d  decode call ms: median %.3f min %.3f (incl. scratch malloc/free + sync)   MFMA launches %d, %.3f ms, %.1f TF  tokens[0]=%s" %
           (n, np.median(ts), ts.min(), p["launches"], p["ms"], p["flops"] / max(p["ms"], 1e-9) / 1e9, td.numpy()[0, :6].tolist()))
     cd.free(); td.free()
-
-if "--trace" in sys.argv or os.environ.get("PD_TRACE"):
-    # phase time stamps of the persistent decode (library built with -DPD_TRACE): 100 MHz wall clock, us relative to it=0
-    n = 50
-    codes = np.maximum(rng.standard_normal((n, 4096)), 0).astype(np.float32)
-    cd = ctx.to_device(codes); td = ctx.empty((n, 15), np.int32)
-    for _ in range(3):
-        check(ctx.h, ctx.lib.dc_op_lm_sample(ctx.h, cd.ptr, n, td.ptr), "dc_op_lm_sample")
-    tr = np.zeros((2, 32, 8), np.uint64)
-    ctx.lib.dc_debug_fetch(ctx.h, b"pd_trace", tr.ctypes.data, tr.nbytes)
-    t0 = float(tr[1, 0, 0])
-    for who, name in ((0, "vocab wg0"), (1, "gate wg0")):
-        print(name, "stamps (us since gate it=0 start): [loop top, h ready, MFMA done, ...]")
-        for it in range(17):
-            row = [(float(v) - t0) / 100.0 if v else None for v in tr[who, it]]
-            print("  it=%2d " % it + " ".join("%8.2f" % v if v is not None else "       -" for v in row[:7]))
