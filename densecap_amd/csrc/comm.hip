@@ -212,9 +212,13 @@ static size_t record_bytes(int capacity, int T) { return 16 + (size_t)capacity *
 // sends and receives of different byte counts, which hangs or corrupts under RCCL.  Peers send their 16-byte shape to
 // rank 0, rank 0 answers every peer with its verdict {ok, n_local, capacity, T of rank 0}; only then does the payload
 // move.  Two tiny messages per peer, once per gather.
-static int shape_handshake(dc_comm* c, int n_local, int cap, int T) {
+// `local_ok`: this rank's own argument validation (advisor finding, round 3: a rank that returned BEFORE the handshake
+// left its peers blocked in it).  A rank with bad arguments still takes part and says so in word 3; rank 0's verdict
+// then fails the gather on EVERY rank together.
+static const int32_t kShapeMagic = 0x44434752, kShapeBad = 0x44434244;   // 'DCGR', 'DCBD'
+static int shape_handshake(dc_comm* c, int n_local, int cap, int T, bool local_ok) {
   std::string err;
-  int32_t mine[4] = {n_local, cap, T, 0x44434752};            // 'DCGR'
+  int32_t mine[4] = {n_local, cap, T, local_ok ? kShapeMagic : kShapeBad};
   if (c->rank != 0) {
     HCHK(hipMemcpyAsync(c->dev_hdr, mine, 16, hipMemcpyHostToDevice, c->stream));
     TCHK(c->tp->group_start(err));
@@ -226,6 +230,8 @@ static int shape_handshake(dc_comm* c, int n_local, int cap, int T) {
     int32_t verdict[4];
     HCHK(hipMemcpyAsync(verdict, c->dev_hdr + 4, 16, hipMemcpyDeviceToHost, c->stream));
     HCHK(hipStreamSynchronize(c->stream));
+    if (verdict[0] == 2)
+      return c->fail(DC_E_STATE, "dc_gather_results: another rank rejected its arguments; no payload was exchanged");
     if (verdict[0] != 1)
       return c->fail(DC_E_STATE, "dc_gather_results: ranks disagree on (n_local, capacity, T): rank 0 has (" +
                                      std::to_string(verdict[1]) + ", " + std::to_string(verdict[2]) + ", " +
@@ -239,15 +245,20 @@ static int shape_handshake(dc_comm* c, int n_local, int cap, int T) {
   std::vector<int32_t> all((size_t)c->world * 4);
   HCHK(hipMemcpyAsync(all.data() + 4, c->dev_hdr + 4, (size_t)(c->world - 1) * 16, hipMemcpyDeviceToHost, c->stream));
   HCHK(hipStreamSynchronize(c->stream));
-  int bad = -1;
-  for (int peer = 1; peer < c->world && bad < 0; ++peer)
-    if (all[4 * peer] != n_local || all[4 * peer + 1] != cap || all[4 * peer + 2] != T || all[4 * peer + 3] != mine[3]) bad = peer;
-  int32_t verdict[4] = {bad < 0 ? 1 : 0, n_local, cap, T};
+  int bad = -1, invalid = local_ok ? -1 : 0;
+  for (int peer = 1; peer < c->world; ++peer) {
+    if (all[4 * peer + 3] == kShapeBad) { if (invalid < 0) invalid = peer; continue; }
+    if (bad < 0 && (all[4 * peer] != n_local || all[4 * peer + 1] != cap || all[4 * peer + 2] != T || all[4 * peer + 3] != kShapeMagic)) bad = peer;
+  }
+  int32_t verdict[4] = {invalid >= 0 ? 2 : (bad < 0 ? 1 : 0), n_local, cap, T};
   HCHK(hipMemcpyAsync(c->dev_hdr, verdict, 16, hipMemcpyHostToDevice, c->stream));
   TCHK(c->tp->group_start(err));
   for (int peer = 1; peer < c->world; ++peer) TCHK(c->tp->send(c->dev_hdr, 16, peer, c->stream, err));
   TCHK(c->tp->group_end(c->stream, err));
   HCHK(hipStreamSynchronize(c->stream));
+  if (invalid > 0)
+    return c->fail(DC_E_STATE, "dc_gather_results: rank " + std::to_string(invalid) + " rejected its arguments; no payload was exchanged");
+  if (invalid == 0) return DC_E_INVALID;                       // rank 0's own arguments: the caller reports the message it recorded
   if (bad >= 0)
     return c->fail(DC_E_STATE, "dc_gather_results: rank " + std::to_string(bad) + " brought (n_local, capacity, T) = (" +
                                    std::to_string(all[4 * bad]) + ", " + std::to_string(all[4 * bad + 1]) + ", " +
@@ -333,22 +344,29 @@ void dc_comm_destroy(dc_comm* c) {
 
 int dc_gather_results(dc_comm* c, const dc_result* local, int n_local, dc_result* gathered) {
   if (!c) return DC_E_INVALID;
-  if (!local || n_local <= 0) return c->fail(DC_E_INVALID, "dc_gather_results: bad arguments");
-  if (c->rank == 0 && !gathered) return c->fail(DC_E_INVALID, "dc_gather_results: rank 0 needs the output array");
-  const int cap = local[0].capacity, T = local[0].T;
-  if (cap <= 0 || T <= 0) return c->fail(DC_E_INVALID, "dc_gather_results: results carry no capacity / T (run a forward first)");
-  for (int i = 0; i < n_local; ++i) {
-    if (local[i].capacity != cap || local[i].T != T || local[i].K < 0 || local[i].K > cap || !local[i].boxes ||
-        !local[i].scores || !local[i].tokens)
-      return c->fail(DC_E_INVALID, "dc_gather_results: every record needs the same capacity and T and K <= capacity");
+  // Local validation first -- but with more than one rank nobody returns before the handshake: the verdict of the
+  // handshake carries a rank's failure to all the others, so that they fail together instead of waiting for it.
+  std::string why;
+  int cap = 0, T = 0;
+  if (!local || n_local <= 0) why = "dc_gather_results: bad arguments";
+  else if (c->rank == 0 && !gathered) why = "dc_gather_results: rank 0 needs the output array";
+  else {
+    cap = local[0].capacity; T = local[0].T;
+    if (cap <= 0 || T <= 0) why = "dc_gather_results: results carry no capacity / T (run a forward first)";
+    for (int i = 0; why.empty() && i < n_local; ++i)
+      if (local[i].capacity != cap || local[i].T != T || local[i].K < 0 || local[i].K > cap || !local[i].boxes ||
+          !local[i].scores || !local[i].tokens)
+        why = "dc_gather_results: every record needs the same capacity and T and K <= capacity";
+    if (why.empty() && c->rank == 0)
+      for (int i = 0; why.empty() && i < c->world * n_local; ++i)
+        if (gathered[i].capacity < cap || !gathered[i].boxes || !gathered[i].scores || !gathered[i].tokens)
+          why = "dc_gather_results: gathered[] entries need capacity >= the senders' capacity";
   }
-  if (c->rank == 0)
-    for (int i = 0; i < c->world * n_local; ++i)
-      if (gathered[i].capacity < cap || !gathered[i].boxes || !gathered[i].scores || !gathered[i].tokens)
-        return c->fail(DC_E_INVALID, "dc_gather_results: gathered[] entries need capacity >= the senders' capacity");
+  if (c->world == 1 && !why.empty()) return c->fail(DC_E_INVALID, why);
   if (hipSetDevice(c->device) != hipSuccess) return c->fail(DC_E_HIP, "hipSetDevice failed");
   if (c->world > 1) {
-    const int rc = shape_handshake(c, n_local, cap, T);
+    const int rc = shape_handshake(c, why.empty() ? n_local : 0, cap, T, why.empty());
+    if (!why.empty()) return c->fail(DC_E_INVALID, why);         // this rank's own message wins over the handshake's
     if (rc != DC_OK) return rc;
   }
   const size_t rb = record_bytes(cap, T), block = rb * (size_t)n_local;

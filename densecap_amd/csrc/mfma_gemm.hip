@@ -1038,28 +1038,29 @@ TileCfg pick_cfg(const GemmDesc& d) {
   if (d.force_cfg >= 1 && d.force_cfg <= 3 && !(d.amax_val != nullptr && d.force_cfg == 1)) return (TileCfg)(d.force_cfg - 1);
   const int pm = d.plan_M > 0 ? d.plan_M : d.M;
   auto blocks = [&](int bm, int bn) { return (long)((pm + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
+  const int cus = device_cu_count();
+  auto fills = [&](long t) { return 2 * t >= 3 * (long)cus; };        // >= 1.5 workgroups per CU (384 tiles on MI355X)
   // fused arg-max: 128x64 tiles (two or three workgroups per CU, see launch_mixed) overlap one tile's epilogue
   // with the others' K loops -- measured 2.43 vs 2.51 ms for the 15 decode steps at 1000 x 10498 with two
   // and the same holds for every K loop too short for the K-split kernel (conv2_1: 214 -> 178 us)
   if (d.amax_val != nullptr)             // arg-max epilogue: 64-column tiles only (the partial rows are indexed by tile_n)
-    return blocks(128, 64) >= 384 ? CFG_128x64 : CFG_64x64;
-  if (d.K < KS_MIN_KTILES * BK && d.N > 64 && blocks(128, 128) >= 384) return CFG_128x64;
-  if (d.N > 64 && blocks(128, 128) >= 384) {
+    return fills(blocks(128, 64)) ? CFG_128x64 : CFG_64x64;
+  if (d.K < KS_MIN_KTILES * BK && d.N > 64 && fills(blocks(128, 128))) return CFG_128x64;
+  if (d.N > 64 && fills(blocks(128, 128))) {
     // long K, many tiles: the K-split kernel (one workgroup per CU: rounds x (2.08 us x K-tiles + 10 us), calibrated on
     // fc6 / fc7 / conv2_2 .. conv4_2) unless its rounds fall so badly that the 128x64 kernel's finer rounds win by 5 %
     // (1080x720 conv4_3: 384 tiles = 1.5 rounds, 587 us, against 768 tiles of 128x64, 473 us measured on its 380-tile twin)
-    const int cus = device_cu_count(), nkt = d.K / BK;
+    const int nkt = d.K / BK;
     const long t128 = blocks(128, 128), t64 = blocks(128, 64);
     const double t_ks = (double)((t128 + cus - 1) / cus) * (2.08 * nkt + 10.0);
     const double t_v2 = v2_cost_units((int)t64, v2_pick_stages((int)t64, cus), cus) * 0.853 * nkt;
     return t64 < (1 << 30) && t_v2 < 0.95 * t_ks ? CFG_128x64 : CFG_128x128;
   }
-  if (d.N <= 64 && blocks(128, 64) >= 384) return CFG_128x64;
-  if (d.N > 64 && blocks(128, 128) >= 200 && blocks(128, 128) <= 256) return CFG_128x128;
-  if (blocks(128, 64) >= 384) {
+  if (d.N <= 64 && fills(blocks(128, 64))) return CFG_128x64;
+  if (d.N > 64 && 32 * blocks(128, 128) >= 25 * (long)cus && blocks(128, 128) <= cus) return CFG_128x128;   // 200..256 tiles: one nearly full round
+  if (fills(blocks(128, 64))) {
     // a round and a half of 128x64 tiles, or finer 64x64 tiles?  (700-row fc7: 384 tiles of 128x64 on 512 slots, 244 us,
     // against 704 of 64x64, 189 us; 480x320 conv2_2: 600 vs 1200 tiles, 105 vs 102 us) -- the round model decides
-    const int cus = device_cu_count();
     const int t64 = (int)blocks(128, 64), t6464 = (int)blocks(64, 64);
     return v2_cost_units(t64, v2_pick_stages(t64, cus), cus) <= v2_cost_units64(t6464, cus) ? CFG_128x64 : CFG_64x64;
   }
@@ -1090,9 +1091,10 @@ int mfma_gemm_splitk(const GemmDesc& d, size_t ws_floats) {
   const int pm = d.plan_M > 0 ? d.plan_M : d.M;       // one image's tiles: the split factor fixes the summation order
   const long tiles = (long)((pm + 127) / 128) * ((d.N + 127) / 128);
   const int nkt = d.K / BK;
+  const long G = device_cu_count();                   // every planner costs its rounds on the device's CU count (256 on MI355X)
   // (problems of 128..255 tiles leave up to half the chip idle in their single round: inside the K-split kernel's domain
   // they are costed below like the smaller ones -- 500 proposals' fc6: 128 tiles x 2; outside it the 128x64 kernel has them)
-  if (tiles >= 256 || d.N < 128 || (tiles >= 128 && nkt < KS_MIN_KTILES)) return 1;
+  if (tiles >= G || d.N < 128 || (2 * tiles >= G && nkt < KS_MIN_KTILES)) return 1;
   // the largest factor that still leaves every workgroup an even run of K-tiles: >= 16 of them when the chip can be
   // filled that way, down to 6 for problems of a handful of tiles (480x320: conv5_x 20 tiles, RPN conv 10 -- 9 x 16
   // K-tiles used 180 / 90 CUs: 55 / 52 us; 12 x 12 and 24 x 6 fill 240: measured below)
@@ -1101,11 +1103,11 @@ int mfma_gemm_splitk(const GemmDesc& d, size_t ws_floats) {
   auto fits = [&](int sp) { return (size_t)sp * 2 * pm * d.N <= ws_floats; };
   int best = 1;
   for (int sp = 2; sp <= 32; ++sp) {
-    if (tiles * sp > 256) break;
+    if (tiles * sp > G) break;
     if (nkt % sp || !fits(sp)) continue;
     const int per = nkt / sp;
     if ((per & 1) || per < 6) continue;
-    if (per < 16 && tiles * best >= 192) continue;     // the chip is (nearly) full already: do not shorten the K runs
+    if (per < 16 && 4 * tiles * best >= 3 * G) continue;     // the chip is (nearly) full already: do not shorten the K runs
     best = sp;
   }
   // Several rounds of shorter K runs, when one round leaves a quarter of the chip idle behind very long runs (fc6 at 300
@@ -1113,7 +1115,7 @@ int mfma_gemm_splitk(const GemmDesc& d, size_t ws_floats) {
   // its K run at the K-split kernel's 2.08 us per K-tile + ~10 us of prologue and reduction phases; the reduce launch
   // reads `sp` partial outputs at ~3 TB/s.  Taken only when it beats the one-round choice by 10 %.
   auto est = [&](int sp) {
-    const long rounds = (tiles * sp + 255) / 256;
+    const long rounds = (tiles * sp + G - 1) / G;
     const double reduce = sp > 1 ? 4.0 + (double)sp * pm * d.N * 4.0 / 3.0e6 : 0.0;
     return (double)rounds * ((double)(nkt / sp) * 2.08 + 10.0) + reduce;
   };
@@ -1127,7 +1129,7 @@ int mfma_gemm_splitk(const GemmDesc& d, size_t ws_floats) {
   int multi = best;
   double t_multi = est(best);
   for (int sp = best + 1; sp <= 32 && nkt >= KS_MIN_KTILES; ++sp) {
-    if (tiles * sp <= 256 || nkt % sp) continue;
+    if (tiles * sp <= G || nkt % sp) continue;
     const int per = nkt / sp;
     if ((per & 1) || per < 16 || !fits(sp)) continue;
     if (est(sp) < t_multi) { multi = sp; t_multi = est(sp); }
@@ -1144,13 +1146,14 @@ bool mfma_gemm_tail_plan(const GemmDesc& d, int* m_split, int* tail_splitk) {
   const int ntm = (d.M + 127) / 128, ntn = (d.N + 127) / 128, nkt = d.K / BK;
   // the K-split kernel's domain only: below KS_MIN_KTILES the 128x64 kernel is the faster one (conv2_1, K = 576: a tail
   // plan used to force it onto the K-split kernel in single-image mode, 205 vs 167 us)
-  if ((nkt & 1) || nkt < KS_MIN_KTILES || 256 % ntn) return false;
+  const long G = device_cu_count();
+  if ((nkt & 1) || nkt < KS_MIN_KTILES || G % ntn) return false;
   const long T = (long)ntm * ntn;
-  const long rounds = T / 256, r = T % 256;
+  const long rounds = T / G, r = T % G;
   // Measured (profiles/r03_streamk_ablation.md): the plan pays only behind at least one full round and with a sizeable
   // remainder -- 844 tiles (r = 76): 351 -> 317 us, 422 tiles (r = 166): 319 -> 300 us; 300 tiles (r = 44, 480x320
   // conv2_2): 108 -> 134 us, 150 tiles and no full round (480x320 conv3_2): 118 -> 130 us
-  if (rounds < 1 || r < 64) return false;
+  if (rounds < 1 || 4 * r < G) return false;
   const double t_tile = nkt * kUsPerKtile;
   const double base = t_tile;                       // the partial round as whole tiles
   double best = base;
@@ -1160,13 +1163,13 @@ bool mfma_gemm_tail_plan(const GemmDesc& d, int* m_split, int* tail_splitk) {
     const int per = nkt / sp;
     if ((per & 1) || per < 6) continue;
     const long units = r * sp;
-    const double t = (double)((units + 255) / 256) * per * kUsPerKtile          // K loops
-                     + (double)((units + 255) / 256) * 4.0                       // per-round prologue + 4-phase reduction
+    const double t = (double)((units + G - 1) / G) * per * kUsPerKtile          // K loops
+                     + (double)((units + G - 1) / G) * 4.0                       // per-round prologue + 4-phase reduction
                      + (double)(sp + 1) * r * 65536.0 / 4.0e6 + 6.0;             // partial tiles through HBM + reduce launch
     if (t < best) { best = t; best_s = sp; }
   }
   if (best_s == 1 || best > 0.93 * base) return false;
-  *m_split = (int)(rounds * 256 / ntn) * 128;       // rows covered by the full rounds (whole row-tiles: ntn | 256)
+  *m_split = (int)(rounds * G / ntn) * 128;         // rows covered by the full rounds (whole row-tiles: ntn | G)
   *tail_splitk = best_s;
   return true;
 }

@@ -177,3 +177,17 @@ def test_gather_results_refuses_unequal_shards_without_hanging():
     shapes = [(2, 20, 15), (2, 24, 15)]                                      # another capacity
     _, out, errs = _loopback_gather(2, 2, 20, 15, shapes=shapes, seed=10)
     assert all(e is not None for e in errs), errs
+
+
+def test_gather_results_local_validation_failure_reaches_every_rank():
+    """Advisor finding (round 3): a rank whose own arguments are bad used to return BEFORE the handshake, leaving the other
+    ranks blocked in it.  The failure now travels in the handshake: all ranks return an error together, nobody hangs --
+    whether the bad rank is a peer or rank 0 itself."""
+    for shapes, bad in (([(2, 20, 15), (0, 20, 15)], 1), ([(0, 20, 15), (2, 20, 15)], 0),
+                        ([(2, 20, 15), (2, 20, 15), (0, 20, 15), (2, 20, 15)], 2)):
+        _, out, errs = _loopback_gather(len(shapes), 2, 20, 15, shapes=shapes, seed=30 + bad)
+        assert all(e is not None for e in errs), errs
+        assert "bad arguments" in str(errs[bad])
+        for r, e in enumerate(errs):
+            if r != bad:
+                assert "rejected its arguments" in str(e), (r, str(e))
