@@ -59,7 +59,9 @@ struct GemmDesc {
   // sk_wgs partial tiles of 128x128 floats; sk_flags[0..sk_wgs) zeroed before the launch; sk_fault = sticky device word
   // raised when an owner gives up waiting for a partner (checked by the host with the results)
   int stages = 0;             // LDS ring depth of the 128x64-tile kernel: 0 = by tile count, 3 (two workgroups per CU) or 2 (three per CU)
-  int force_cfg = 0;          // measurement hook (dc_debug_set "force_cfg"): 0 = planned, 1 = 128x128, 2 = 128x64, 3 = 64x64 tiles; 4 = planned tiles, no split-K
+  int force_cfg = 0;          // measurement hook (dc_debug_set "force_cfg"): 0 = planned, 1 = 128x128, 2 = 128x64, 3 = 64x64 tiles; 4 = planned tiles, no split-K;
+                              // 5 = 128x128 tiles on the v2 kernel with a two-stage ring (two workgroups per CU); 6 = the K-split 128x128 kernel whatever K
+  int stagger = 0;            // measurement hook (dc_debug_set "stagger"): workgroups start after a pseudo-random pause of up to this many 64-cycle sleeps
   const int* sk_lo = nullptr;
   int sk_np = 0;
   float* sk_slots = nullptr;
@@ -79,6 +81,9 @@ hipError_t launch_splitk_reduce_pool(const float* ws, int S, const float* bias, 
                                      int ldc, int H, int Wd, int relu, hipStream_t s);
 // can this conv problem take GemmDesc::pool (operands within the kernels' 32-bit buffer offsets)?
 bool mfma_gemm_can_pool(const GemmDesc& d);
+// Largest image group a launch may carry (dc_set_group).  Split-K factors are functions of ONE image's problem, so the
+// partial-output workspace test assumes a group of this size: an image gets the same factor in every group.
+constexpr int kGemmMaxGroup = 4;
 // split factor launch_mfma_gemm would like for this problem (1 = none)
 int mfma_gemm_splitk(const GemmDesc& d, size_t ws_floats);      // ws_floats: capacity of the partial-output workspace
 // Tail plan for problems whose 128x128 tile count is not a multiple of the 256 CUs: rows [0, m_split) run as

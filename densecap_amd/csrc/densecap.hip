@@ -87,13 +87,14 @@ struct dc_ctx {
   float rpn_nms_thresh = 0.7f, final_nms_thresh = 0.3f;
   int max_lanes = 3;
   bool captions_after_final_nms = false;
-  int group = 0;             // images per lane group (dc_set_group): 0 = default (1), 1, 2
+  int group = 0;             // images per lane group (dc_set_group): 0 = default (1), 1 .. kGemmMaxGroup
   int arena_allocs = 0;      // lane workspace (re)allocations so far (dc_debug_fetch "arena_allocs")
   double host_enqueue_ms = 0;  // host ms per image spent enqueueing in the last dc_forward_batch
   int beam_size = 0;         // 0 = greedy LM:sample; > 0 = LM:beamsearch (LanguageModel.lua:129-131)
   int64_t beam_chunk_floats = (int64_t)1 << 28;   // cap of the beam search's full-logits buffer (dc_debug_set)
   uint32_t* fault_dev = nullptr;   // sticky device word: a stream-K owner gave up waiting for its partner (checked with the results)
   int force_cfg = 0;         // measurement hook: tile configuration of plain launches (dc_debug_set "force_cfg")
+  int stagger = 0;           // measurement hook: start-up stagger of a launch's workgroups (dc_debug_set "stagger")
   int v2_stages = 0;         // LDS ring depth of the 128x64-tile kernel (dc_debug_set "v2_stages": 0 by tile count, 2 or 3 forced)
   int tail_mode = 0;         // partial last round in single-image mode: 0 stream-K, 1 K-split tail plan, 2 whole tiles (dc_debug_set)
   bool serial_mode = false;  // lanes == 1: idle CUs in a layer's last round are worth a tail split-K (dc_set_lanes)
@@ -182,6 +183,7 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, float* ws = nullp
   GemmDesc d = d_in;
   d.stages = ctx->v2_stages;
   d.force_cfg = ctx->force_cfg;
+  d.stagger = ctx->stagger;
   ProfEvt pe{nullptr, nullptr, gemm_flops(d)};
   if (ctx->prof) {
     pe.a = prof_event(ctx); pe.b = prof_event(ctx);
@@ -288,7 +290,7 @@ int conv3x3_pool(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, co
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 // num_proposals = -1 (LocalizationLayer.lua:322-324: uncapped RPN NMS): capacity = every anchor of this image size
 int effective_proposals(const dc_ctx* ctx, int H, int W);
-constexpr size_t kSplitkWsFloats = (size_t)1600 * 128 * 128;  // 100 MiB per lane: split-K partial outputs (up to 8 x a two-image group's 384 x 4096 fc6 rows), tail plans, stream-K slots
+constexpr size_t kSplitkWsFloats = (size_t)3200 * 128 * 128;  // 200 MiB per lane: split-K partial outputs (up to 8 x a four-image group's 4 x 384 x 4096 fc6 rows), tail plans, stream-K slots
 
 int effective_proposals(const dc_ctx* ctx, int H, int W) {
   if (ctx->num_proposals != -1) return ctx->num_proposals;
@@ -864,7 +866,7 @@ int dc_set_lanes(dc_ctx* ctx, int lanes) {
 
 int dc_set_group(dc_ctx* ctx, int images) {
   if (!ctx) return DC_E_INVALID;
-  if (images < 0 || images > 2) return ctx->fail(DC_E_INVALID, "dc_set_group: 0 (default = 1), 1 or 2 images per group");
+  if (images < 0 || images > kGemmMaxGroup) return ctx->fail(DC_E_INVALID, "dc_set_group: 0 (default = 1) .. %d images per group", kGemmMaxGroup);
   ctx->group = images;
   return DC_OK;
 }
@@ -1050,7 +1052,8 @@ static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, i
   for (int i = 0; i < n; ++i)
     if (outs[i].capacity <= 0) return ctx->fail(DC_E_INVALID, "dc_result.capacity must be > 0");
   // images travel in groups of G through a lane (dc_set_group): the group's dense stages share launches
-  const int G = std::max(1, std::min(ctx->group > 0 ? ctx->group : 1, n));
+  int G = std::max(1, std::min(ctx->group > 0 ? ctx->group : 1, n));
+  while (G > 1 && (size_t)G * H * W * 64 * 4 >= 0xffffe000ull) --G;      // a group's conv1_x activation shares one 32-bit offset space
   const int ngroups = (n + G - 1) / G;
   const int nl = std::min(ngroups, ctx->max_lanes);
   while ((int)ctx->lanes.size() < nl) ctx->lanes.emplace_back(new Lane());
@@ -1252,8 +1255,13 @@ int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value) {
     return DC_OK;
   }
   if (strcmp(name, "force_cfg") == 0) {
-    if (value < 0 || value > 4) return ctx->fail(DC_E_INVALID, "dc_debug_set: force_cfg must be 0..4");
+    if (value < 0 || value > 6) return ctx->fail(DC_E_INVALID, "dc_debug_set: force_cfg must be 0..6");
     ctx->force_cfg = (int)value;
+    return DC_OK;
+  }
+  if (strcmp(name, "stagger") == 0) {
+    if (value < 0 || value > 4096) return ctx->fail(DC_E_INVALID, "dc_debug_set: stagger must be 0..4096 (64-cycle sleeps)");
+    ctx->stagger = (int)value;
     return DC_OK;
   }
   if (strcmp(name, "tail_mode") == 0) {

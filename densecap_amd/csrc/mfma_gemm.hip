@@ -451,6 +451,15 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
 }
 
 
+// Measurement hook (GemmDesc::stagger): a launch's workgroups all start within a microsecond and then march through their
+// K loops in lockstep -- every CU asks for its next K-tile at the same moment.  A one-off pseudo-random pause of up to
+// `stagger` x 64 cycles spreads them over a K-tile's period.  Results do not change.
+__device__ __forceinline__ void start_stagger(const GemmDesc& d) {
+  if (d.stagger <= 0) return;
+  const unsigned n = ((blockIdx.x * 2654435761u) >> 12) % (unsigned)d.stagger;
+  for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+}
+
 // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (b % 8); each XCD gets a contiguous run of logical tile ids so
 // that neighbours in the fast dimension share its L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -461,6 +470,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 template <int TM, int TN, bool CONV, int NS, bool AMAX = false>
 __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  start_stagger(d);
   const int bid = xcd_remap(blockIdx.x, ntm * ntn);
   int tile_m, tile_n;
   if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
@@ -485,6 +495,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
 template <bool CONV, int NS, bool AMAX>
 __global__ __launch_bounds__(256) void mfma_gemm_v2_mixed_kernel(GemmDesc d, int ntm, int ntn, int m_fastest, int nbig) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  start_stagger(d);
   int Meff = d.M;
   if (d.m_dev != nullptr) {
     const int me = *d.m_dev;
@@ -823,6 +834,7 @@ __device__ __forceinline__ void ks_segment(const GemmDesc& d, const int m0, cons
 template <bool CONV>
 __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  start_stagger(d);
   int bid = xcd_remap(blockIdx.x, ntm * ntn * d.splitk);
   const int slice = bid % d.splitk;                  // K slice of this workgroup (split-K), fastest index
   bid /= d.splitk;
@@ -990,6 +1002,14 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   if (!fits || (size_t)BN * d.K * 4 >= 0xfffffff0ull) return hipErrorInvalidValue;
   if constexpr (TM == 2 && TN == 2) {
     if (d.amax_val != nullptr) return hipErrorInvalidValue;    // the arg-max epilogue lives in the 64-column v2 variant
+    if (d.force_cfg == 5 && d.splitk == 1 && d.m_begin == 0 && d.a_rows == 0) {
+      // measurement route: 128x128 tiles on the v2 kernel with a TWO-stage ring -- 64 KiB of LDS, two workgroups per CU
+      const size_t lds2 = (size_t)2 * (BM + BN) * BK * sizeof(float);
+      const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<2, 2, CONV, 2>);
+      if (hipError_t e = ensure_dyn_lds(fn, lds2); e != hipSuccess) return e;
+      hipLaunchKernelGGL((mfma_gemm_v2_kernel<2, 2, CONV, 2>), dim3(ntm * ntn), dim3(256), lds2, stream, d, ntm, ntn, m_fastest);
+      return hipGetLastError();
+    }
     if (cfg128_uses_ks(d)) {                                   // short K loops do not amortise the 4-phase reduction
       // 64 KiB operand ring, reused as the 4 x 16 KiB reduction slots; leaves 96 KiB of the CU's LDS to co-resident workgroups
       const size_t lds_ks = (size_t)2 * (BM + BN) * BK * sizeof(float);
@@ -1036,6 +1056,7 @@ enum TileCfg { CFG_128x128 = 0, CFG_128x64 = 1, CFG_64x64 = 2 };
 TileCfg pick_cfg(const GemmDesc& d) {
   if (d.splitk > 1) return CFG_128x128;
   if (d.force_cfg >= 1 && d.force_cfg <= 3 && !(d.amax_val != nullptr && d.force_cfg == 1)) return (TileCfg)(d.force_cfg - 1);
+  if ((d.force_cfg == 5 || d.force_cfg == 6) && d.amax_val == nullptr && d.N > 64) return CFG_128x128;
   const int pm = d.plan_M > 0 ? d.plan_M : d.M;
   auto blocks = [&](int bm, int bn) { return (long)((pm + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
   const int cus = device_cu_count();
@@ -1068,7 +1089,8 @@ TileCfg pick_cfg(const GemmDesc& d) {
 }
 // a 128x128 launch runs the K-split kernel when its K loop is long enough (or the caller's row window / split-K needs it)
 bool cfg128_uses_ks(const GemmDesc& d) {
-  const bool forced = d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0;
+  const bool forced = d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0 || d.force_cfg == 6;
+  if (d.force_cfg == 5 && !forced) return false;
   return d.amax_val == nullptr && (d.K % (2 * BK * d.splitk)) == 0 && (forced || d.K >= KS_MIN_KTILES * BK);
 }
 
@@ -1099,8 +1121,8 @@ int mfma_gemm_splitk(const GemmDesc& d, size_t ws_floats) {
   // filled that way, down to 6 for problems of a handful of tiles (480x320: conv5_x 20 tiles, RPN conv 10 -- 9 x 16
   // K-tiles used 180 / 90 CUs: 55 / 52 us; 12 x 12 and 24 x 6 fill 240: measured below)
   // every choice is a function of ONE image's problem (plan_M): a group of two images must get the factor each image gets
-  // alone, so the workspace test assumes the largest group the ABI allows (dc_set_group: 2)
-  auto fits = [&](int sp) { return (size_t)sp * 2 * pm * d.N <= ws_floats; };
+  // alone, so the workspace test assumes the largest group the ABI allows (dc_set_group: kGemmMaxGroup)
+  auto fits = [&](int sp) { return (size_t)sp * kGemmMaxGroup * pm * d.N <= ws_floats; };
   int best = 1;
   for (int sp = 2; sp <= 32; ++sp) {
     if (tiles * sp > G) break;

@@ -2,7 +2,7 @@
 function exported through the C ABI (dc_debug_plan_gemm): pinned here without a GPU.
 
 * the table of the BASELINE workloads (a policy change must be a conscious edit of this file);
-* image groups: a launch over two images' rows (dc_set_group(2)) must be planned exactly like one image alone wherever
+* image groups: a launch over the rows of 2, 3 or 4 images (dc_set_group) must be planned exactly like one image alone wherever
   the plan fixes the fp32 summation order -- this is what makes grouped results bit-identical (a 300-proposal fc6 once
   got another split factor in a group because of a workspace test on the group's rows);
 * split-K factors cut K into equal, even runs of K-tiles."""
@@ -94,17 +94,18 @@ def test_plans_of_the_other_baseline_workloads():
         assert (p["kind"], p["route"]) == ("plain", "v2_64x64"), (M, N, K, p)
 
 
-def test_groups_of_two_images_are_planned_like_one_image():
-    """dc_set_group(2): the launch covers 2 x rows, planned with plan_M = rows.  Wherever the plan fixes the summation
+@pytest.mark.parametrize("G", [2, 3, 4])
+def test_groups_of_images_are_planned_like_one_image(G):
+    """dc_set_group(G): the launch covers G x rows, planned with plan_M = rows.  Wherever the plan fixes the summation
     order it must be the single image's (multi-lane scheduling: groups are not used in single-image mode)."""
     bad = []
     dense = [(4096, 25088), (4096, 4096), (512, 4096), (2048, 512), (72, 256), (5, 4096)]
     for P in list(range(1, 130)) + list(range(130, 2100, 13)) + [256, 300, 384, 385, 500, 512, 640, 1000, 1024, 2000]:
         for N, K in dense:
-            a, b = plan(P, N, K), plan(2 * P, N, K, plan_M=P)
+            a, b = plan(P, N, K), plan(G * P, N, K, plan_M=P)
             if order_class(a) != order_class(b):
                 bad.append(("dense", P, N, K, a, b))
-        a, b = plan(P, VOCAB_STEP, 512, amax=1), plan(2 * P, VOCAB_STEP, 512, plan_M=P, amax=1)
+        a, b = plan(P, VOCAB_STEP, 512, amax=1), plan(G * P, VOCAB_STEP, 512, plan_M=P, amax=1)
         if order_class(a) != order_class(b):
             bad.append(("decode", P, a, b))
     convs = [(64, 64, 0), (64, 128, 1), (128, 128, 1), (128, 256, 2), (256, 256, 2), (256, 512, 3), (512, 512, 3),
@@ -113,14 +114,14 @@ def test_groups_of_two_images_are_planned_like_one_image():
                    (97, 333), (600, 900)]:
         for cin, cout, level in convs:
             rows = conv_rows(H, W, level)
-            a, b = plan(rows, cout, 9 * cin, cin=cin), plan(2 * rows, cout, 9 * cin, plan_M=rows, cin=cin)
+            a, b = plan(rows, cout, 9 * cin, cin=cin), plan(G * rows, cout, 9 * cin, plan_M=rows, cin=cin)
             if order_class(a) != order_class(b):
                 bad.append(("conv", H, W, cin, cout, level, a, b))
     assert not bad, bad[:5]
 
 
 def test_split_factors_cut_k_into_equal_even_runs_and_fit_the_workspace():
-    ws_floats = 1600 * 128 * 128
+    ws_floats = 3200 * 128 * 128
     for M in (1, 50, 64, 128, 200, 300, 384, 500, 640, 1000, 1710, 2400):
         for N, K in [(4096, 25088), (4096, 4096), (512, 4096), (512, 4608), (256, 4608), (512, 2304), (1024, 6272)]:
             for serial in (0, 1):
@@ -129,7 +130,7 @@ def test_split_factors_cut_k_into_equal_even_runs_and_fit_the_workspace():
                 nkt = K // 32
                 assert nkt % sp == 0 and (sp == 1 or (nkt // sp) % 2 == 0), (M, N, K, p)
                 if p["kind"] == "splitk":
-                    assert sp * 2 * M * N <= ws_floats, (M, N, K, p)          # also for a group of two such images
+                    assert sp * 4 * M * N <= ws_floats, (M, N, K, p)          # also for a group of four such images
                     assert p["route"] == "ks"
 
 

@@ -193,6 +193,14 @@ def test_config3_batch32_300_proposals(model, weights):
     imgs = np.stack([base[i % 4] for i in range(32)])
     batch = model.forward_batch(imgs)
     assert len(batch) == 32
+    try:                                   # the same batch in groups of four images per lane (how bench.py runs this config)
+        model.setGroup(4)
+        grouped = model.forward_batch(imgs)
+    finally:
+        model.setGroup(0)
+    for a, b in zip(batch, grouped):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
     parity.oracle_threads()
     for i in range(4):
         # P=300 against the ORACLE (not against the HIP path itself): final lists identical or proven near-tie
@@ -524,41 +532,42 @@ def test_webcam_daemon_with_the_hip_model(tmp_path):
 
 
 def test_image_groups_do_not_change_results(model, weights):
-    """dc_set_group: two images sharing the dense stages' launches (convolutions over both images, fc6/fc7 and the
-    decode over both images' RoI rows) must give each image exactly the results it gets alone -- the kernel route and the
-    split-K factor are planned per image.  Odd batch sizes leave a group of one at the end."""
+    """dc_set_group: 2, 3 or 4 images sharing the dense stages' launches (convolutions over all of them, fc6/fc7 and the
+    decode over all their RoI rows) must give each image exactly the results it gets alone -- the kernel route and the
+    split-K factor are planned per image.  Batch sizes that are no multiple of the group leave a smaller group at the end."""
     from densecap_amd.weights import make_synthetic_image
     try:
-        for (H, W, P, n) in [(224, 288, 100, 5), (600, 720, 1000, 3), (203, 301, 64, 4)]:
+        for (H, W, P, n) in [(224, 288, 100, 7), (600, 720, 1000, 5), (203, 301, 64, 6), (600, 720, 300, 9)]:
             model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
             imgs = np.stack([make_synthetic_image(H, W, 70 + s) for s in range(n)])
             outs = {}
-            for group in (1, 2, 0):
+            for group in (1, 2, 3, 4, 0):
                 model.setGroup(group)
                 outs[group] = model.forward_batch(imgs)
             for i in range(n):
                 single = model.forward_raw(imgs[i])
-                for group in (1, 2, 0):
+                for group in (1, 2, 3, 4, 0):
                     for x, y in zip(outs[group][i], single):
-                        np.testing.assert_array_equal(x, y)
+                        np.testing.assert_array_equal(x, y, err_msg="%dx%d P=%d group %d image %d" % (W, H, P, group, i))
                 assert len(single[0]) > 0
         # random sizes / proposal counts / thresholds (odd sizes exercise the ceil-mode pool windows per image)
         rng = np.random.default_rng(11)
-        for case in range(6):
+        for case in range(8):
             H = int(rng.integers(40, 330)); W = int(rng.integers(40, 400))
             P = int(rng.choice([1, 7, 50, 128, 300, -1]))
             model.setTestArgs(rpn_nms_thresh=float(rng.choice([0.3, 0.7])), final_nms_thresh=float(rng.choice([0.0, 0.3, 0.5])),
                               num_proposals=P)
             model.setCaptionOrder(bool(case % 2))
-            imgs = np.stack([make_synthetic_image(H, W, 900 + 3 * case + s) for s in range(3)])
-            model.setGroup(2)
-            pair = model.forward_batch(imgs)
+            G = 2 + case % 3
+            imgs = np.stack([make_synthetic_image(H, W, 900 + 3 * case + s) for s in range(G + 1)])
+            model.setGroup(G)
+            grouped = model.forward_batch(imgs)
             model.setGroup(1)
-            for i in range(3):
-                for x, y in zip(pair[i], model.forward_raw(imgs[i])):
-                    np.testing.assert_array_equal(x, y, err_msg="case %d (%dx%d, P=%d) image %d" % (case, W, H, P, i))
+            for i in range(G + 1):
+                for x, y in zip(grouped[i], model.forward_raw(imgs[i])):
+                    np.testing.assert_array_equal(x, y, err_msg="case %d (%dx%d, P=%d, group %d) image %d" % (case, W, H, P, G, i))
         with pytest.raises(Exception):
-            model.setGroup(3)
+            model.setGroup(5)
     finally:
         model.setGroup(0)
         model.setCaptionOrder(False)

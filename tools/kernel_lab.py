@@ -1,0 +1,240 @@
+"""Round-4 measurement campaign (run on the GPU box): one process, many A/B arms, one JSON.
+
+  python tools/kernel_lab.py kernels   # contraction kernels: shape x tile configuration (force_cfg) x start stagger
+  python tools/kernel_lab.py e2e       # images/s over proposals x lanes x images per group (dc_set_group)
+  python tools/kernel_lab.py pmc-target <arm>   # a short fixed dispatch list for a rocprofv3 --pmc pass
+
+Every arm is a measurement hook of include/densecap_debug.h; none of them changes a result except by choosing among
+deterministic fp32 summation orders (force_cfg).  Output: gpurun_out/lab_<mode>.json + a table on stdout.
+"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from densecap_amd._lib import check  # noqa: E402
+from densecap_amd.ops import Context  # noqa: E402
+
+OUT = os.path.join(ROOT, "gpurun_out")
+os.makedirs(OUT, exist_ok=True)
+CFG_NAMES = {0: "planned", 1: "128x128", 2: "128x64", 3: "64x64", 5: "v2_128x128_ns2", 6: "ks_forced"}
+
+
+def dset(ctx, name, v):
+    check(ctx.h, ctx.lib.dc_debug_set(ctx.h, name.encode(), int(v)), "dc_debug_set(%s)" % name)
+
+
+def prof(ctx, reset):
+    l = C.c_int64(0); ms = C.c_double(0); fl = C.c_double(0)
+    ctx.lib.dc_mfma_profile(ctx.h, reset, C.byref(l), C.byref(ms), C.byref(fl))
+    return l.value, ms.value, fl.value
+
+
+class Ops:
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.rng = np.random.default_rng(0)
+        self.cache = {}
+
+    def buf(self, key, n):
+        if key not in self.cache:
+            self.cache[key] = self.ctx.to_device(self.rng.standard_normal(n).astype(np.float32))
+        return self.cache[key]
+
+    def free(self):
+        for b in self.cache.values():
+            b.free()
+        self.cache = {}
+
+    def run_dense(self, M, N, K, reps):
+        ctx = self.ctx
+        A = self.buf(("A", M * K), M * K); W = self.buf(("W", N * K), N * K); b = self.buf(("b", N), N)
+        Cc = self.buf(("C", M * N), M * N)
+        call = lambda: check(ctx.h, ctx.lib.dc_op_linear(ctx.h, A.ptr, W.ptr, b.ptr, Cc.ptr, M, N, K, 1), "dc_op_linear")
+        return self._time(call, reps)
+
+    def run_conv(self, nimg, H, Wd, Cin, Cout, reps, pool=False):
+        ctx = self.ctx
+        A = self.buf(("A", nimg * H * Wd * Cin), nimg * H * Wd * Cin); W = self.buf(("W", Cout * 9 * Cin), Cout * 9 * Cin)
+        b = self.buf(("b", Cout), Cout); Cc = self.buf(("C", nimg * H * Wd * Cout), nimg * H * Wd * Cout)
+        if pool:
+            call = lambda: check(ctx.h, ctx.lib.dc_op_conv3x3_relu_pool(ctx.h, A.ptr, W.ptr, b.ptr, Cc.ptr, H, Wd, Cin, Cout), "pool")
+        else:
+            call = lambda: check(ctx.h, ctx.lib.dc_op_conv3x3(ctx.h, A.ptr, W.ptr, b.ptr, Cc.ptr, nimg, H, Wd, Cin, Cout, 1), "conv")
+        return self._time(call, reps)
+
+    def _time(self, call, reps):
+        call()                                            # warm-up (kernel attributes, caches)
+        prof(self.ctx, 1)
+        for _ in range(reps):
+            call()
+        l, ms, fl = prof(self.ctx, -1)
+        return dict(us=ms / max(l, 1) * 1e3, tf=fl / max(ms, 1e-9) / 1e9, gflop=fl / max(l, 1) / 1e9)
+
+
+DENSE = [("fc6", 1000, 4096, 25088), ("fc6_x4", 4000, 4096, 25088), ("fc7", 1000, 4096, 4096), ("fc7_x8", 8000, 4096, 4096),
+         ("dense_c3_2", 27000, 256, 2304), ("dense_c3_2_x4", 108000, 256, 2304), ("dense_c2_2", 108000, 128, 1152),
+         ("dense_c4_2", 6750, 512, 4608), ("dense_c4_2_x8", 54000, 512, 4608)]
+CONVS = [("conv1_2", 600, 720, 64, 64), ("conv2_1", 300, 360, 64, 128), ("conv2_2", 300, 360, 128, 128),
+         ("conv3_1", 150, 180, 128, 256), ("conv3_2", 150, 180, 256, 256), ("conv4_1", 75, 90, 256, 512),
+         ("conv4_2", 75, 90, 512, 512)]
+
+
+def check_arms(ctx):
+    """Every forced route against the planned one on two modest problems (they differ in fp32 summation order at most)."""
+    rng = np.random.default_rng(1)
+    M, N, K = 1000, 512, 2304
+    A = ctx.to_device(rng.standard_normal(M * K).astype(np.float32)); W = ctx.to_device(rng.standard_normal(N * K).astype(np.float32))
+    b = ctx.to_device(rng.standard_normal(N).astype(np.float32)); Cc = ctx.empty((M, N))
+    H, Wd, Cin, Cout = 75, 90, 256, 512
+    X = ctx.to_device(rng.standard_normal(H * Wd * Cin).astype(np.float32)); Wc = ctx.to_device(rng.standard_normal(Cout * 9 * Cin).astype(np.float32))
+    Y = ctx.empty((H, Wd, Cout))
+    ref = {}
+    for cfg, stag in [(0, 0), (1, 0), (2, 0), (3, 0), (5, 0), (6, 0), (0, 32), (5, 32), (6, 32)]:
+        dset(ctx, "force_cfg", cfg); dset(ctx, "stagger", stag)
+        check(ctx.h, ctx.lib.dc_op_linear(ctx.h, A.ptr, W.ptr, b.ptr, Cc.ptr, M, N, K, 1), "dc_op_linear")
+        d = Cc.numpy().copy()
+        check(ctx.h, ctx.lib.dc_op_conv3x3(ctx.h, X.ptr, Wc.ptr, b.ptr, Y.ptr, 1, H, Wd, Cin, Cout, 1), "conv")
+        c = Y.numpy().copy()
+        if not ref:
+            ref = dict(d=d, c=c)
+        ed = float(np.abs(d - ref["d"]).max() / np.abs(ref["d"]).max()); ec = float(np.abs(c - ref["c"]).max() / np.abs(ref["c"]).max())
+        print("check cfg=%s stagger=%d: dense rel err %.2e, conv rel err %.2e" % (CFG_NAMES[cfg], stag, ed, ec), flush=True)
+        assert ed < 1e-4 and ec < 1e-4, "forced route departs from the planned one"
+    for x in (A, W, b, Cc, X, Wc, Y):
+        x.free()
+
+
+def kernels(reps=5):
+    ctx = Context(0)
+    check_arms(ctx)
+    ops = Ops(ctx)
+    rows = []
+    arms = [(0, 0), (2, 0), (5, 0), (1, 0), (6, 0), (0, 32), (5, 32), (6, 32), (0, 64)]
+    print("%-16s %-16s %8s %10s %8s" % ("op", "cfg", "stagger", "us", "TF"))
+    try:
+        for name, M, N, K in DENSE:
+            for cfg, stag in arms:
+                if cfg == 6 and K % 64:
+                    continue
+                dset(ctx, "force_cfg", cfg); dset(ctx, "stagger", stag)
+                try:
+                    r = ops.run_dense(M, N, K, reps if M * N * K < 5e13 else 2)
+                except Exception as e:       # noqa: BLE001 -- a refused route is a data point, not a failure
+                    r = dict(error=str(e)[:120])
+                rows.append(dict(op=name, M=M, N=N, K=K, cfg=CFG_NAMES[cfg], stagger=stag, **r))
+                print("%-16s %-16s %8d %10.1f %8.1f" % (name, CFG_NAMES[cfg], stag, r.get("us", -1), r.get("tf", -1)), flush=True)
+            ops.free()
+        for nimg in (1, 4):
+            for name, H, Wd, Cin, Cout in CONVS:
+                for cfg, stag in arms:
+                    if cfg == 6 and (9 * Cin) % 64:
+                        continue
+                    dset(ctx, "force_cfg", cfg); dset(ctx, "stagger", stag)
+                    try:
+                        r = ops.run_conv(nimg, H, Wd, Cin, Cout, reps)
+                    except Exception as e:   # noqa: BLE001
+                        r = dict(error=str(e)[:120])
+                    rows.append(dict(op="%s_x%d" % (name, nimg), H=H, W=Wd, Cin=Cin, Cout=Cout, nimg=nimg, cfg=CFG_NAMES[cfg],
+                                     stagger=stag, **r))
+                    print("%-16s %-16s %8d %10.1f %8.1f" % ("%s_x%d" % (name, nimg), CFG_NAMES[cfg], stag, r.get("us", -1),
+                                                            r.get("tf", -1)), flush=True)
+                ops.free()
+    finally:
+        dset(ctx, "force_cfg", 0); dset(ctx, "stagger", 0)
+        json.dump(rows, open(os.path.join(OUT, "lab_kernels.json"), "w"), indent=0)
+        ctx.close()
+
+
+def e2e():
+    from densecap_amd import DenseCapModel
+    from densecap_amd.weights import make_synthetic_image, make_synthetic_weights
+    W = make_synthetic_weights(seed=1234)
+    m = DenseCapModel(W, device=0)
+    ctx = m.ctx
+    H, Wd, n = 600, 720, 24
+    host = np.stack([make_synthetic_image(H, Wd, i) for i in range(n)])
+    dev = ctx.to_device(host)
+    rows = []
+    print("%-6s %-6s %-6s %-8s %10s" % ("P", "lanes", "group", "stagger", "images/s"))
+
+    def rate(reps=3):
+        m.forward_batch_device(dev.ptr, n, H, Wd)            # workspaces exist, clocks warm
+        best = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            m.forward_batch_device(dev.ptr, n, H, Wd)
+            best.append(n / (time.perf_counter() - t0))
+        return float(np.median(best)), float(max(best))
+    try:
+        for P in (300, 1000):
+            m.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
+            for lanes in (1, 2, 3):
+                for group in (1, 2, 3, 4):
+                    if lanes == 3 and group == 4:
+                        pass
+                    m.setLanes(lanes); m.setGroup(group)
+                    med, mx = rate()
+                    rows.append(dict(P=P, lanes=lanes, group=group, stagger=0, images_per_s=med, best=mx))
+                    print("%-6d %-6d %-6d %-8d %10.1f" % (P, lanes, group, 0, med), flush=True)
+            for lanes, group in ((2, 1), (1, 1), (2, 4)):
+                m.setLanes(lanes); m.setGroup(group)
+                dset(ctx, "stagger", 32)
+                med, mx = rate()
+                dset(ctx, "stagger", 0)
+                rows.append(dict(P=P, lanes=lanes, group=group, stagger=32, images_per_s=med, best=mx))
+                print("%-6d %-6d %-6d %-8d %10.1f" % (P, lanes, group, 32, med), flush=True)
+    finally:
+        json.dump(rows, open(os.path.join(OUT, "lab_e2e.json"), "w"), indent=0)
+        m.setGroup(0)
+        dev.free()
+        ctx.close()
+
+
+PMC_ARMS = {
+    # arm -> list of (kind, args, force_cfg, stagger): every entry is dispatched twice, in this order
+    "a": [("dense", (1000, 4096, 25088), 0, 0), ("dense", (4000, 4096, 25088), 0, 0), ("dense", (1000, 4096, 25088), 0, 32),
+          ("conv", (1, 150, 180, 256, 256), 0, 0), ("conv", (1, 150, 180, 256, 256), 5, 0), ("conv", (4, 150, 180, 256, 256), 0, 0),
+          ("conv", (4, 150, 180, 256, 256), 5, 0), ("conv", (1, 600, 720, 64, 64), 0, 0), ("conv", (1, 600, 720, 64, 64), 5, 0),
+          ("conv", (1, 75, 90, 512, 512), 0, 0), ("conv", (1, 75, 90, 512, 512), 5, 0)],
+}
+
+
+def pmc_target(arm):
+    ctx = Context(0)
+    ops = Ops(ctx)
+    order = []
+    for kind, a, cfg, stag in PMC_ARMS[arm]:
+        dset(ctx, "force_cfg", cfg); dset(ctx, "stagger", stag)
+        for _ in range(2):
+            if kind == "dense":
+                M, N, K = a
+                A = ops.buf(("A", M * K), M * K); Wt = ops.buf(("W", N * K), N * K); b = ops.buf(("b", N), N)
+                Cc = ops.buf(("C", M * N), M * N)
+                check(ctx.h, ctx.lib.dc_op_linear(ctx.h, A.ptr, Wt.ptr, b.ptr, Cc.ptr, M, N, K, 1), "dc_op_linear")
+            else:
+                nimg, H, Wd, Cin, Cout = a
+                A = ops.buf(("A", nimg * H * Wd * Cin), nimg * H * Wd * Cin); Wt = ops.buf(("W", Cout * 9 * Cin), Cout * 9 * Cin)
+                b = ops.buf(("b", Cout), Cout); Cc = ops.buf(("C", nimg * H * Wd * Cout), nimg * H * Wd * Cout)
+                check(ctx.h, ctx.lib.dc_op_conv3x3(ctx.h, A.ptr, Wt.ptr, b.ptr, Cc.ptr, nimg, H, Wd, Cin, Cout, 1), "conv")
+            order.append(dict(kind=kind, args=a, cfg=CFG_NAMES[cfg], stagger=stag))
+        ops.free()
+    json.dump(order, open(os.path.join(OUT, "lab_pmc_order_%s.json" % arm), "w"))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1] if len(sys.argv) > 1 else "kernels"
+    if mode == "kernels":
+        kernels(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+    elif mode == "e2e":
+        e2e()
+    elif mode == "pmc-target":
+        pmc_target(sys.argv[2] if len(sys.argv) > 2 else "a")
+    else:
+        raise SystemExit(__doc__)

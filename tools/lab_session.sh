@@ -1,0 +1,32 @@
+#!/bin/bash
+# One GPU-box session of the round-4 measurement campaign (run through gpurun from the repo root):
+#   gpurun --timeout 1500 -- 'bash tools/lab_session.sh [tests] [kernels] [e2e] [pmc]'
+set -u
+REPO=$(pwd)
+OUT=$REPO/gpurun_out
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+WHAT="${*:-tests kernels e2e pmc}"
+for w in $WHAT; do
+  case $w in
+    tests)   timeout 900 python -m pytest tests -m gpu -x -q > "$OUT/lab_tests.log" 2>&1; tail -5 "$OUT/lab_tests.log" ;;
+    kernels) timeout 600 python tools/kernel_lab.py kernels > "$OUT/lab_kernels.txt" 2>&1; tail -3 "$OUT/lab_kernels.txt" ;;
+    e2e)     timeout 600 python tools/kernel_lab.py e2e > "$OUT/lab_e2e.txt" 2>&1; tail -40 "$OUT/lab_e2e.txt" ;;
+    pmc)
+      cd /tmp
+      rocprofv3 -L > "$OUT/rocprof_counters.txt" 2>&1
+      i=0
+      for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
+                 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" \
+                 "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC" \
+                 "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"; do
+        i=$((i+1))
+        rm -rf /tmp/rp_lab$i
+        timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/rp_lab$i -o lab$i -- python $REPO/tools/kernel_lab.py pmc-target a > /tmp/rp_lab$i.log 2>&1
+        find /tmp/rp_lab$i -name "lab${i}_*.csv" -exec cp {} "$OUT"/ \;
+        tail -2 /tmp/rp_lab$i.log
+      done
+      cd "$REPO" ;;
+  esac
+done
+ls -la "$OUT" | tail -30
