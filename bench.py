@@ -48,6 +48,54 @@ def stage_gflop(H, W, P, T, V, k=12, R=256, D=4096, E=512, Hd=512):
     return {"vgg16_trunk": trunk / 1e9, "rpn_conv_heads_decode": rpn / 1e9, "fc6_fc7": fc / 1e9, "lstm_decode": lm / 1e9}
 
 
+def mfma_family_bytes(H, W, P, T, V, k=12, R=256, D=4096, E=512, Hd=512):
+    """Algorithmic HBM bytes of the MFMA contraction family per image (operands read once + result written once per
+    launch, fp32): the denominator `roofline.traffic` is judged against.  Returns (bytes per image, launches per image)."""
+    h, w, total, launches = H, W, 0.0, 0
+    for i, (cin, cout, pool) in enumerate(VGG):
+        oh, ow = ((h + 1) // 2, (w + 1) // 2) if pool else (h, w)
+        if i > 0:                      # conv1_1 is not a member of the family (its own kernel)
+            total += 4.0 * (h * w * cin + cout * 9 * cin + oh * ow * cout)
+            launches += 1
+        h, w = oh, ow
+    total += 4.0 * (h * w * 512 + R * 9 * 512 + h * w * R); launches += 1            # RPN conv
+    total += 4.0 * (h * w * R + 6 * k * R + h * w * 6 * k); launches += 1            # fused 1x1 heads
+    total += 4.0 * (P * 49 * 512 + D * 49 * 512 + P * D); launches += 1              # fc6
+    total += 4.0 * (P * D + D * D + P * D); launches += 1                            # fc7
+    total += 4.0 * (P * D + E * D + P * E); launches += 1                            # LM encoder
+    total += 4.0 * (P * E + 4 * Hd * E + P * 4 * Hd); launches += 1                  # image step gates
+    total += 4.0 * (P * Hd + 4 * Hd * Hd + P * 4 * Hd); launches += 1                # h0.Wh
+    v1pad = (V + 1 + 63) // 64 * 64
+    step = 4.0 * (P * Hd + (v1pad + 4 * Hd) * Hd + P * 4 * Hd + 2 * P * (v1pad // 64))   # [Wout; Wh] panel, gates out, arg-max partials
+    total += (T - 1) * step; launches += T - 1
+    total += 4.0 * (P * Hd + (V + 1) * Hd + 2 * P * (v1pad // 64)); launches += 1    # last step: arg-max only
+    return total, launches
+
+
+def record_bytes(P, T):
+    """One image's record in dc_gather_results: {K, T, capacity, 0; boxes[P][4]; scores[P]; int32 tokens[P][T]} (comm.hip)."""
+    return 16 + P * (16 + 4 + 4 * T)
+
+
+def shard_table(world, K, P, T):
+    """What an N-GPU run of this file does, without running it: rank r owns global images [r*K, (r+1)*K) and the ONE
+    gather per timed region posts, inside one RCCL group, world-1 receives on rank 0 and one send on every peer."""
+    rb = record_bytes(P, T)
+    block = rb * K
+    return {
+        "world": world, "images_per_gpu": K, "total_images_per_region": world * K,
+        "shards": [{"rank": r, "global_images": [r * K, (r + 1) * K]} for r in range(world)],
+        "gather": {
+            "carrier": "dc_gather_results (RCCL ncclSend/ncclRecv in one group, include/densecap.h)",
+            "record_bytes": rb, "block_bytes_per_rank": block,
+            "handshake": {"peer_to_rank0_bytes": 16, "rank0_to_peer_bytes": 16, "messages": 2 * (world - 1)},
+            "rank0_posts": [{"op": "ncclRecv", "peer": p, "bytes": block, "offset": block * p} for p in range(1, world)],
+            "peer_posts": [{"rank": p, "op": "ncclSend", "peer": 0, "bytes": block} for p in range(1, world)],
+            "total_payload_bytes": block * (world - 1),
+            "unpack_order": "gathered[r * images_per_gpu + i] = image i of rank r"},
+    }
+
+
 class GpuSampler:
     """Polls the GPU's shader clock and power while a leg runs (sysfs: pp_dpm_sclk's active level and hwmon
     power1_average/power1_input; `rocm-smi --json` when sysfs has neither).  Means over the window go into the line so a
@@ -229,10 +277,20 @@ def main():
                     help="torch.distributed backend for barriers / timing (gloo: ranks may share one GPU, or none with --stub)")
     ap.add_argument("--gather", default="auto", choices=["auto", "abi", "torch"],
                     help="carrier of the end-of-run gather: abi = dc_gather_results (RCCL), torch = torch.distributed.gather")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="print the per-rank shard table and the exact RCCL byte counts an N-GPU run would post, then exit (no GPU, no ranks)")
+    ap.add_argument("--no-host-input-leg", action="store_true", help="skip the H2D-inclusive legs (images in host memory)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--stub-comm-fail", default="never:-1", help=argparse.SUPPRESS)   # "create:R": StubComm cannot be created on rank R
     args = ap.parse_args()
 
+    if args.dry_run:
+        world = int(os.environ.get("WORLD_SIZE", args.gpus))
+        print(json.dumps({"dry_run": True, "metric": "images/sec at 720x600, 1000 proposals", "n_gpus": world,
+                          "config": {"height": args.height, "width": args.width, "proposals": args.proposals,
+                                     "parallelism": "image-sharded x%d" % world},
+                          **shard_table(world, args.steps, args.proposals, 15)}), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # called directly with --gpus N: start one rank per GPU the way the driver does
         import socket
@@ -419,12 +477,13 @@ def main():
         model.mfma_profile(reset=1)      # HIP events around every MFMA launch during the timed regions
 
     # ---- timed regions ----------------------------------------------------------------------------------------
-    elapsed_all, total_boxes = [], 0
+    elapsed_all, total_boxes, own_all = [], 0, []
     for rep in range(max(1, args.repeats)):
         barrier()
         sync()
         t0 = time.perf_counter()
         results = model.forward_batch_device(imgs, K, H, W)
+        own_all.append(time.perf_counter() - t0)          # this rank's own shard, before the gather and the closing barrier
         gathered = gather(results)
         sync()
         barrier()
@@ -459,6 +518,31 @@ def main():
     order = sorted(range(len(elapsed_all)), key=lambda i: elapsed_all[i])
     elapsed = elapsed_all[order[len(order) // 2]]          # median repeat
     nrep = len(elapsed_all)
+    # per-rank rate of the median region (each rank's own shard, gather and closing barrier excluded): a slow GPU / NUMA
+    # placement shows up here before it shows in the max-over-ranks time
+    own_rate = K / max(own_all[order[len(order) // 2]], 1e-9)
+    per_rank_rates = [own_rate]
+    if dist is not None:
+        tt = torch.tensor([own_rate], dtype=torch.float64, device=coll_device)
+        allr = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allr, tt)
+        per_rank_rates = [float(t.item()) for t in allr]
+
+    # ---- H2D-inclusive legs ("include H2D of the image"): the same K images in HOST memory, pageable and
+    # pinned, through dc_forward_batch(imgs_on_device = 0).  `value` keeps inputs resident in HBM (the tier's rule); these
+    # two figures say what the boundary delivers when it is handed host buffers.
+    host_legs = None
+    if on_gpu and dist is None and not args.no_host_input_leg:
+        host_legs = {}
+        pinned_t = torch.from_numpy(host[:K]).pin_memory()
+        for kind, arr in (("pageable", host[:K]), ("pinned", pinned_t.numpy())):
+            model.forward_batch(arr[:min(K, args.lanes)])
+            sync()
+            h0 = time.perf_counter()
+            model.forward_batch(arr)
+            sync()
+            host_legs[kind] = K / (time.perf_counter() - h0)
+        del pinned_t
 
     # ---- sustained leg: the same timed region back to back for >= --sustain-seconds, clocks and power sampled ---------
     # A 0.4 s region can ride boost clocks that a production loop never sees; this leg is what a long run delivers.
@@ -565,8 +649,16 @@ def main():
                                                                  args.dist_backend, "; " + gather_note if gather_note else ""))},
             "repeats": {"n": nrep, "statistic": "median", "images_per_s": [world * K / e for e in elapsed_all],
                         "timed_seconds_total": sum(elapsed_all)},
+            "per_rank_images_per_s": per_rank_rates,
             "sustained": sustained,
         }
+        out["config"]["shard_table"] = shard_table(world, K, P, model.seq_length) if dist is not None else None
+        if host_legs is not None:
+            out["value_host_inputs"] = {"pageable": host_legs["pageable"], "pinned": host_legs["pinned"], "unit": "images/s",
+                                        "vs_value": {k: v / burst for k, v in host_legs.items()},
+                                        "note": "one region of %d images handed over in host memory (dc_forward_batch, "
+                                                "imgs_on_device = 0): the 5.2 MB H2D copy of an image rides the lane's stream "
+                                                "ahead of its kernels; `value` is measured with inputs resident in HBM" % K}
         if not on_gpu:
             out["lanes"] = args.lanes
             out["config"]["gather_order_verified"] = gather_order_verified
@@ -583,6 +675,8 @@ def main():
                           "128x128: conv4_1; 64x64: RPN heads, LSTM gates of the image step)",
                 "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "algorithmic_bytes_per_launch": mfma_family_bytes(H, W, P, T, V)[0] / mfma_family_bytes(H, W, P, T, V)[1],
+                "algorithmic_bytes_per_image": mfma_family_bytes(H, W, P, T, V)[0],
                 "launches_per_image": prof["launches"] / float(max(nprof, 1)),
                 "algorithmic_gflop_per_image": mfma_flops_per_image / 1e9,
                 "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
@@ -629,6 +723,7 @@ def main():
                     # the committed counter passes ran THIS workload (same command, --lanes 1): average HBM bytes of one
                     # launch of the family, per launch like `achieved` (provenance in traffic_from_profile)
                     roof["traffic"] = roof["traffic_from_profile"]["hbm_bytes_per_launch"]
+                    roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
             except Exception:
                 roof["traffic_from_profile"] = None
             out["roofline"] = roof

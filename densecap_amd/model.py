@@ -89,6 +89,8 @@ class DenseCapModel:
         weights["test_args"] (optional; t7.weights_from_checkpoint fills it): the test-time state the checkpoint OBJECT
         carries -- localization_layer.test_clip_boxes / test_nms_thresh / test_max_proposals and opt.final_nms_thresh --
         which is what the model runs with until somebody calls setTestArgs."""
+        from .weights import check_weight_shapes
+        check_weight_shapes(weights)                  # before any pointer crosses the ABI: dc_load_weights trusts the shapes
         self.ctx = ctx or Context(device)
         self.lib = self.ctx.lib
         stored = dict(weights.get("test_args") or {})

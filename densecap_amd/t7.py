@@ -72,10 +72,31 @@ def _lua_list(t):
     return out
 
 
+class T7FormatError(ValueError):
+    """The bytes are not a well-formed Torch7 serialisation (or not one this reader understands): raised instead of
+    returning a half-parsed object."""
+
+
 class T7Reader:
+    """Torch7 `File.lua` binary reader.  Every structural field is checked against what `torch.save` can write
+    (docs/SEMANTICS.md, section `.t7`), so that a damaged or truncated file fails loudly:
+      * lengths (strings, closures, storages, table counts) are non-negative and fit the bytes that are left;
+      * a NEW object's index is the next one in sequence (File.lua numbers objects 1, 2, 3 ... in the order they are first
+        written), anything else must be a back-reference to an object already read;
+      * a tensor's view (size, stride, offset) lies inside its storage; at most MAX_DIMS dimensions; booleans are 0 / 1;
+      * `load` requires the top-level object to end exactly at the end of the file."""
+    MAX_DIMS = 16
+
     def __init__(self, f):
         self.f = f
         self.memo = {}
+        pos = f.tell()
+        f.seek(0, 2)
+        self.size = f.tell()
+        f.seek(pos)
+
+    def _left(self):
+        return self.size - self.f.tell()
 
     def _read(self, fmt):
         sz = struct.calcsize(fmt)
@@ -83,6 +104,11 @@ class T7Reader:
         if len(b) != sz:
             raise EOFError("truncated t7 file")
         return struct.unpack(fmt, b)
+
+    def _bytes(self, n, what):
+        if n < 0 or n > self._left():
+            raise T7FormatError("t7: %s of %d bytes at offset %d does not fit the file (%d bytes left)" % (what, n, self.f.tell(), self._left()))
+        return self.f.read(n)
 
     def read_int(self):
         return self._read("<i")[0]
@@ -95,7 +121,19 @@ class T7Reader:
 
     def read_string(self):
         n = self.read_int()
-        return self.f.read(n).decode("latin-1")
+        return self._bytes(n, "string").decode("latin-1")
+
+    def read_bool(self):
+        v = self.read_int()                                    # File.lua writes a boolean as the int 1 or 0
+        if v not in (0, 1):
+            raise T7FormatError("t7: boolean %d at offset %d" % (v, self.f.tell() - 4))
+        return v == 1
+
+    def _new_index(self, idx):
+        """File.lua gives the objects of one file the indices 1, 2, 3 ... in the order of their first appearance."""
+        if idx != len(self.memo) + 1:
+            raise T7FormatError("t7: object index %d at offset %d is neither a back-reference nor the next new index (%d)"
+                                % (idx, self.f.tell() - 4, len(self.memo) + 1))
 
     def read_object(self):
         t = self.read_int()
@@ -105,39 +143,60 @@ class T7Reader:
             v = self.read_double()
             return int(v) if v == int(v) and abs(v) < 2 ** 53 else v
         if t == TYPE_BOOLEAN:
-            return self.read_int() == 1
+            return self.read_bool()
         if t == TYPE_STRING:
             return self.read_string()
         if t == TYPE_TABLE:
             idx = self.read_int()
             if idx in self.memo:
                 return self.memo[idx]
+            self._new_index(idx)
             n = self.read_int()
+            if n < 0 or n > self._left() // 8:                # an entry is at least two 4-byte tags
+                raise T7FormatError("t7: table of %d entries at offset %d does not fit the file" % (n, self.f.tell() - 4))
             tab = {}
             self.memo[idx] = tab
             for _ in range(n):
                 k = self.read_object()
                 v = self.read_object()
-                tab[k] = v
+                try:
+                    tab[k] = v
+                except TypeError:
+                    raise T7FormatError("t7: unhashable table key of type %s" % type(k).__name__)
             return tab
         if t == TYPE_TORCH:
             idx = self.read_int()
             if idx in self.memo:
                 return self.memo[idx]
+            self._new_index(idx)
             version = self.read_string()
             if version.startswith("V "):
                 cls = self.read_string()
             else:
                 cls = version
             if cls in _TENSOR_DTYPES:
+                self.memo[idx] = None                          # the tensor's slot: its storage is numbered after it
                 nd = self.read_int()
+                if nd < 0 or nd > self.MAX_DIMS:
+                    raise T7FormatError("t7: tensor with %d dimensions at offset %d" % (nd, self.f.tell() - 4))
                 size = [self.read_long() for _ in range(nd)]
                 stride = [self.read_long() for _ in range(nd)]
                 offset = self.read_long() - 1
                 storage = self.read_object()
+                if storage is not None and not (isinstance(storage, np.ndarray) and storage.ndim == 1):
+                    raise T7FormatError("t7: a tensor's storage field holds a %s" % type(storage).__name__)
                 if storage is None or nd == 0:
                     arr = np.zeros((0,), _TENSOR_DTYPES[cls])
                 else:
+                    if storage.dtype != np.dtype(_TENSOR_DTYPES[cls]):
+                        raise T7FormatError("t7: %s over a %s storage" % (cls, storage.dtype))
+                    if min(size) < 0 or min(stride) < 0 or offset < 0:
+                        raise T7FormatError("t7: tensor view with a negative size / stride / offset")
+                    last = offset + sum((n - 1) * st for n, st in zip(size, stride)) if min(size) > 0 else offset - 1
+                    if last >= storage.size:
+                        raise T7FormatError("t7: tensor view (size %s, stride %s, offset %d) leaves its storage of %d elements"
+                                            % (size, stride, offset + 1, storage.size))
+                    stride = [st if n > 1 else 0 for n, st in zip(size, stride)]      # a length-1 axis never steps
                     arr = np.lib.stride_tricks.as_strided(
                         storage[offset:], shape=size, strides=[s * storage.itemsize for s in stride]).copy()
                 self.memo[idx] = arr
@@ -145,12 +204,16 @@ class T7Reader:
             if cls in _STORAGE_DTYPES:
                 n = self.read_long()
                 dt = np.dtype(_STORAGE_DTYPES[cls])
-                arr = np.frombuffer(self.f.read(n * dt.itemsize), dtype=dt).copy()
+                if n < 0 or n > self._left() // dt.itemsize:
+                    raise T7FormatError("t7: storage of %d elements at offset %d does not fit the file" % (n, self.f.tell() - 8))
+                arr = np.frombuffer(self._bytes(n * dt.itemsize, "storage"), dtype=dt).copy()
                 self.memo[idx] = arr
                 return arr
             obj = TorchObject(cls)
             self.memo[idx] = obj
             obj.fields = self.read_object()     # default torch class read(): one table of fields
+            if not isinstance(obj.fields, dict):
+                raise T7FormatError("t7: %s is followed by a %s, not by its field table" % (cls, type(obj.fields).__name__))
             return obj
         if t in (TYPE_FUNCTION, TYPE_RECUR_FUNCTION, TYPE_LEGACY_RECUR_FUNCTION):
             # File.lua: RECUR_FUNCTION (8) / LEGACY_RECUR_FUNCTION (7) are memoised objects: [index][int size][string.dump
@@ -162,21 +225,28 @@ class T7Reader:
                 idx = self.read_int()
                 if idx in self.memo:
                     return self.memo[idx]
+                self._new_index(idx)
             size = self.read_int()
-            code = self.f.read(size)
-            if len(code) != size:
-                raise EOFError("truncated t7 file (function body)")
+            self._bytes(size, "function body")
             fn = LuaFunction(size)
             if idx is not None:
                 self.memo[idx] = fn
             fn.upvalues = self.read_object()
+            if fn.upvalues is not None and not isinstance(fn.upvalues, dict):
+                raise T7FormatError("t7: a closure's upvalues are a %s, not a table" % type(fn.upvalues).__name__)
             return fn
-        raise ValueError("t7: unknown type tag %d" % t)
+        raise T7FormatError("t7: unknown type tag %d at offset %d" % (t, self.f.tell() - 4))
 
 
-def load(path):
+def load(path, strict=True):
+    """torch.load(path) for the binary format.  strict: the file must hold exactly one object (what torch.save writes);
+    bytes after it mean the structure was not what it claimed to be."""
     with open(path, "rb") as f:
-        return T7Reader(f).read_object()
+        r = T7Reader(f)
+        obj = r.read_object()
+        if strict and r._left() != 0:
+            raise T7FormatError("t7: %d bytes follow the top-level object" % r._left())
+        return obj
 
 
 # ---- minimal writer (tests / exporting synthetic checkpoints) ---------------------------------------

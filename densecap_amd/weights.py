@@ -84,3 +84,49 @@ def make_synthetic_image(H=600, W=720, seed=0):
     img = torch.rand(3, H, W, generator=g, dtype=torch.float32) * 255.0
     mean = torch.tensor(VGG_MEAN_BGR, dtype=torch.float32).view(3, 1, 1)
     return (img - mean).contiguous().numpy()
+
+
+def check_weight_shapes(W):
+    """dc_load_weights reads every tensor with the sizes the struct's dimension fields imply (include/densecap.h): the
+    host must not hand it an array that is shorter.  Raises ValueError naming the first tensor that does not fit the
+    architecture the others describe (DenseCapModel.lua:61-100, LocalizationLayer.lua:609-690, LanguageModel.lua:27-61).
+    Called by DenseCapModel before any pointer crosses the C ABI -- a checkpoint of another architecture, or one whose
+    tensor headers were damaged, ends here."""
+    def shape(key, a=None):
+        a = W[key] if a is None else a
+        return tuple(int(v) for v in (a.shape if hasattr(a, "shape") else np.asarray(a).shape))
+
+    def need(key, want, a=None):
+        got = shape(key, a)
+        if got != tuple(want):
+            raise ValueError("%s has shape %s, the architecture needs %s" % (key, got, tuple(want)))
+
+    if len(W["conv_w"]) != len(VGG16_CONVS) or len(W["conv_b"]) != len(VGG16_CONVS):
+        raise ValueError("conv_w / conv_b: expected the %d VGG-16 convolutions" % len(VGG16_CONVS))
+    for i, (cin, cout) in enumerate(VGG16_CONVS):
+        need("conv_w[%d]" % i, (cout, cin, 3, 3), W["conv_w"][i])
+        need("conv_b[%d]" % i, (cout,), W["conv_b"][i])
+    a = shape("anchors")
+    if len(a) != 2 or a[0] != 2 or a[1] < 1:
+        raise ValueError("anchors has shape %s, need (2, k)" % (a,))
+    k = a[1]
+    R = shape("rpn_conv_w")[0] if len(shape("rpn_conv_w")) == 4 else -1
+    need("rpn_conv_w", (R, 512, 3, 3)); need("rpn_conv_b", (R,))
+    need("rpn_box_w", (4 * k, R, 1, 1)); need("rpn_box_b", (4 * k,))
+    need("rpn_score_w", (2 * k, R, 1, 1)); need("rpn_score_b", (2 * k,))
+    D = shape("fc7_w")[0] if len(shape("fc7_w")) == 2 else -1
+    need("fc7_w", (D, D)); need("fc7_b", (D,))
+    need("fc6_w", (D, 512 * 7 * 7)); need("fc6_b", (D,))
+    need("obj_w", (1, D)); need("obj_b", (1,)); need("boxreg_w", (4, D)); need("boxreg_b", (4,))
+    E = shape("lm_enc_w")[0] if len(shape("lm_enc_w")) == 2 else -1
+    need("lm_enc_w", (E, D)); need("lm_enc_b", (E,))
+    V = int(W["vocab_size"])
+    need("lm_emb", (V + 2, E))
+    Hd4 = shape("lstm_w")[1] if len(shape("lstm_w")) == 2 else -1
+    if Hd4 <= 0 or Hd4 % 4:
+        raise ValueError("lstm_w has shape %s, need (E + Hd, 4*Hd)" % (shape("lstm_w"),))
+    Hd = Hd4 // 4
+    need("lstm_w", (E + Hd, 4 * Hd)); need("lstm_b", (4 * Hd,))
+    need("lm_out_w", (V + 1, Hd)); need("lm_out_b", (V + 1,))
+    if len(W["field_centers"]) != 4 or int(W["seq_length"]) < 1 or V < 1:
+        raise ValueError("field_centers / seq_length / vocab_size are not usable")

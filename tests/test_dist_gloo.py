@@ -149,6 +149,31 @@ def test_bench_world8_control_flow_under_gloo():
     assert d["lanes"] == 2            # rank 0's trial {2: 102, 3: 100, 4: 101}; rank 1 alone would pick 4 (StubModel.autotuneLanes)
     assert d["sustained"]["images"] % (8 * 5) == 0 and d["sustained"]["images_per_s"] > 0
     assert abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    # self-diagnosing first run on a real node: every rank's own rate and the exact shard / byte table are in the line
+    assert len(d["per_rank_images_per_s"]) == 8 and all(v > 0 for v in d["per_rank_images_per_s"])
+    st = d["config"]["shard_table"]
+    assert st["world"] == 8 and st["images_per_gpu"] == 5 and [x["global_images"] for x in st["shards"]][3] == [15, 20]
+    rb = 16 + 40 * (16 + 4 + 4 * 15)              # --proposals 40 in the stub runs
+    assert st["gather"]["record_bytes"] == rb and st["gather"]["block_bytes_per_rank"] == 5 * rb
+    assert [(p["peer"], p["offset"]) for p in st["gather"]["rank0_posts"]] == [(p, p * 5 * rb) for p in range(1, 8)]
+    assert st["gather"]["total_payload_bytes"] == 7 * 5 * rb and len(st["gather"]["peer_posts"]) == 7
+
+
+def test_bench_dry_run_prints_the_shard_table_without_ranks():
+    """`bench.py --gpus 8 --dry-run`: what the 8-GPU run of BASELINE configs[3] (512 images, 64 per GPU) will post, with no
+    GPU, no torch.distributed and no ranks -- so that a driver with an 8-GPU node can check its first run against it."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run"], capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["dry_run"] is True and d["world"] == 8 and d["total_images_per_region"] == 512
+    assert d["shards"][7] == {"rank": 7, "global_images": [448, 512]}
+    g = d["gather"]
+    assert g["record_bytes"] == 80016 and g["block_bytes_per_rank"] == 64 * 80016
+    assert g["handshake"]["messages"] == 14 and g["total_payload_bytes"] == 7 * 64 * 80016
+    assert all(p["op"] == "ncclSend" and p["peer"] == 0 and p["bytes"] == 64 * 80016 for p in g["peer_posts"])
 
 
 def test_bench_world8_carrier_failure_falls_back_on_every_rank():
