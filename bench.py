@@ -268,8 +268,12 @@ def main():
     ap.add_argument("--proposals", type=int, default=1000)
     ap.add_argument("--lanes", type=int, default=0,
                     help="streams images are pipelined over (1 = serial, 0 = pick 2/3/4 by an untimed trial before the timed region)")
-    ap.add_argument("--group", type=int, default=0,
-                    help="images per group inside a lane (dc_set_group): 0/1 = every image on its own (default), 2 = pairs share the dense launches")
+    ap.add_argument("--group", type=int, default=-1,
+                    help="images per group inside a lane (dc_set_group, a scheduling knob: results are bit-identical): 1 = every image "
+                         "on its own, 2..4 = the group's images share the dense launches, -1 (default) = pick 1 / 2 / 4 by an untimed trial")
+    ap.add_argument("--plan-mode", type=int, default=-1, choices=[-1, 0, 1],
+                    help="contraction planning: -1 follows --lanes (default), 0 = multi-lane planning even with --lanes 1 (profiler passes "
+                         "that must see the kernels of the timed multi-lane schedule on one stream), 1 = single-image planning")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-pass", action="store_true",
                     help="skip the secondary caption-order measurement (keeps rocprof kernel statistics to one workload)")
@@ -339,8 +343,10 @@ def main():
         model = DenseCapModel(weights, device=device_index)
         model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
         model.setLanes(args.lanes if args.lanes > 0 else 3)
-        model.setGroup(args.group)
+        model.setGroup(max(args.group, 0))
         ctx = model.ctx
+        if args.plan_mode >= 0:
+            check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"plan_mode", args.plan_mode), "dc_debug_set")
         # K distinct images per rank (global image id = rank*n_img + i), resident in HBM
         host = np.stack([make_synthetic_image(H, W, rank * n_img + i) for i in range(n_img)])
         dev = ctx.to_device(host)
@@ -449,6 +455,19 @@ def main():
             dist.broadcast(lt, src=0)
             args.lanes = int(lt.item())
             model.setLanes(args.lanes)
+    group_trials = None
+    if args.group < 0:
+        args.group = 1
+        if on_gpu and args.lanes != 1:
+            # the same kind of knob as the lane count: images per group inside a lane (bit-identical results)
+            group_trials = model.autotuneGroup(imgs, min(n_img, 16), H, W)
+            args.group = max(group_trials, key=group_trials.get)
+        if dist is not None:
+            gt = torch.tensor([args.group], dtype=torch.int32, device=coll_device)
+            dist.broadcast(gt, src=0)
+            args.group = int(gt.item())
+        if on_gpu:
+            model.setGroup(args.group)
     if on_gpu and args.lanes == 1:
         # per-launch events from the first image on: the whole invocation stays on ONE stream (single-image mode would run
         # the un-timed setup / warm-up images with the two-stream decode and leave their kernels in a rocprofv3 trace)
@@ -596,6 +615,7 @@ def main():
         # different images run concurrently.  Roofline pass: the same workload on ONE lane, HIP events around every
         # MFMA launch (on the stream it is launched on).  It describes the serial schedule, not the timed one.
         model.setLanes(1)
+        model.setGroup(1)
         nprof = min(K, 5)
         model.forward_batch_device(imgs, 1, H, W)
         sync()
@@ -616,6 +636,7 @@ def main():
         stage_live = model.stage_times()
         single_image_latency_ms = sorted(lat)[1]
         model.setLanes(args.lanes)
+        model.setGroup(args.group)
         serial_pass = True
 
     if rank == 0:
@@ -744,8 +765,11 @@ def main():
             out["hbm_stages"] = hb
             out["lanes"] = args.lanes
             out["host_enqueue_us_per_image"] = host_enqueue_us
+            out["group"] = args.group
             if lane_trials is not None:
                 out["lanes_trial_images_per_s"] = {str(k): v for k, v in lane_trials.items()}
+            if group_trials is not None:
+                out["group_trial_images_per_s"] = {str(k): v for k, v in group_trials.items()}
             if alt is not None:
                 out["value_captions_after_final_nms"] = alt   # same outputs, decode only final-NMS survivors
             out["stage_ms_serial_image"] = stage

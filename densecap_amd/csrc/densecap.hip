@@ -53,6 +53,7 @@ struct Lane {
   int32_t *tok = nullptr, *seq = nullptr;
   float *out_boxes = nullptr, *out_scores = nullptr, *out_feats = nullptr;
   float* splitk_ws = nullptr;   // split-K partial tiles (<= 256 tiles of 128x128)
+  int* tickets = nullptr;       // 2 x kTickets arrival counters of the in-kernel split-K finish (main stream | aux stream); own allocation, zeroed once
   int32_t* out_tokens = nullptr;
   // pinned host staging
   void* host_stage = nullptr;
@@ -95,6 +96,8 @@ struct dc_ctx {
   uint32_t* fault_dev = nullptr;   // sticky device word: a stream-K owner gave up waiting for its partner (checked with the results)
   int force_cfg = 0;         // measurement hook: tile configuration of plain launches (dc_debug_set "force_cfg")
   int stagger = 0;           // measurement hook: start-up stagger of a launch's workgroups (dc_debug_set "stagger")
+  bool splitk_fused = true;  // split-K finished inside the launch by the last workgroup of a tile (dc_debug_set "splitk_fused" 0 = reduce launch)
+  int plan_mode = -1;        // measurement hook "plan_mode": -1 = planning follows the lane count, 0 = multi-lane planning, 1 = single-image planning
   int v2_stages = 0;         // LDS ring depth of the 128x64-tile kernel (dc_debug_set "v2_stages": 0 by tile count, 2 or 3 forced)
   int tail_mode = 0;         // partial last round in single-image mode: 0 stream-K, 1 K-split tail plan, 2 whole tiles (dc_debug_set)
   bool serial_mode = false;  // lanes == 1: idle CUs in a layer's last round are worth a tail split-K (dc_set_lanes)
@@ -179,7 +182,18 @@ hipEvent_t prof_event(dc_ctx* ctx) {
 // every MFMA contraction goes through here (optionally bracketed by HIP events).  `ws` (optional) is a
 // scratch buffer of ws_floats floats on the same stream: problems with few tiles and a long K are split
 // along K over several workgroups per tile and finished by a small reduce kernel.
-int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, float* ws = nullptr, size_t ws_floats = 0) {
+// Scratch of one stream's contractions: partial tiles (split-K, tail plans, stream-K slots) and the per-tile arrival
+// counters of the in-kernel split-K finish (kTickets ints, zero when idle: the last arriver of a tile resets its counter).
+struct Ws {
+  float* p = nullptr;
+  size_t floats = 0;
+  int* tickets = nullptr;
+};
+constexpr int kTickets = 1024;          // >= tiles of any split launch (split-K and tail plans cover < one round of CUs)
+
+int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, const Ws& w = Ws()) {
+  float* const ws = w.p;
+  const size_t ws_floats = w.floats;
   GemmDesc d = d_in;
   d.stages = ctx->v2_stages;
   d.force_cfg = ctx->force_cfg;
@@ -191,13 +205,17 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, float* ws = nullp
   }
   hipError_t e = hipSuccess;
   GemmPlan pl;                                                // mfma_gemm_plan decides; this function only acts on it
-  mfma_gemm_plan(d, ctx->serial_mode, ctx->tail_mode, ws != nullptr ? ws_floats : 0, &pl);
+  const bool serial_plan = ctx->plan_mode < 0 ? ctx->serial_mode : ctx->plan_mode == 1;
+  mfma_gemm_plan(d, serial_plan, ctx->tail_mode, ws != nullptr ? ws_floats : 0, &pl);
   const int m_split = pl.m_split;
   if (pl.kind == GEMM_PLAN_SPLITK) {
     // few tiles, long K: every tile is shared by `splitk` workgroups
-    d.splitk = pl.splitk; d.splitk_ws = ws;
+    // the split factor is planned on ONE image (plan_M): a group's launch may carry more tiles than counters -> reduce launch
+    const bool fused = w.tickets != nullptr && ctx->splitk_fused &&
+                       (long)((d.M + 127) / 128) * ((d.N + 127) / 128) <= kTickets;
+    d.splitk = pl.splitk; d.splitk_ws = ws; d.splitk_tickets = fused ? w.tickets : nullptr;
     e = launch_mfma_gemm(d, s);
-    if (e == hipSuccess)
+    if (e == hipSuccess && !fused)
       e = d.pool ? launch_splitk_reduce_pool(ws, pl.splitk, d.bias, d.C, 0, d.M, d.N, d.ldc, d.H, d.Wd, d.relu, s)
                  : launch_splitk_reduce(ws, pl.splitk, d.bias, d.C, d.M, d.N, d.ldc, d.relu, s);
   } else if (pl.kind == GEMM_PLAN_STREAMK) {
@@ -228,9 +246,10 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, float* ws = nullp
     }
     if (e == hipSuccess) {
       GemmDesc b = d;
-      b.m_begin = m_split; b.a_rows = d.M; b.splitk = tail_sp; b.splitk_ws = ws;
+      const bool fused = w.tickets != nullptr && ctx->splitk_fused;     // (a tail covers less than one round of tiles)
+      b.m_begin = m_split; b.a_rows = d.M; b.splitk = tail_sp; b.splitk_ws = ws; b.splitk_tickets = fused ? w.tickets : nullptr;
       e = launch_mfma_gemm_ks(b, s);
-      if (e == hipSuccess)
+      if (e == hipSuccess && !fused)
         e = d.pool ? launch_splitk_reduce_pool(ws, tail_sp, d.bias, d.C, m_split, d.M - m_split, d.N, d.ldc, d.H, d.Wd, d.relu, s)
                    : launch_splitk_reduce(ws, tail_sp, d.bias, d.C + (size_t)m_split * d.ldc, d.M - m_split, d.N, d.ldc, d.relu, s);
     }
@@ -261,36 +280,38 @@ void prof_collect(dc_ctx* ctx) {
 }
 
 int linear(dc_ctx* ctx, hipStream_t s, const float* A, const float* W, const float* bias, float* C, int M, int N,
-           int K, int relu, float* ws = nullptr, size_t ws_floats = 0, int plan_M = 0) {
+           int K, int relu, const Ws& ws = Ws(), int plan_M = 0) {
   GemmDesc d;
   d.A = A; d.W = W; d.bias = bias; d.C = C; d.M = M; d.N = N; d.K = K; d.ldc = N; d.relu = relu; d.plan_M = plan_M;
-  return run_gemm(ctx, d, s, ws, ws_floats);
+  return run_gemm(ctx, d, s, ws);
 }
 int conv3x3(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, const float* b, float* out, int nimg, int H,
-            int W, int Cin, int Cout, int relu, float* ws = nullptr, size_t ws_floats = 0) {
+            int W, int Cin, int Cout, int relu, const Ws& ws = Ws()) {
   GemmDesc d;
   d.A = in; d.W = w; d.bias = b; d.C = out; d.M = nimg * H * W; d.N = Cout; d.K = 9 * Cin; d.ldc = Cout;
   d.relu = relu; d.conv = 1; d.H = H; d.Wd = W; d.Cin = Cin; d.plan_M = H * W;
-  return run_gemm(ctx, d, s, ws, ws_floats);
+  return run_gemm(ctx, d, s, ws);
 }
 // conv3x3 + ReLU + nn.SpatialMaxPooling(2,2,2,2):ceil() (VGG layers conv1_2, conv2_2, conv3_3, conv4_3,
 // DenseCapModel.lua:61-76): the pool rides in the conv's epilogue -- the full-resolution activation never reaches HBM
 // (conv1_2: 110 MB store -> 28 MB) and four launches disappear.  out: (ceil(H/2), ceil(W/2), Cout).
 int conv3x3_pool(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, const float* b, float* out, int nimg, int H,
-                 int W, int Cin, int Cout, int relu, float* ws, size_t ws_floats) {
+                 int W, int Cin, int Cout, int relu, const Ws& ws) {
   GemmDesc d;
   const int slots = 4 * ((H + 1) / 2) * ((W + 1) / 2);          // window slots of one image
   d.A = in; d.W = w; d.bias = b; d.C = out; d.M = nimg * slots; d.N = Cout; d.K = 9 * Cin; d.plan_M = slots;
   d.ldc = Cout; d.relu = relu; d.conv = 1; d.H = H; d.Wd = W; d.Cin = Cin; d.pool = 1;
   if (!mfma_gemm_can_pool(d))
     return ctx->fail(DC_E_UNSUPPORTED, "conv3x3_pool: %dx%dx%d activation exceeds the kernels' 32-bit operand offsets", H, W, Cin);
-  return run_gemm(ctx, d, s, ws, ws_floats);
+  return run_gemm(ctx, d, s, ws);
 }
 
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 // num_proposals = -1 (LocalizationLayer.lua:322-324: uncapped RPN NMS): capacity = every anchor of this image size
 int effective_proposals(const dc_ctx* ctx, int H, int W);
 constexpr size_t kSplitkWsFloats = (size_t)3200 * 128 * 128;  // 200 MiB per lane: split-K partial outputs (up to 8 x a four-image group's 4 x 384 x 4096 fc6 rows), tail plans, stream-K slots
+
+Ws lane_ws(const Lane& L) { return Ws{L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0, L.tickets}; }
 
 int effective_proposals(const dc_ctx* ctx, int H, int W) {
   if (ctx->num_proposals != -1) return ctx->num_proposals;
@@ -316,6 +337,10 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P, int G) {
     for (auto& e : L.ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
+  }
+  if (L.tickets == nullptr) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&L.tickets), 2 * kTickets * sizeof(int)));
+    HIPCHK(hipMemset(L.tickets, 0, 2 * kTickets * sizeof(int)));
   }
   if (L.H == H && L.W == W && L.P == P && L.G == G && L.arena.p) return DC_OK;
   int fh = H, fw = W;
@@ -394,7 +419,7 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P, int G) {
 // One contiguous block of decode rows and the stream it runs on.  LSTM rows are independent, so a batch may be cut
 // into blocks that advance on different streams: every row sees exactly the same arithmetic (the K order of a GEMM
 // element does not depend on the tile it falls in), only the kernels of the blocks overlap in time.
-struct LmPart { hipStream_t s; int r0, n; float* ws; size_t ws_floats; };
+struct LmPart { hipStream_t s; int r0, n; Ws ws; };
 
 // LanguageModel:sample greedy decode (LanguageModel.lua:293-348) for the rows of `codes` covered by `parts`
 // (n_dev: optional device-side row count <= n of a single part starting at row 0; rows past it are not computed).
@@ -425,7 +450,7 @@ int lm_sample_parts(dc_ctx* ctx, Lane& L, const float* codes, const LmPart* part
       GemmDesc g;
       g.A = codes + (size_t)p.r0 * D; g.W = ctx->enc_w; g.bias = ctx->enc_b; g.C = L.enc + (size_t)p.r0 * E;
       g.M = p.n; g.N = E; g.K = D; g.ldc = E; g.relu = 1; g.m_dev = n_dev; g.plan_M = plan;
-      DCCHK(run_gemm(ctx, g, s, p.ws, p.ws ? p.ws_floats : 0));
+      DCCHK(run_gemm(ctx, g, s, p.ws));
     }
     {  // step 0: gates = (b + enc.Wx) + 0.Wh ; c0 = 0 (output ignored, no vocab projection needed)
       GemmDesc g;
@@ -471,12 +496,12 @@ int lm_sample_parts(dc_ctx* ctx, Lane& L, const float* codes, const LmPart* part
 
 // `plan`: rows of one image when n covers a group (0 = n); see GemmDesc::plan_M
 int lm_sample(dc_ctx* ctx, Lane& L, const float* codes, int n, int plan, const int32_t* n_dev, int32_t* seq_out) {
-  const LmPart whole{L.stream, 0, n, L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0};
+  const LmPart whole{L.stream, 0, n, lane_ws(L)};
   return lm_sample_parts(ctx, L, codes, &whole, 1, n_dev, seq_out, plan);
 }
 // decode rows [r0, r0+n) of the lane's buffers (codes / seq_out are the BASE pointers); n_dev: device row count
 int lm_sample_rows(dc_ctx* ctx, Lane& L, const float* codes, int r0, int n, const int32_t* n_dev, int32_t* seq_out) {
-  const LmPart part{L.stream, r0, n, L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0};
+  const LmPart part{L.stream, r0, n, lane_ws(L)};
   return lm_sample_parts(ctx, L, codes, &part, 1, n_dev, seq_out, 0);
 }
 
@@ -570,9 +595,9 @@ int lm_beamsearch(dc_ctx* ctx, Lane& L, const float* codes, int n, int32_t* seq_
 int lm_sample_two_streams(dc_ctx* ctx, Lane& L, const float* codes, int n, int plan, int32_t* seq_out) {
   const int h = std::min(n, ((n / 2 + 127) / 128) * 128);
   if (h >= n || L.aux == nullptr) return lm_sample(ctx, L, codes, n, plan, nullptr, seq_out);
-  const size_t wsf = L.splitk_ws ? kSplitkWsFloats / 2 : 0;
-  const LmPart parts[2] = {{L.stream, 0, h, L.splitk_ws, wsf},
-                           {L.aux, h, n - h, L.splitk_ws ? L.splitk_ws + wsf : nullptr, wsf}};
+  const size_t wsf = L.splitk_ws ? kSplitkWsFloats / 2 : 0;     // each block its own half of the partial-tile scratch and its own counters
+  const LmPart parts[2] = {{L.stream, 0, h, Ws{L.splitk_ws, wsf, L.tickets}},
+                           {L.aux, h, n - h, Ws{L.splitk_ws ? L.splitk_ws + wsf : nullptr, wsf, L.tickets ? L.tickets + kTickets : nullptr}}};
   HIPCHK(hipEventRecord(L.ev_fork, L.stream));
   HIPCHK(hipStreamWaitEvent(L.aux, L.ev_fork, 0));
   DCCHK(lm_sample_parts(ctx, L, codes, parts, 2, nullptr, seq_out, plan));
@@ -602,11 +627,11 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
     if (kVgg[i].pool_after) {
       // conv + ReLU + ceil-mode 2x2 pool in one launch
       DCCHK(conv3x3_pool(ctx, s, L.act[cur], ctx->conv_w[i], ctx->conv_b[i], L.act[cur ^ 1], g, h, w, kVgg[i].cin,
-                         kVgg[i].cout, 1, L.splitk_ws, kSplitkWsFloats));
+                         kVgg[i].cout, 1, lane_ws(L)));
       h = (h + 1) / 2; w = (w + 1) / 2;
     } else {
       DCCHK(conv3x3(ctx, s, L.act[cur], ctx->conv_w[i], ctx->conv_b[i], L.act[cur ^ 1], g, h, w, kVgg[i].cin,
-                    kVgg[i].cout, 1, L.splitk_ws, kSplitkWsFloats));
+                    kVgg[i].cout, 1, lane_ws(L)));
     }
     cur ^= 1;
   }
@@ -614,10 +639,8 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
   const size_t feat_elems = (size_t)h * w * 512;
   HIPCHK(hipEventRecord(L.ev[1], s));
   // ---- RPN (LocalizationLayer.lua:265, build_rpn :609-690) ----------------------------------
-  DCCHK(conv3x3(ctx, s, L.feat, ctx->rpn_w, ctx->rpn_b, L.rpn_hidden, g, h, w, 512, ctx->R, 1, L.splitk_ws,
-                kSplitkWsFloats));
-  DCCHK(linear(ctx, s, L.rpn_hidden, ctx->heads_w, ctx->heads_b, L.heads, g * h * w, 6 * ctx->k, ctx->R, 0, nullptr, 0,
-               h * w));
+  DCCHK(conv3x3(ctx, s, L.feat, ctx->rpn_w, ctx->rpn_b, L.rpn_hidden, g, h, w, 512, ctx->R, 1, lane_ws(L)));
+  DCCHK(linear(ctx, s, L.rpn_hidden, ctx->heads_w, ctx->heads_b, L.heads, g * h * w, 6 * ctx->k, ctx->R, 0, Ws(), h * w));
   for (int i = 0; i < g; ++i)
     KCHK(launch_rpn_decode(L.heads + (size_t)i * h * w * 6 * ctx->k, h, w, ctx->k, ctx->anchors, ctx->fc[0], ctx->fc[1],
                            ctx->fc[2], ctx->fc[3], H, W, L.rpn_boxes + (size_t)i * L.A * 4, nullptr, nullptr,
@@ -639,9 +662,8 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
   HIPCHK(hipEventRecord(L.ev[4], s));
   // ---- recog_base fc6/fc7 (DenseCapModel.lua:133) ------------------------------------------------
   const int R = g * P;                      // RoI rows of the group
-  DCCHK(linear(ctx, s, L.roi_feats, ctx->fc6_w, ctx->fc6_b, L.fc6_out, R, ctx->D, 49 * 512, 1, L.splitk_ws,
-               kSplitkWsFloats, P));
-  DCCHK(linear(ctx, s, L.fc6_out, ctx->fc7_w, ctx->fc7_b, L.codes, R, ctx->D, ctx->D, 1, L.splitk_ws, kSplitkWsFloats, P));
+  DCCHK(linear(ctx, s, L.roi_feats, ctx->fc6_w, ctx->fc6_b, L.fc6_out, R, ctx->D, 49 * 512, 1, lane_ws(L), P));
+  DCCHK(linear(ctx, s, L.fc6_out, ctx->fc7_w, ctx->fc7_b, L.codes, R, ctx->D, ctx->D, 1, lane_ws(L), P));
   HIPCHK(hipEventRecord(L.ev[5], s));
   // ---- objectness / box regression / final boxes (DenseCapModel.lua:134,139-140) -----------------
   KCHK(launch_recog_heads(L.codes, ctx->head5_w, ctx->head5_b, L.roi_boxes, L.obj, L.final_trans, L.final_boxes, R,
@@ -778,6 +800,10 @@ int lane0_stream(dc_ctx* ctx, hipStream_t* s) {
     HIPCHK(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
   }
+  if (L.tickets == nullptr) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&L.tickets), 2 * kTickets * sizeof(int)));
+    HIPCHK(hipMemset(L.tickets, 0, 2 * kTickets * sizeof(int)));
+  }
   *s = L.stream;
   return DC_OK;
 }
@@ -818,6 +844,7 @@ void dc_destroy(dc_ctx* ctx) {
     Lane& L = *lp;
     if (L.arena.p) hipFree(L.arena.p);
     if (L.beam_base) hipFree(L.beam_base);
+    if (L.tickets) hipFree(L.tickets);
     if (L.host_stage) hipHostFree(L.host_stage);
     for (auto& ev : L.ev) if (ev) hipEventDestroy(ev);
     if (L.ev_fork) hipEventDestroy(L.ev_fork);
@@ -1259,6 +1286,16 @@ int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value) {
     ctx->force_cfg = (int)value;
     return DC_OK;
   }
+  if (strcmp(name, "splitk_fused") == 0) {
+    if (value != 0 && value != 1) return ctx->fail(DC_E_INVALID, "dc_debug_set: splitk_fused must be 0 or 1");
+    ctx->splitk_fused = value != 0;
+    return DC_OK;
+  }
+  if (strcmp(name, "plan_mode") == 0) {
+    if (value < -1 || value > 1) return ctx->fail(DC_E_INVALID, "dc_debug_set: plan_mode must be -1, 0 or 1");
+    ctx->plan_mode = (int)value;
+    return DC_OK;
+  }
   if (strcmp(name, "stagger") == 0) {
     if (value < 0 || value > 4096) return ctx->fail(DC_E_INVALID, "dc_debug_set: stagger must be 0..4096 (64-cycle sleeps)");
     ctx->stagger = (int)value;
@@ -1340,7 +1377,7 @@ int dc_op_conv3x3(dc_ctx* ctx, const float* in, const float* w, const float* b, 
     return ctx->fail(DC_E_INVALID, "dc_op_conv3x3: need Cin %% 32 == 0 and positive sizes");
   float* ws = nullptr;
   HIPCHK(hipMalloc((void**)&ws, kSplitkWsFloats * 4));
-  int rc = conv3x3(ctx, s, in, w, b, out, n_img, H, W, Cin, Cout, relu, ws, kSplitkWsFloats);
+  int rc = conv3x3(ctx, s, in, w, b, out, n_img, H, W, Cin, Cout, relu, Ws{ws, kSplitkWsFloats, lane0(ctx).tickets});
   hipError_t e2 = hipStreamSynchronize(s);
   (void)hipFree(ws);
   prof_collect(ctx);
@@ -1355,7 +1392,7 @@ int dc_op_conv3x3_relu_pool(dc_ctx* ctx, const float* in, const float* w, const 
     return ctx->fail(DC_E_INVALID, "dc_op_conv3x3_relu_pool: need Cin %% 32 == 0, Cout %% 4 == 0 and positive sizes");
   float* ws = nullptr;
   HIPCHK(hipMalloc((void**)&ws, kSplitkWsFloats * 4));
-  int rc = conv3x3_pool(ctx, s, in, w, b, out, 1, H, W, Cin, Cout, 1, ws, kSplitkWsFloats);
+  int rc = conv3x3_pool(ctx, s, in, w, b, out, 1, H, W, Cin, Cout, 1, Ws{ws, kSplitkWsFloats, lane0(ctx).tickets});
   hipError_t e2 = hipStreamSynchronize(s);
   (void)hipFree(ws);
   prof_collect(ctx);
@@ -1379,7 +1416,7 @@ int dc_op_linear(dc_ctx* ctx, const float* A, const float* W, const float* bias,
   if (K % 32 || M <= 0 || N <= 0) return ctx->fail(DC_E_INVALID, "dc_op_linear: need K %% 32 == 0");
   float* ws = nullptr;
   HIPCHK(hipMalloc((void**)&ws, kSplitkWsFloats * 4));
-  int rc = linear(ctx, s, A, W, bias, C, M, N, K, relu, ws, kSplitkWsFloats);
+  int rc = linear(ctx, s, A, W, bias, C, M, N, K, relu, Ws{ws, kSplitkWsFloats, lane0(ctx).tickets});
   hipError_t e2 = hipStreamSynchronize(s);
   (void)hipFree(ws);
   prof_collect(ctx);

@@ -194,6 +194,9 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
   auto issue_piece = [&](int kt, int st, int p) {
     float* sa = smem + st * STAGE + (8 * wid) * BK;       // this wave's 8-row slice of pass 0
     float* sb = sa + BM * BK;
+#ifdef ABL_NO_DMA
+    if (kt >= 2) return;                                   // timing-only ablation build: operands of later K-tiles never arrive
+#endif
     if (p < PA) {
       if constexpr (CONV) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, sa + p * 32 * BK, 16, (int)cv_vo[p], cv_soff, 0, 0);
@@ -220,7 +223,13 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
   const int b_base = BM * BK + (wn * 32 * TN) * BK;
 
   f32x4 fa[2][TM], fb[2][TN];
+#ifdef ABL_NO_READS
+  bool abl_reads_on = true;
+#endif
   auto read_piece = [&](int st, int g, int set, int p) {   // p in [0,TM): A fragment, [TM,TM+TN): B fragment
+#ifdef ABL_NO_READS
+    if (!abl_reads_on) return;                             // timing-only ablation build: fragments are read once, then reused
+#endif
     const float* base = smem + st * STAGE + foff[g];
     if (p < TM) fa[set][p] = *reinterpret_cast<const f32x4*>(base + a_base + p * 32 * BK);
     else fb[set][p - TM] = *reinterpret_cast<const f32x4*>(base + b_base + (p - TM) * 32 * BK);
@@ -239,8 +248,14 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
   constexpr int NM = 4 * TM * TN;        // MFMAs per group
   auto mfma_slot = [&](int set, int q) {
     const int e = q / (TM * TN), rem = q % (TM * TN), i = rem / TN, j = rem % TN;
+#ifdef V2_AGPR_ACC
+    // experiment: accumulators pinned to the AGPR half of the register file (the K-split kernel's are there by pressure)
+    if constexpr (AMAX) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[set][j][e]), "v"(fa[set][i][e]));
+    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[set][i][e]), "v"(fb[set][j][e]));
+#else
     if constexpr (AMAX) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[set][j][e], fa[set][i][e], acc[i][j], 0, 0, 0);
     else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
+#endif
   };
   // one MFMA group with `nside` side operations spread evenly between its MFMAs (pinned order)
   auto group_with = [&](int set, int nside, auto&& side) {
@@ -265,6 +280,10 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   read_frag(0, 0, 0);
+#ifdef ABL_NO_READS
+  read_frag(0, 1, 1);
+  abl_reads_on = false;
+#endif
 
   // One K-tile whose ring stage ST is a compile-time constant: every LDS address of its fragment reads and LDS-DMA
   // destinations is an immediate (the ring walk costs no address arithmetic between the MFMAs).
@@ -280,8 +299,12 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
       group_with(1, TM + TN, [&](int k) { read_piece(st, 2, 0, k); });
       group_with(0, TM + TN, [&](int k) { read_piece(st, 3, 1, k); });
       __builtin_amdgcn_sched_barrier(0);
+#ifndef ABL_NO_WAITCNT
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifndef ABL_NO_BARRIER
       __builtin_amdgcn_s_barrier();
+#endif
       __builtin_amdgcn_sched_barrier(0);
       const bool more2 = kt + 2 < nkt, next2 = kt + 1 < nkt;
       if (more2) issue_begin();
@@ -295,8 +318,12 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
     group_with(1, TM + TN, [&](int k) { read_piece(st, 2, 0, k); });
     // ---- mid-tile rendezvous: tile kt+1 has landed everywhere; the stage of tile kt-1 is free
     __builtin_amdgcn_sched_barrier(0);
+#ifndef ABL_NO_WAITCNT
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * (PA + PB)) : "memory");
+#endif
+#ifndef ABL_NO_BARRIER
     __builtin_amdgcn_s_barrier();
+#endif
     __builtin_amdgcn_sched_barrier(0);
     const bool more = kt + NS - 1 < nkt;
     if (more) issue_begin();
@@ -549,7 +576,7 @@ constexpr unsigned SK_SPIN_LIMIT = 1u << 22;       // bounded: a partner that ne
 template <bool CONV, bool HALF = false>
 __device__ __forceinline__ void ks_segment(const GemmDesc& d, const int m0, const int n0, const int Meff, const int slice,
                                            const int kt0, const int nkt, const int mode, const int sk_wg,
-                                           const int sk_npartner, float* const smem) {
+                                           const int sk_npartner, float* const smem, const int tile_id = 0) {
   constexpr int BM = 128, BN = 128;
   constexpr int PA = BM / 32, PB = BN / 32;
   constexpr int NI = HALF ? 2 : 4;         // live 32-row blocks of A
@@ -829,6 +856,81 @@ __device__ __forceinline__ void ks_segment(const GemmDesc& d, const int m0, cons
     __syncthreads();
     if (tid == 0) __hip_atomic_store(d.sk_flags + sk_wg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (mode == KS_NORMAL && d.splitk > 1 && d.splitk_tickets != nullptr) {
+    // ---- split-K finish by the LAST workgroup to arrive at this tile (no reduce launch) ------------------------------
+    // producer side: every thread's partial stores are ordered before the barrier; thread 0's agent-scope release then
+    // publishes them with the ticket (the per-XCD L2s are not coherent: the release writes the dirty lines back);
+    // consumer side: the last arriver's acquire (one lane), a barrier, then plain loads of all `splitk` partial tiles.
+    int* const s_last = reinterpret_cast<int*>(smem);      // (the ring / reduction slots are free: the loop above ended on a barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const int old = __hip_atomic_fetch_add(d.splitk_tickets + tile_id, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == d.splitk - 1;
+      if (last) __hip_atomic_store(d.splitk_tickets + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      *s_last = last;
+    }
+    __syncthreads();
+    if (*s_last == 0) return;
+    const int Mw = d.M - d.m_begin;                          // rows of the partial-output window
+    const float* const ws = d.splitk_ws;
+    const int c4 = tid & 31;                                 // this thread's 4 columns of the tile
+    const int n = n0 + c4 * 4;
+    if (n >= d.N) return;                                    // (N % 4 == 0 wherever split-K is planned)
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (d.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(d.bias + n);
+    if (CONV && d.pool) {
+      // four consecutive rows of the window-ordered M axis are one pool window (splitk_reduce_pool_kernel, verbatim)
+      const int Wo = (d.Wd + 1) >> 1, per = ((d.H + 1) >> 1) * Wo;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int wl = (tid >> 5) + 8 * it;                  // window of the tile, 0..31
+        const int mrow = m0 + 4 * wl;
+        if (mrow >= Meff) continue;
+        const int win = mrow >> 2, wi = win % per, wy = wi / Wo, wx = wi - wy * Wo;
+        f32x4 best = {0.f, 0.f, 0.f, 0.f};
+        bool have = false;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (2 * wy + (c >> 1) >= d.H || 2 * wx + (c & 1) >= d.Wd) continue;
+          const size_t m = (size_t)(mrow - d.m_begin) + c;
+          f32x4 acc = *reinterpret_cast<const f32x4*>(ws + m * d.N + n);
+          for (int sl = 1; sl < d.splitk; ++sl) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ws + ((size_t)sl * Mw + m) * d.N + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = acc[e] + v[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = acc[e] + bv[e];
+            if (d.relu) t = t > 0.f ? t : 0.f;
+            best[e] = (!have || t > best[e]) ? t : best[e];
+          }
+          have = true;
+        }
+        *reinterpret_cast<f32x4*>(d.C + (size_t)win * d.ldc + n) = best;
+      }
+      return;
+    }
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int mrow = m0 + (tid >> 5) + 8 * it;
+      if (mrow >= Meff) continue;
+      const size_t m = (size_t)(mrow - d.m_begin);
+      f32x4 acc = *reinterpret_cast<const f32x4*>(ws + m * d.N + n);
+      for (int sl = 1; sl < d.splitk; ++sl) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ws + ((size_t)sl * Mw + m) * d.N + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = acc[e] + v[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[e] = acc[e] + bv[e];
+        if (d.relu) acc[e] = acc[e] > 0.f ? acc[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(d.C + (size_t)mrow * d.ldc + n) = acc;
+    }
+  }
 }
 
 template <bool CONV>
@@ -849,13 +951,14 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
     if (m0 >= Meff) return;
   }
   const int nkt = d.K / BK / d.splitk;               // this workgroup's K range (the whole K unless split-K)
+  const int tile_id = tile_m * ntn + tile_n;          // split-K arrival counter of this tile (GemmDesc::splitk_tickets)
   if constexpr (!CONV) {
     if (Meff - m0 <= 64) {                             // a <= 64-row tile (50-proposal batch, last tile of 300 rows)
-      ks_segment<false, true>(d, m0, n0, Meff, slice, slice * nkt, nkt, KS_NORMAL, 0, 0, smem);
+      ks_segment<false, true>(d, m0, n0, Meff, slice, slice * nkt, nkt, KS_NORMAL, 0, 0, smem, tile_id);
       return;
     }
   }
-  ks_segment<CONV>(d, m0, n0, Meff, slice, slice * nkt, nkt, KS_NORMAL, 0, 0, smem);
+  ks_segment<CONV>(d, m0, n0, Meff, slice, slice * nkt, nkt, KS_NORMAL, 0, 0, smem, tile_id);
 }
 
 // =========================================================================================

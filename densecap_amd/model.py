@@ -182,6 +182,25 @@ class DenseCapModel:
         self.setLanes(max(rates, key=rates.get))
         return rates
 
+    def autotuneGroup(self, dev_ptr, n, H, W, candidates=(1, 2, 4), reps=2):
+        """Pick the images-per-group setting (dc_set_group: a scheduling knob like the lane count -- results are
+        bit-identical) at the current lane count.  With few proposals per image the RoI stages of one image leave the
+        chip's tile rounds badly filled and a group of four shares them (300 proposals: +9 % images/s at two lanes); at
+        1000 proposals groups change nothing.  Returns {group: images/s}; the best one is left set."""
+        import time
+        rates = {}
+        for g in candidates:
+            self.setGroup(g)
+            self.forward_batch_device(dev_ptr, min(n, 2 * g), H, W)
+            best = 0.0
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                self.forward_batch_device(dev_ptr, n, H, W)
+                best = max(best, n / (time.perf_counter() - t0))
+            rates[g] = best
+        self.setGroup(max(rates, key=rates.get))
+        return rates
+
     def setCaptionOrder(self, after_final_nms):
         """False (default): decode all proposals then NMS, as the reference does.  True: final NMS first,
         decode only the survivors (bit-identical outputs, less LSTM work)."""
@@ -190,8 +209,9 @@ class DenseCapModel:
         return self
 
     def setGroup(self, images):
-        """Images per group inside a batch call: 0/1 = every image on its own (default), 2 = pairs share the launches of
-        the dense stages (bit-identical results; +4.5 % images/s on one lane, nothing with two or more lanes)."""
+        """Images per group inside a batch call: 0/1 = every image on its own (default), 2..4 = the images of a group share
+        the launches of the dense stages (bit-identical results; 1000 proposals: +4.5 % images/s on one lane, nothing with
+        two or more lanes; 300 proposals: +9 % at two lanes with groups of four)."""
         check(self.ctx.h, self.lib.dc_set_group(self.ctx.h, int(images)), "dc_set_group")
         return self
 

@@ -38,8 +38,16 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
  *                        was measured fastest for that shape class (default), 1 = never stream-K, 2 = whole tiles only.
  *                        The routes differ in the fp32 summation order of the affected rows (each one deterministic).
  *   "force_cfg"          measurement hook for tools/route_sweep.py: 0 = planned (default), 1 / 2 / 3 = plain launches use
- *                        128x128 / 128x64 / 64x64 tiles and no split-K, 4 = planned tiles, no split-K.  Changes the fp32
+ *                        128x128 / 128x64 / 64x64 tiles and no split-K, 4 = planned tiles, no split-K, 5 = 128x128 tiles on the 2x2-wave kernel
+ *                        with a two-stage ring (two workgroups per CU), 6 = the K-split 128x128 kernel whatever K.  Changes the fp32
  *                        summation order with the kernel family; never set by the product path.
+ *   "splitk_fused"       1 (default) = a split-K launch is finished INSIDE the launch by the last workgroup to arrive at each tile;
+ *                        0 = by a separate reduce launch, as before round 4.  Bit-identical results either way.
+ *   "plan_mode"          -1 (default) = contraction planning follows dc_set_lanes (1 lane = single-image planning: stream-K /
+ *                        tail plans over partial last rounds); 0 / 1 force multi-lane / single-image planning whatever the lane
+ *                        count -- lets a one-stream profiler pass run exactly the kernels of the multi-lane schedule.
+ *   "stagger"            0 (default) .. 4096: every workgroup of a contraction launch first sleeps a pseudo-random number (below
+ *                        this value) of 64-cycle periods.  Measurement only (profiles/r04_kernel_lab.md).
  *   "v2_stages"          LDS ring depth of the 128x64-tile contraction kernel: 0 = by tile count (default: two stages, three
  *                        workgroups per CU, once a launch has >= 3 tiles per CU; three stages otherwise), 2 or 3 forced.
  *                        Same K order either way: bit-identical results.

@@ -151,6 +151,83 @@ def kernels(reps=5):
         ctx.close()
 
 
+def steady(tag):
+    """Steady-state efficiency of the planned routes (many rounds, start stagger on: the state the multi-lane schedule
+    runs in), for comparing library builds (DENSECAP_HIP_LIB): a few trunk shapes x 4 images + the 1000-row decode."""
+    ctx = Context(0)
+    ops = Ops(ctx)
+    rows = []
+    shapes = [("conv1_2_x4", 4, 600, 720, 64, 64), ("conv2_2_x4", 4, 300, 360, 128, 128), ("conv3_2_x4", 4, 150, 180, 256, 256),
+              ("conv3_2_x1", 1, 150, 180, 256, 256), ("conv4_2_x4", 4, 75, 90, 512, 512)]
+    print("%-14s %-12s %8s %10s %8s" % ("build", "op", "stagger", "us", "TF"))
+    try:
+        for name, nimg, H, Wd, Cin, Cout in shapes:
+            for stag in (0, 32):
+                dset(ctx, "stagger", stag)
+                for _ in range(3):
+                    ops.run_conv(nimg, H, Wd, Cin, Cout, 1)
+                r = [ops.run_conv(nimg, H, Wd, Cin, Cout, 6) for _ in range(2)]
+                best = min(r, key=lambda x: x["us"])
+                rows.append(dict(build=tag, op=name, stagger=stag, us=best["us"], tf=best["tf"], us_all=[x["us"] for x in r]))
+                print("%-14s %-12s %8d %10.1f %8.1f" % (tag, name, stag, best["us"], best["tf"]), flush=True)
+            ops.free()
+        for name, M, N, K in [("dense_c3_2_x4", 108000, 256, 2304), ("fc7_x8", 8000, 4096, 4096)]:
+            for stag in (0, 32):
+                dset(ctx, "stagger", stag)
+                for _ in range(3):
+                    ops.run_dense(M, N, K, 1)
+                r = [ops.run_dense(M, N, K, 6) for _ in range(2)]
+                best = min(r, key=lambda x: x["us"])
+                rows.append(dict(build=tag, op=name, stagger=stag, us=best["us"], tf=best["tf"], us_all=[x["us"] for x in r]))
+                print("%-14s %-12s %8d %10.1f %8.1f" % (tag, name, stag, best["us"], best["tf"]), flush=True)
+            ops.free()
+    finally:
+        dset(ctx, "stagger", 0)
+        ctx.close()
+    # the decode (vocabulary arg-max + h.Wh per step) needs the language model's weights
+    from densecap_amd import DenseCapModel
+    from densecap_amd.weights import make_synthetic_weights
+    m = DenseCapModel(make_synthetic_weights(seed=1234), device=0)
+    c2 = m.ctx
+    rng = np.random.default_rng(0)
+    for n in (1000, 4000):
+        codes = np.maximum(rng.standard_normal((n, 4096)), 0).astype(np.float32)
+        cd = c2.to_device(codes); td = c2.empty((n, 15), np.int32)
+        for stag in (0, 32):
+            dset(c2, "stagger", stag)
+            for _ in range(3):
+                check(c2.h, c2.lib.dc_op_lm_sample(c2.h, cd.ptr, n, td.ptr), "dc_op_lm_sample")
+            best = None
+            for _ in range(3):
+                prof(c2, 1)
+                check(c2.h, c2.lib.dc_op_lm_sample(c2.h, cd.ptr, n, td.ptr), "dc_op_lm_sample")
+                l, ms, fl = prof(c2, -1)
+                if best is None or ms < best[1]:
+                    best = (l, ms, fl)
+            rows.append(dict(build=tag, op="decode_%d" % n, stagger=stag, us=best[1] * 1e3, tf=best[2] / best[1] / 1e9, launches=best[0]))
+            print("%-14s %-12s %8d %10.1f %8.1f" % (tag, "decode_%d" % n, stag, best[1] * 1e3, best[2] / best[1] / 1e9), flush=True)
+        cd.free(); td.free()
+    dset(c2, "stagger", 0)
+    if tag in ("base", "V2_AGPR_ACC"):            # builds with RIGHT results: also the end-to-end rate
+        from densecap_amd.weights import make_synthetic_image
+        H, Wd, nimg = 600, 720, 16
+        dev = c2.to_device(np.stack([make_synthetic_image(H, Wd, i) for i in range(nimg)]))
+        m.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=1000)
+        for lanes in (2, 1):
+            m.setLanes(lanes)
+            m.forward_batch_device(dev.ptr, nimg, H, Wd)
+            rates = []
+            for _ in range(4):
+                t0 = time.perf_counter()
+                m.forward_batch_device(dev.ptr, nimg, H, Wd)
+                rates.append(nimg / (time.perf_counter() - t0))
+            rows.append(dict(build=tag, op="e2e_lanes%d" % lanes, images_per_s=float(np.median(rates)), all=rates))
+            print("%-14s %-12s %8s %10.1f images/s" % (tag, "e2e_lanes%d" % lanes, "-", float(np.median(rates))), flush=True)
+        dev.free()
+    c2.close()
+    json.dump(rows, open(os.path.join(OUT, "lab_steady_%s.json" % tag), "w"), indent=0)
+
+
 def e2e():
     from densecap_amd import DenseCapModel
     from densecap_amd.weights import make_synthetic_image, make_synthetic_weights
@@ -196,6 +273,42 @@ def e2e():
         ctx.close()
 
 
+def ab(knob, a, b):
+    """End-to-end A/B of one debug knob, interleaved (A B A B ...) so that clock / box drift cancels: images/s at
+    (proposals, lanes, group) settings of the headline workload and of configs[2]."""
+    from densecap_amd import DenseCapModel
+    from densecap_amd.weights import make_synthetic_image, make_synthetic_weights
+    m = DenseCapModel(make_synthetic_weights(seed=1234), device=0)
+    ctx = m.ctx
+    H, Wd, n = 600, 720, 24
+    dev = ctx.to_device(np.stack([make_synthetic_image(H, Wd, i) for i in range(n)]))
+    rows = []
+    print("%-14s %-5s %-5s %-5s %12s %12s %8s" % ("knob", "P", "lanes", "group", "A images/s", "B images/s", "B/A"))
+    try:
+        for P, lanes, group in ((1000, 1, 1), (1000, 2, 1), (300, 1, 1), (300, 2, 4), (50, 1, 1)):
+            m.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
+            m.setLanes(lanes); m.setGroup(group)
+            ra, rb = [], []
+            for v in (a, b):
+                dset(ctx, knob, v)
+                m.forward_batch_device(dev.ptr, n, H, Wd)
+            for _ in range(5):
+                for v, acc in ((a, ra), (b, rb)):
+                    dset(ctx, knob, v)
+                    t0 = time.perf_counter()
+                    m.forward_batch_device(dev.ptr, n, H, Wd)
+                    acc.append(n / (time.perf_counter() - t0))
+            A, B = float(np.median(ra)), float(np.median(rb))
+            rows.append(dict(knob=knob, a=a, b=b, P=P, lanes=lanes, group=group, A=A, B=B, ratio=B / A, all_a=ra, all_b=rb))
+            print("%-14s %-5d %-5d %-5d %12.1f %12.1f %8.3f" % ("%s %d|%d" % (knob, a, b), P, lanes, group, A, B, B / A), flush=True)
+    finally:
+        dset(ctx, knob, a)
+        json.dump(rows, open(os.path.join(OUT, "lab_ab_%s.json" % knob), "w"), indent=0)
+        m.setGroup(0)
+        dev.free()
+        ctx.close()
+
+
 PMC_ARMS = {
     # arm -> list of (kind, args, force_cfg, stagger): every entry is dispatched twice, in this order
     "a": [("dense", (1000, 4096, 25088), 0, 0), ("dense", (4000, 4096, 25088), 0, 0), ("dense", (1000, 4096, 25088), 0, 32),
@@ -234,6 +347,10 @@ if __name__ == "__main__":
         kernels(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
     elif mode == "e2e":
         e2e()
+    elif mode == "ab":
+        ab(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
+    elif mode == "steady":
+        steady(sys.argv[2] if len(sys.argv) > 2 else "base")
     elif mode == "pmc-target":
         pmc_target(sys.argv[2] if len(sys.argv) > 2 else "a")
     else:
