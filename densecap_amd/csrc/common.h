@@ -54,11 +54,6 @@ struct GemmDesc {
   // and writes its raw partial tile to splitk_ws[(slice*M + m)*N + n]; launch_splitk_reduce finishes the job
   int splitk = 1;
   float* splitk_ws = nullptr;
-  // split-K finish INSIDE the launch (round 4): per-tile arrival counters (zero before the first launch; the last arriver
-  // resets its tile's counter).  The workgroup that arrives last at a tile adds the `splitk` partial tiles in the fixed
-  // order s = 0 .. splitk-1 and runs the epilogue (bias, ReLU, pool window) -- bit-identical to launch_splitk_reduce[_pool],
-  // without the second launch.  nullptr = partial tiles only (the caller launches the reduce kernel).
-  int* splitk_tickets = nullptr;
   // stream-K over the tiles of rows [m_begin, M) (K-split kernel, launch_mfma_gemm_sk): sk_lo[0..sk_wgs] = unit offsets
   // of the workgroups on the line of K units (unit = 2 K-tiles, sk_np units per tile, tiles n-fastest); sk_slots =
   // sk_wgs partial tiles of 128x128 floats; sk_flags[0..sk_wgs) zeroed before the launch; sk_fault = sticky device word

@@ -53,7 +53,6 @@ struct Lane {
   int32_t *tok = nullptr, *seq = nullptr;
   float *out_boxes = nullptr, *out_scores = nullptr, *out_feats = nullptr;
   float* splitk_ws = nullptr;   // split-K partial tiles (<= 256 tiles of 128x128)
-  int* tickets = nullptr;       // 2 x kTickets arrival counters of the in-kernel split-K finish (main stream | aux stream); own allocation, zeroed once
   int32_t* out_tokens = nullptr;
   // pinned host staging
   void* host_stage = nullptr;
@@ -96,7 +95,6 @@ struct dc_ctx {
   uint32_t* fault_dev = nullptr;   // sticky device word: a stream-K owner gave up waiting for its partner (checked with the results)
   int force_cfg = 0;         // measurement hook: tile configuration of plain launches (dc_debug_set "force_cfg")
   int stagger = 0;           // measurement hook: start-up stagger of a launch's workgroups (dc_debug_set "stagger")
-  bool splitk_fused = true;  // split-K finished inside the launch by the last workgroup of a tile (dc_debug_set "splitk_fused" 0 = reduce launch)
   int plan_mode = -1;        // measurement hook "plan_mode": -1 = planning follows the lane count, 0 = multi-lane planning, 1 = single-image planning
   int v2_stages = 0;         // LDS ring depth of the 128x64-tile kernel (dc_debug_set "v2_stages": 0 by tile count, 2 or 3 forced)
   int tail_mode = 0;         // partial last round in single-image mode: 0 stream-K, 1 K-split tail plan, 2 whole tiles (dc_debug_set)
@@ -182,14 +180,11 @@ hipEvent_t prof_event(dc_ctx* ctx) {
 // every MFMA contraction goes through here (optionally bracketed by HIP events).  `ws` (optional) is a
 // scratch buffer of ws_floats floats on the same stream: problems with few tiles and a long K are split
 // along K over several workgroups per tile and finished by a small reduce kernel.
-// Scratch of one stream's contractions: partial tiles (split-K, tail plans, stream-K slots) and the per-tile arrival
-// counters of the in-kernel split-K finish (kTickets ints, zero when idle: the last arriver of a tile resets its counter).
+// Scratch of one stream's contractions: partial tiles of split-K launches and tail plans, stream-K slots.
 struct Ws {
   float* p = nullptr;
   size_t floats = 0;
-  int* tickets = nullptr;
 };
-constexpr int kTickets = 1024;          // >= tiles of any split launch (split-K and tail plans cover < one round of CUs)
 
 int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, const Ws& w = Ws()) {
   float* const ws = w.p;
@@ -210,12 +205,9 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, const Ws& w = Ws(
   const int m_split = pl.m_split;
   if (pl.kind == GEMM_PLAN_SPLITK) {
     // few tiles, long K: every tile is shared by `splitk` workgroups
-    // the split factor is planned on ONE image (plan_M): a group's launch may carry more tiles than counters -> reduce launch
-    const bool fused = w.tickets != nullptr && ctx->splitk_fused &&
-                       (long)((d.M + 127) / 128) * ((d.N + 127) / 128) <= kTickets;
-    d.splitk = pl.splitk; d.splitk_ws = ws; d.splitk_tickets = fused ? w.tickets : nullptr;
+    d.splitk = pl.splitk; d.splitk_ws = ws;
     e = launch_mfma_gemm(d, s);
-    if (e == hipSuccess && !fused)
+    if (e == hipSuccess)
       e = d.pool ? launch_splitk_reduce_pool(ws, pl.splitk, d.bias, d.C, 0, d.M, d.N, d.ldc, d.H, d.Wd, d.relu, s)
                  : launch_splitk_reduce(ws, pl.splitk, d.bias, d.C, d.M, d.N, d.ldc, d.relu, s);
   } else if (pl.kind == GEMM_PLAN_STREAMK) {
@@ -246,10 +238,9 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, const Ws& w = Ws(
     }
     if (e == hipSuccess) {
       GemmDesc b = d;
-      const bool fused = w.tickets != nullptr && ctx->splitk_fused;     // (a tail covers less than one round of tiles)
-      b.m_begin = m_split; b.a_rows = d.M; b.splitk = tail_sp; b.splitk_ws = ws; b.splitk_tickets = fused ? w.tickets : nullptr;
+      b.m_begin = m_split; b.a_rows = d.M; b.splitk = tail_sp; b.splitk_ws = ws;
       e = launch_mfma_gemm_ks(b, s);
-      if (e == hipSuccess && !fused)
+      if (e == hipSuccess)
         e = d.pool ? launch_splitk_reduce_pool(ws, tail_sp, d.bias, d.C, m_split, d.M - m_split, d.N, d.ldc, d.H, d.Wd, d.relu, s)
                    : launch_splitk_reduce(ws, tail_sp, d.bias, d.C + (size_t)m_split * d.ldc, d.M - m_split, d.N, d.ldc, d.relu, s);
     }
@@ -311,7 +302,7 @@ size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 int effective_proposals(const dc_ctx* ctx, int H, int W);
 constexpr size_t kSplitkWsFloats = (size_t)3200 * 128 * 128;  // 200 MiB per lane: split-K partial outputs (up to 8 x a four-image group's 4 x 384 x 4096 fc6 rows), tail plans, stream-K slots
 
-Ws lane_ws(const Lane& L) { return Ws{L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0, L.tickets}; }
+Ws lane_ws(const Lane& L) { return Ws{L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0}; }
 
 int effective_proposals(const dc_ctx* ctx, int H, int W) {
   if (ctx->num_proposals != -1) return ctx->num_proposals;
@@ -337,10 +328,6 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P, int G) {
     for (auto& e : L.ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
-  }
-  if (L.tickets == nullptr) {
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&L.tickets), 2 * kTickets * sizeof(int)));
-    HIPCHK(hipMemset(L.tickets, 0, 2 * kTickets * sizeof(int)));
   }
   if (L.H == H && L.W == W && L.P == P && L.G == G && L.arena.p) return DC_OK;
   int fh = H, fw = W;
@@ -595,9 +582,9 @@ int lm_beamsearch(dc_ctx* ctx, Lane& L, const float* codes, int n, int32_t* seq_
 int lm_sample_two_streams(dc_ctx* ctx, Lane& L, const float* codes, int n, int plan, int32_t* seq_out) {
   const int h = std::min(n, ((n / 2 + 127) / 128) * 128);
   if (h >= n || L.aux == nullptr) return lm_sample(ctx, L, codes, n, plan, nullptr, seq_out);
-  const size_t wsf = L.splitk_ws ? kSplitkWsFloats / 2 : 0;     // each block its own half of the partial-tile scratch and its own counters
-  const LmPart parts[2] = {{L.stream, 0, h, Ws{L.splitk_ws, wsf, L.tickets}},
-                           {L.aux, h, n - h, Ws{L.splitk_ws ? L.splitk_ws + wsf : nullptr, wsf, L.tickets ? L.tickets + kTickets : nullptr}}};
+  const size_t wsf = L.splitk_ws ? kSplitkWsFloats / 2 : 0;     // each block its own half of the partial-tile scratch
+  const LmPart parts[2] = {{L.stream, 0, h, Ws{L.splitk_ws, wsf}},
+                           {L.aux, h, n - h, Ws{L.splitk_ws ? L.splitk_ws + wsf : nullptr, wsf}}};
   HIPCHK(hipEventRecord(L.ev_fork, L.stream));
   HIPCHK(hipStreamWaitEvent(L.aux, L.ev_fork, 0));
   DCCHK(lm_sample_parts(ctx, L, codes, parts, 2, nullptr, seq_out, plan));
@@ -800,10 +787,6 @@ int lane0_stream(dc_ctx* ctx, hipStream_t* s) {
     HIPCHK(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
   }
-  if (L.tickets == nullptr) {
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&L.tickets), 2 * kTickets * sizeof(int)));
-    HIPCHK(hipMemset(L.tickets, 0, 2 * kTickets * sizeof(int)));
-  }
   *s = L.stream;
   return DC_OK;
 }
@@ -844,7 +827,6 @@ void dc_destroy(dc_ctx* ctx) {
     Lane& L = *lp;
     if (L.arena.p) hipFree(L.arena.p);
     if (L.beam_base) hipFree(L.beam_base);
-    if (L.tickets) hipFree(L.tickets);
     if (L.host_stage) hipHostFree(L.host_stage);
     for (auto& ev : L.ev) if (ev) hipEventDestroy(ev);
     if (L.ev_fork) hipEventDestroy(L.ev_fork);
@@ -1286,11 +1268,6 @@ int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value) {
     ctx->force_cfg = (int)value;
     return DC_OK;
   }
-  if (strcmp(name, "splitk_fused") == 0) {
-    if (value != 0 && value != 1) return ctx->fail(DC_E_INVALID, "dc_debug_set: splitk_fused must be 0 or 1");
-    ctx->splitk_fused = value != 0;
-    return DC_OK;
-  }
   if (strcmp(name, "plan_mode") == 0) {
     if (value < -1 || value > 1) return ctx->fail(DC_E_INVALID, "dc_debug_set: plan_mode must be -1, 0 or 1");
     ctx->plan_mode = (int)value;
@@ -1377,7 +1354,7 @@ int dc_op_conv3x3(dc_ctx* ctx, const float* in, const float* w, const float* b, 
     return ctx->fail(DC_E_INVALID, "dc_op_conv3x3: need Cin %% 32 == 0 and positive sizes");
   float* ws = nullptr;
   HIPCHK(hipMalloc((void**)&ws, kSplitkWsFloats * 4));
-  int rc = conv3x3(ctx, s, in, w, b, out, n_img, H, W, Cin, Cout, relu, Ws{ws, kSplitkWsFloats, lane0(ctx).tickets});
+  int rc = conv3x3(ctx, s, in, w, b, out, n_img, H, W, Cin, Cout, relu, Ws{ws, kSplitkWsFloats});
   hipError_t e2 = hipStreamSynchronize(s);
   (void)hipFree(ws);
   prof_collect(ctx);
@@ -1392,7 +1369,7 @@ int dc_op_conv3x3_relu_pool(dc_ctx* ctx, const float* in, const float* w, const 
     return ctx->fail(DC_E_INVALID, "dc_op_conv3x3_relu_pool: need Cin %% 32 == 0, Cout %% 4 == 0 and positive sizes");
   float* ws = nullptr;
   HIPCHK(hipMalloc((void**)&ws, kSplitkWsFloats * 4));
-  int rc = conv3x3_pool(ctx, s, in, w, b, out, 1, H, W, Cin, Cout, 1, Ws{ws, kSplitkWsFloats, lane0(ctx).tickets});
+  int rc = conv3x3_pool(ctx, s, in, w, b, out, 1, H, W, Cin, Cout, 1, Ws{ws, kSplitkWsFloats});
   hipError_t e2 = hipStreamSynchronize(s);
   (void)hipFree(ws);
   prof_collect(ctx);
@@ -1416,7 +1393,7 @@ int dc_op_linear(dc_ctx* ctx, const float* A, const float* W, const float* bias,
   if (K % 32 || M <= 0 || N <= 0) return ctx->fail(DC_E_INVALID, "dc_op_linear: need K %% 32 == 0");
   float* ws = nullptr;
   HIPCHK(hipMalloc((void**)&ws, kSplitkWsFloats * 4));
-  int rc = linear(ctx, s, A, W, bias, C, M, N, K, relu, Ws{ws, kSplitkWsFloats, lane0(ctx).tickets});
+  int rc = linear(ctx, s, A, W, bias, C, M, N, K, relu, Ws{ws, kSplitkWsFloats});
   hipError_t e2 = hipStreamSynchronize(s);
   (void)hipFree(ws);
   prof_collect(ctx);

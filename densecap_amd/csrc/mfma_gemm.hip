@@ -576,7 +576,7 @@ constexpr unsigned SK_SPIN_LIMIT = 1u << 22;       // bounded: a partner that ne
 template <bool CONV, bool HALF = false>
 __device__ __forceinline__ void ks_segment(const GemmDesc& d, const int m0, const int n0, const int Meff, const int slice,
                                            const int kt0, const int nkt, const int mode, const int sk_wg,
-                                           const int sk_npartner, float* const smem, const int tile_id = 0) {
+                                           const int sk_npartner, float* const smem) {
   constexpr int BM = 128, BN = 128;
   constexpr int PA = BM / 32, PB = BN / 32;
   constexpr int NI = HALF ? 2 : 4;         // live 32-row blocks of A
@@ -856,81 +856,6 @@ __device__ __forceinline__ void ks_segment(const GemmDesc& d, const int m0, cons
     __syncthreads();
     if (tid == 0) __hip_atomic_store(d.sk_flags + sk_wg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (mode == KS_NORMAL && d.splitk > 1 && d.splitk_tickets != nullptr) {
-    // ---- split-K finish by the LAST workgroup to arrive at this tile (no reduce launch) ------------------------------
-    // producer side: every thread's partial stores are ordered before the barrier; thread 0's agent-scope release then
-    // publishes them with the ticket (the per-XCD L2s are not coherent: the release writes the dirty lines back);
-    // consumer side: the last arriver's acquire (one lane), a barrier, then plain loads of all `splitk` partial tiles.
-    int* const s_last = reinterpret_cast<int*>(smem);      // (the ring / reduction slots are free: the loop above ended on a barrier)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      const int old = __hip_atomic_fetch_add(d.splitk_tickets + tile_id, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = old == d.splitk - 1;
-      if (last) __hip_atomic_store(d.splitk_tickets + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-      *s_last = last;
-    }
-    __syncthreads();
-    if (*s_last == 0) return;
-    const int Mw = d.M - d.m_begin;                          // rows of the partial-output window
-    const float* const ws = d.splitk_ws;
-    const int c4 = tid & 31;                                 // this thread's 4 columns of the tile
-    const int n = n0 + c4 * 4;
-    if (n >= d.N) return;                                    // (N % 4 == 0 wherever split-K is planned)
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (d.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(d.bias + n);
-    if (CONV && d.pool) {
-      // four consecutive rows of the window-ordered M axis are one pool window (splitk_reduce_pool_kernel, verbatim)
-      const int Wo = (d.Wd + 1) >> 1, per = ((d.H + 1) >> 1) * Wo;
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int wl = (tid >> 5) + 8 * it;                  // window of the tile, 0..31
-        const int mrow = m0 + 4 * wl;
-        if (mrow >= Meff) continue;
-        const int win = mrow >> 2, wi = win % per, wy = wi / Wo, wx = wi - wy * Wo;
-        f32x4 best = {0.f, 0.f, 0.f, 0.f};
-        bool have = false;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (2 * wy + (c >> 1) >= d.H || 2 * wx + (c & 1) >= d.Wd) continue;
-          const size_t m = (size_t)(mrow - d.m_begin) + c;
-          f32x4 acc = *reinterpret_cast<const f32x4*>(ws + m * d.N + n);
-          for (int sl = 1; sl < d.splitk; ++sl) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ws + ((size_t)sl * Mw + m) * d.N + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = acc[e] + v[e];
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float t = acc[e] + bv[e];
-            if (d.relu) t = t > 0.f ? t : 0.f;
-            best[e] = (!have || t > best[e]) ? t : best[e];
-          }
-          have = true;
-        }
-        *reinterpret_cast<f32x4*>(d.C + (size_t)win * d.ldc + n) = best;
-      }
-      return;
-    }
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int mrow = m0 + (tid >> 5) + 8 * it;
-      if (mrow >= Meff) continue;
-      const size_t m = (size_t)(mrow - d.m_begin);
-      f32x4 acc = *reinterpret_cast<const f32x4*>(ws + m * d.N + n);
-      for (int sl = 1; sl < d.splitk; ++sl) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(ws + ((size_t)sl * Mw + m) * d.N + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = acc[e] + v[e];
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[e] = acc[e] + bv[e];
-        if (d.relu) acc[e] = acc[e] > 0.f ? acc[e] : 0.f;
-      }
-      *reinterpret_cast<f32x4*>(d.C + (size_t)mrow * d.ldc + n) = acc;
-    }
-  }
 }
 
 template <bool CONV>
@@ -951,14 +876,13 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
     if (m0 >= Meff) return;
   }
   const int nkt = d.K / BK / d.splitk;               // this workgroup's K range (the whole K unless split-K)
-  const int tile_id = tile_m * ntn + tile_n;          // split-K arrival counter of this tile (GemmDesc::splitk_tickets)
   if constexpr (!CONV) {
     if (Meff - m0 <= 64) {                             // a <= 64-row tile (50-proposal batch, last tile of 300 rows)
-      ks_segment<false, true>(d, m0, n0, Meff, slice, slice * nkt, nkt, KS_NORMAL, 0, 0, smem, tile_id);
+      ks_segment<false, true>(d, m0, n0, Meff, slice, slice * nkt, nkt, KS_NORMAL, 0, 0, smem);
       return;
     }
   }
-  ks_segment<CONV>(d, m0, n0, Meff, slice, slice * nkt, nkt, KS_NORMAL, 0, 0, smem, tile_id);
+  ks_segment<CONV>(d, m0, n0, Meff, slice, slice * nkt, nkt, KS_NORMAL, 0, 0, smem);
 }
 
 // =========================================================================================

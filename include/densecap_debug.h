@@ -41,8 +41,6 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
  *                        128x128 / 128x64 / 64x64 tiles and no split-K, 4 = planned tiles, no split-K, 5 = 128x128 tiles on the 2x2-wave kernel
  *                        with a two-stage ring (two workgroups per CU), 6 = the K-split 128x128 kernel whatever K.  Changes the fp32
  *                        summation order with the kernel family; never set by the product path.
- *   "splitk_fused"       1 (default) = a split-K launch is finished INSIDE the launch by the last workgroup to arrive at each tile;
- *                        0 = by a separate reduce launch, as before round 4.  Bit-identical results either way.
  *   "plan_mode"          -1 (default) = contraction planning follows dc_set_lanes (1 lane = single-image planning: stream-K /
  *                        tail plans over partial last rounds); 0 / 1 force multi-lane / single-image planning whatever the lane
  *                        count -- lets a one-stream profiler pass run exactly the kernels of the multi-lane schedule.

@@ -547,59 +547,3 @@ def test_nms_clustered_boxes_cross_every_window(ctx, maxb):
     ref = O.nms(b5, 0.5, maxb)
     assert got.tolist() == ref.tolist()
     assert len(ref) > 900
-
-
-@pytest.mark.parametrize("lanes", [3, 1])
-def test_splitk_finish_inside_the_launch_equals_the_reduce_launch(lanes):
-    """Round 4: the workgroup that arrives LAST at a split-K tile adds the partial tiles (fixed order s = 0..S-1) and runs the
-    epilogue -- bias, ReLU, the pool window -- instead of a second launch (dc_debug_set "splitk_fused" 0 brings the reduce
-    launch back).  Every split shape of the path, both ways, must agree BIT FOR BIT, call after call (the per-tile arrival
-    counters reset themselves), and with fresh data in the same scratch (a stale partial tile read across XCDs would show)."""
-    import torch
-    from densecap_amd import ops
-    from densecap_amd._lib import check
-    c = ops.Context(0)
-    try:
-        check(c.h, c.lib.dc_set_lanes(c.h, lanes), "dc_set_lanes")
-        g = torch.Generator().manual_seed(77 + lanes)
-        rng = np.random.default_rng(5)
-
-        def both(fn):
-            outs = []
-            for fused in (1, 0, 1):
-                check(c.h, c.lib.dc_debug_set(c.h, b"splitk_fused", fused), "dc_debug_set")
-                outs.append(fn())
-            np.testing.assert_array_equal(outs[0], outs[1])
-            np.testing.assert_array_equal(outs[2], outs[1])
-            return outs[0]
-        # convolutions: conv5_x (56 tiles x 4), RPN conv (28 x 9), a 480x320-class conv5 (20 tiles x 12), conv4_2 / conv3_2
-        # (tail plans in single-image mode), two images in one launch
-        for (N, Cin, H, W, Cout) in [(1, 512, 38, 45, 512), (1, 512, 38, 45, 256), (1, 512, 20, 30, 512), (1, 512, 75, 90, 512),
-                                     (1, 256, 150, 180, 256), (2, 512, 38, 45, 512)]:
-            w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).numpy()
-            b = torch.randn(Cout, generator=g).numpy()
-            for rep in range(2):
-                x = (torch.relu(torch.randn(N, Cin, H, W, generator=g)) * (1.0 + rep)).numpy()
-                out = both(lambda: ops.conv3x3(c, x, w, b, relu=True))
-                if rep == 0:
-                    ref = torch.relu(torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(),
-                                                                torch.from_numpy(b).double(), padding=1)).float().numpy()
-                    _close(out, ref, rel=2e-5)
-        # pooled convolutions with a split finish (odd sizes: windows at both borders)
-        for (Cin, H, W, Cout) in [(512, 19, 23, 512), (512, 38, 45, 512), (512, 75, 90, 512)]:
-            w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).numpy()
-            b = torch.randn(Cout, generator=g).numpy()
-            x = torch.randn(Cin, H, W, generator=g).numpy()
-            both(lambda: ops.conv3x3_relu_pool(c, x, w, b))
-        # dense: LM encoder (32 tiles x 8), fc6 at 300 rows (96 tiles x 8: three rounds of workgroups, a short last row tile),
-        # fc6 at 50 rows, fc7 at 300 rows
-        for (M, N, K) in [(1000, 512, 4096), (300, 4096, 25088), (50, 4096, 25088), (300, 4096, 4096), (500, 4096, 25088)]:
-            wd = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
-            bd = rng.standard_normal(N).astype(np.float32)
-            xd = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
-            out = both(lambda: ops.linear(c, xd, wd, bd, relu=True))
-            if K <= 4096:
-                _close(out, np.maximum(xd.astype(np.float64) @ wd.astype(np.float64).T + bd, 0).astype(np.float32), rel=2e-5)
-    finally:
-        check(c.h, c.lib.dc_debug_set(c.h, b"splitk_fused", 1), "dc_debug_set")
-        c.close()

@@ -12,7 +12,9 @@ for w in $WHAT; do
     tests)   timeout 900 python -m pytest tests -m gpu -x -q > "$OUT/lab_tests.log" 2>&1; tail -5 "$OUT/lab_tests.log" ;;
     kernels) timeout 600 python tools/kernel_lab.py kernels > "$OUT/lab_kernels.txt" 2>&1; tail -3 "$OUT/lab_kernels.txt" ;;
     e2e)     timeout 600 python tools/kernel_lab.py e2e > "$OUT/lab_e2e.txt" 2>&1; tail -40 "$OUT/lab_e2e.txt" ;;
-    ab_splitk) timeout 600 python tools/kernel_lab.py ab splitk_fused 0 1 > "$OUT/lab_ab_splitk.txt" 2>&1; grep -v amdgpu.ids "$OUT/lab_ab_splitk.txt" | tail -12 ;;
+    ab_*)    # end-to-end A/B of one debug knob: ab_<knob>_<a>_<b>
+      k=${w#ab_}; b=${k##*_}; k=${k%_*}; a=${k##*_}; k=${k%_*}
+      timeout 600 python tools/kernel_lab.py ab $k $a $b > "$OUT/lab_ab_$k.txt" 2>&1; grep -v amdgpu.ids "$OUT/lab_ab_$k.txt" | tail -12 ;;
     bench)   timeout 600 python bench.py > "$OUT/lab_bench_default.json" 2> "$OUT/lab_bench_default.err"; tail -c 3000 "$OUT/lab_bench_default.json"
              timeout 600 python bench.py --proposals 300 --steps 32 --no-cpu-baseline --sustain-seconds 3 --repeats 5 > "$OUT/lab_bench_p300.json" 2> "$OUT/lab_bench_p300.err"; tail -c 1500 "$OUT/lab_bench_p300.json" ;;
     steady)  # every experiment build of the library (make -C densecap_amd/csrc variants) on the same steady-state shapes
