@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 # one lane = one stream for the profiled images (per-launch events switch the two-stream decode off); the short legs only
-BENCH="python $REPO/bench.py --lanes 1 --no-cpu-baseline --no-alt-pass --sustain-seconds 0"
+BENCH="python $REPO/bench.py --lanes 1 --group 1 --no-cpu-baseline --no-alt-pass --no-host-input-leg --sustain-seconds 0"
 run() {  # name, bench args, rocprof args...
   local name=$1 args=$2; shift 2
   rm -rf /tmp/rp_$name
@@ -22,9 +22,17 @@ grep '^{' /tmp/rp_lanes1.json > "$OUT/bench_lanes1.json"
 run fetch "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc FETCH_SIZE
 run write "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc WRITE_SIZE
 run mfma "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT
+# PROFILE WHAT IS TIMED: one stream (per-kernel counters need non-overlapping kernels) but the MULTI-LANE planning of the
+# headline schedule (--plan-mode 0): conv4_2 / conv4_3 on whole K-split tiles, no stream-K, no tail plans
+BENCH="python $REPO/bench.py --lanes 1 --plan-mode 0 --group 1 --no-cpu-baseline --no-alt-pass --no-host-input-leg --sustain-seconds 0"
+run mlplan "--steps 10 --warmup 3 --repeats 1" --kernel-trace --stats
+grep '^{' /tmp/rp_mlplan.json > "$OUT/bench_mlplan.json"
+run mlplan_fetch "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc FETCH_SIZE
+run mlplan_write "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc WRITE_SIZE
+run mlplan_mfma "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT
 # the DEFAULT (multi-lane) schedule -- the one the headline number comes from -- under the kernel trace as well
 # (rocprofv3 serialises dispatches, so the overlap itself is not visible; per-kernel durations and counts are)
-BENCH="python $REPO/bench.py --no-cpu-baseline --no-alt-pass --sustain-seconds 0"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-alt-pass --no-host-input-leg --sustain-seconds 0"
 run default "--steps 10 --warmup 3 --repeats 2" --kernel-trace --stats
 grep '^{' /tmp/rp_default.json > "$OUT/bench_default_under_rocprof.json"
 cd "$REPO"
@@ -32,7 +40,7 @@ python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 Q="--no-cpu-baseline --sustain-seconds 2 --repeats 3"
 python bench.py --height 320 --width 480 --proposals 50 --lanes 1 --steps 30 --no-alt-pass $Q > "$OUT/bench_webcam_480_p50.json" 2>/dev/null
 python bench.py --height 480 --width 720 --proposals 1000 --steps 32 $Q > "$OUT/bench_config0_720x480.json" 2>/dev/null
-python bench.py --proposals 300 --steps 32 $Q > "$OUT/bench_config3_p300.json" 2>/dev/null
+python bench.py --proposals 300 --steps 32 $Q > "$OUT/bench_config3_p300.json" 2>/dev/null     # (images per group picked by the untimed trial)
 python bench.py --height 720 --width 1080 --proposals 2000 --steps 12 --warmup 2 $Q > "$OUT/bench_config5.json" 2>/dev/null
 python tools/gemm_bench.py 5 --serial > "$OUT/gemm_bench_serial.txt" 2>/dev/null
 python tools/gemm_bench.py 5 > "$OUT/gemm_bench_multilane.txt" 2>/dev/null

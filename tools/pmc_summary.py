@@ -25,6 +25,82 @@ def fam(name):
     return n
 
 
+def layer_table(d, tag, serial_plan):
+    """Per-LAYER figures of a one-stream pass: the MFMA launches of an image leave the library in a fixed order
+    (tools/launch_list.py); the MFMA-family dispatches of the trace are cut into images and laid over that list.  Every
+    position's kernel name is checked against the planner's prediction.  tag: file prefix of the passes (<tag>_kernel_trace,
+    <tag>fetch_, <tag>write_, <tag>mfma_ counter passes)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import launch_list
+    L = launch_list.launches(serial=serial_plan)
+    flat = [(li, k) for li, l in enumerate(L) for k in l["kernels"]]
+
+    def mfma_rows(name):
+        rows = [r for r in csv.DictReader(open(os.path.join(d, name + "_kernel_trace.csv"))) if fam(r["Kernel_Name"]).startswith("mfma_gemm")]
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        return rows[1:]                                      # the first contraction of a process is dc_load_weights' xg table
+    def lay(rows):
+        n = len(flat)
+        if len(rows) < n or len(rows) % n:
+            return None, "%d MFMA dispatches are not a multiple of the %d per image" % (len(rows), n)
+        for i, r in enumerate(rows):
+            if fam(r["Kernel_Name"]) != flat[i % n][1]:
+                return None, "dispatch %d is %s, the plan says %s (%s)" % (i, fam(r["Kernel_Name"]), flat[i % n][1], L[flat[i % n][0]]["layer"])
+        return [flat[i % n][0] for i in range(len(rows))], None
+    base = tag if tag else "lanes1"
+    rows = mfma_rows(base)
+    idx, err = lay(rows)
+    if err:
+        return dict(_error=err)
+    tab = [collections.OrderedDict(layer=l["layer"], kernel=" + ".join(l["kernels"]), kind=l["kind"], gflop=l["gflop"],
+                                   algorithmic_bytes=l["algorithmic_bytes"], us=0.0, n=0) for l in L]
+    for r, li in zip(rows, idx):
+        tab[li]["us"] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    nimg = len(rows) // len(flat)
+    for t in tab:
+        t["us"] /= nimg; t["n"] = nimg
+        t["tflops"] = t["gflop"] / t["us"] * 1e3 if t["us"] else 0.0
+    pre = (tag + "_") if tag else ""
+    for cname, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        if not os.path.exists(os.path.join(d, pre + cname + "_counter_collection.csv")):
+            continue
+        crow = mfma_rows(pre + cname)
+        cidx, err = lay(crow)
+        if err:
+            continue
+        vals = {}
+        for r in csv.DictReader(open(os.path.join(d, pre + cname + "_counter_collection.csv"))):
+            if r["Counter_Name"] == key:
+                vals[r["Dispatch_Id"]] = vals.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+        acc = [0.0] * len(L)
+        for r, li in zip(crow, cidx):
+            acc[li] += vals.get(r["Dispatch_Id"], 0.0)
+        for t, a in zip(tab, acc):
+            t[cname + "_kb"] = a / (len(crow) // len(flat))
+    if os.path.exists(os.path.join(d, pre + "mfma_counter_collection.csv")):
+        crow = mfma_rows(pre + "mfma")
+        cidx, err = lay(crow)
+        if not err:
+            per = collections.defaultdict(lambda: collections.defaultdict(float))
+            for r in csv.DictReader(open(os.path.join(d, pre + "mfma_counter_collection.csv"))):
+                per[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+            acc = [collections.defaultdict(float) for _ in L]
+            for r, li in zip(crow, cidx):
+                for k, v in per[r["Dispatch_Id"]].items():
+                    acc[li][k] += v
+                acc[li]["_dur_us"] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            for t, c in zip(tab, acc):
+                if c.get("GRBM_GUI_ACTIVE", 0) > 0:
+                    gui = c["GRBM_GUI_ACTIVE"] / 8.0
+                    t["mfma_util"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024.0)
+                    t["clock_ghz"] = gui / c["_dur_us"] / 1e3
+    for t in tab:
+        if "fetch_kb" in t:
+            t["fabric_bytes"] = (2.0 * t["fetch_kb"] + t.get("write_kb", 0.0)) * 1024      # FETCH_SIZE x2: MI355X_MICROARCH.md (wide coalesced reads)
+            t["fabric_over_algorithmic"] = t["fabric_bytes"] / t["algorithmic_bytes"]
+    return tab
+
+
 def main():
     d, prefix = sys.argv[1], sys.argv[2]
     os.makedirs(os.path.dirname(prefix) or ".", exist_ok=True)
@@ -78,8 +154,36 @@ def main():
         summ["_commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"]).decode().strip()
     except Exception:
         summ["_commit"] = None
+    # per-layer tables: the serial (single-image) planning of the lanes1 passes, and -- when the passes exist -- the
+    # multi-lane planning on one stream (bench.py --lanes 1 --plan-mode 0: the kernels of the TIMED schedule)
+    summ["_layers_single_image_plan"] = layer_table(d, "", 1)
+    if os.path.exists(os.path.join(d, "mlplan_kernel_trace.csv")):
+        summ["_layers_multi_lane_plan"] = layer_table(d, "mlplan", 0)
+    # algorithmic bytes per kernel family (operands once + result once), next to the fabric bytes counted above
+    lt = summ["_layers_single_image_plan"]
+    if isinstance(lt, list):
+        famb = collections.defaultdict(lambda: [0.0, 0])
+        for t in lt:
+            ks = t["kernel"].split(" + ")
+            for k in ks:
+                famb[k][0] += t["algorithmic_bytes"] / len(ks); famb[k][1] += 1
+        for f, (tot, n) in famb.items():
+            if f in summ:
+                summ[f]["algorithmic_bytes_per_launch"] = tot / n
+                if "avg_hbm_bytes_per_launch" in summ[f]:
+                    summ[f]["fabric_over_algorithmic"] = summ[f]["avg_hbm_bytes_per_launch"] / (tot / n)
     json.dump(summ, open(prefix + "_pmc_summary.json", "w"), indent=1)
-    for extra in ("default_kernel_stats.csv", "bench_default_under_rocprof.json", "bench_default.json",
+    for key in ("_layers_single_image_plan", "_layers_multi_lane_plan"):
+        tab = summ.get(key)
+        if isinstance(tab, list):
+            print(key)
+            for t in tab:
+                print("  %-20s %-42s %8.1f us %6.1f TF  mfma %.2f @ %.2f GHz  fabric %7.1f MB / alg %6.1f MB = %.2f" % (
+                    t["layer"], t["kernel"][:42], t["us"], t["tflops"], t.get("mfma_util", 0), t.get("clock_ghz", 0),
+                    t.get("fabric_bytes", 0) / 1e6, t["algorithmic_bytes"] / 1e6, t.get("fabric_over_algorithmic", 0)))
+        elif tab:
+            print(key, tab)
+    for extra in ("mlplan_kernel_stats.csv", "bench_mlplan.json", "default_kernel_stats.csv", "bench_default_under_rocprof.json", "bench_default.json",
                   "bench_webcam_480_p50.json", "bench_config3_p300.json", "bench_config5.json", "bench_config0_720x480.json",
                   "gemm_bench_serial.txt", "gemm_bench_multilane.txt", "decode_bench.txt", "parity_report.json"):
         if os.path.exists(os.path.join(d, extra)):
