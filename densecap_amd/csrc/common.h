@@ -48,6 +48,23 @@ struct GemmDesc {
   // entries; columns [amax_cols, N) are stored raw to C[m*ldc + (n - amax_cols)].  amax_cols = 0: every column.
   int amax_cols = 0;
   int amax_n = 0;
+  // Fused decode step (round 4; LanguageModel.lua:316-335 between two vocabulary projections): with lstm_c set, the columns
+  // [amax_cols, N) are LSTM GATE tiles -- W rows gate-interleaved (row amax_cols + 4u + g = gate g of hidden unit u, g in
+  // i,f,o,g), so that a lane of the transposed accumulator holds the four gates of a unit -- and their epilogue is the
+  // step's row-wise tail: token of the row (lstm_fixed_tok, or the arg-max this launch's own vocabulary tiles merged into
+  // lstm_best by 64-bit atomic max: the gate tiles are enqueued LAST and wait on lstm_done), gates = xg[tok] + h.Wh,
+  // c' = f*c + i*g, h' = o*tanh(c') written to lstm_h (not the A operand: h ping-pongs), token to lstm_seq.
+  // lstm_best alone (no lstm_c): arg-max tiles only (last step); the last tile to arrive at a row block writes the tokens.
+  const float* lstm_xg = nullptr;            // (V+2, 4Hd) b + Emb.Wx per token, gate-interleaved columns 4u + g
+  float* lstm_c = nullptr;                   // (M, Hd) cell state, in place
+  float* lstm_h = nullptr;                   // (M, Hd) h_{t+1}
+  unsigned long long* lstm_best = nullptr;   // (M) packed (orderable logit << 32 | ~column); zero before the launch
+  int* lstm_done = nullptr;                  // (ceil(M/64)) arg-max tiles that have merged their 64 rows; zero before the launch
+  int32_t* lstm_seq = nullptr;               // seq[m * lstm_T + lstm_t] = token (1-based); null = not recorded
+  int lstm_T = 0, lstm_t = 0;
+  int lstm_fixed_tok = -1;                   // >= 0: the rows' token is this constant (0 = no xg row): nothing to wait for
+  int lstm_zero_c = 0;                       // c = 0 on entry (image step)
+  unsigned* lstm_fault = nullptr;            // sticky word raised when a gate tile gives up waiting (checked with the results)
   // optional device-side row count: effective M = min(M, *m_dev); workgroups past it exit at once
   const int32_t* m_dev = nullptr;
   // split-K (K-split 128x128 kernel only): `splitk` workgroups share one tile, each sums a contiguous K range
@@ -140,6 +157,9 @@ hipError_t launch_iota_count(int32_t* idx, int32_t* count_out, const int32_t* co
 hipError_t launch_lstm_step_tail(const float* pval, const int32_t* pidx, int ntiles, int ld, int fixed_tok,
                                  const float* xg, const float* gates_pre, float* c, float* h, int n,
                                  const int32_t* n_dev, int Hd, int zero_c, int32_t* seq, int T, int t, hipStream_t s);
+// gate-interleaved copies for the fused decode step (GemmDesc::lstm_*): dst row / column 4u + g = src row / column g*Hd + u
+hipError_t launch_permute_gate_rows(const float* src, float* dst, int Hd, int K, hipStream_t s);
+hipError_t launch_permute_gate_cols(const float* src, float* dst, size_t rows, int Hd, hipStream_t s);
 // objectness + box regression heads + final ApplyBoxTransform (DenseCapModel.lua:134,139-140)
 hipError_t launch_recog_heads(const float* codes, const float* w5 /*(5,D): obj, 4 boxreg*/, const float* b5,
                               const float* roi_boxes, float* obj, float* trans, float* final_boxes, int n, int D,

@@ -85,6 +85,31 @@ __device__ __forceinline__ float pool_window(const GemmDesc& d, int win, float v
   return best;
 }
 
+// ---- fused decode step helpers -------------------------------------------------------------------------------------------
+// arg-max key: larger logit wins, then the LOWER column (torch.max's first maximum); -0 == +0 like a float compare
+__device__ __forceinline__ unsigned long long amax_key(float v, int col) {
+  if (v == 0.f) v = 0.f;
+  unsigned u = __float_as_uint(v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)col);
+}
+// token of a merged key: 1 + column; a row whose logits held no comparable value (all NaN) keeps what the two-level
+// reduction of the unfused route produces for it: column 0x7fffffff, i.e. token INT_MIN (never a valid id)
+__device__ __forceinline__ int amax_token(unsigned long long key) {
+  return key != 0ull ? 1 + (int)(0xffffffffu - (unsigned)(key & 0xffffffffull)) : (int)0x80000000;
+}
+// torch-rnn nn.LSTM point-wise step on one hidden unit, the arithmetic of lstm_step_tail_kernel operation for operation
+// (every product and sum rounded on its own: no contraction)
+__device__ __forceinline__ float lstm_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ void lstm_unit(float gi, float gf, float go, float gg, float cprev, float& c_out, float& h_out) {
+  const float ig = lstm_sigmoid(gi), fg = lstm_sigmoid(gf), og = lstm_sigmoid(go);
+  const float gt = tanhf(gg);
+  const float cn = __fadd_rn(__fmul_rn(fg, cprev), __fmul_rn(ig, gt));
+  c_out = cn;
+  h_out = __fmul_rn(og, tanhf(cn));
+}
+constexpr unsigned LSTM_SPIN_LIMIT = 1u << 22;
+
 // =========================================================================================
 // v2: LDS-DMA (buffer_load ... lds) ring of three stages (two for the 128x64 tiles of launches with >= 3 tiles per CU:
 // three workgroups per CU), fragment double-buffering, ONE barrier per K-tile placed in the MIDDLE of the tile's MFMA
@@ -354,6 +379,71 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
     // acc[i][j] is the transposed block: this lane's row is m = m0 + wm*32*TM + i*32 + (lane&31); register e is column
     // n = n0 + wn*32*TN + j*32 + 8*(e>>2) + 4*hsel + (e&3), ascending in (j, e).  Ties: lower column (first max).
     const int an = d.amax_cols > 0 ? d.amax_n : d.N;           // real vocabulary columns
+    if (d.lstm_c != nullptr && n0 >= d.amax_cols) {
+      // ---- LSTM gate tile of a fused decode step: this lane owns rows m (one per 32-row block i) and, per group of four
+      // consecutive registers, the gates i,f,o,g of hidden unit u = (column - amax_cols) / 4
+      __syncthreads();                                         // the operand ring is reused for the rows' tokens
+      int* const tok_s = reinterpret_cast<int*>(smem);         // [BM]
+      if (d.lstm_fixed_tok >= 0) {
+        if (tid < BM) tok_s[tid] = d.lstm_fixed_tok;
+      } else {
+        // the arg-max tiles of these rows were enqueued before this tile; wait until all of them have merged their maxima
+        if (tid == 0) {
+          const int nwait = d.amax_cols / 64;
+          for (int b = m0 >> 6; b <= ((min(m0 + BM, Meff) - 1) >> 6); ++b) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(d.lstm_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwait) {
+              __builtin_amdgcn_s_sleep(2);
+              if (++spins > LSTM_SPIN_LIMIT) {               // report, do not hang (the host falls back to the unfused route)
+                if (d.lstm_fault != nullptr) __hip_atomic_store(d.lstm_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (tid < BM && m0 + tid < Meff) {
+          const int tok = amax_token(__hip_atomic_load(d.lstm_best + m0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          tok_s[tid] = tok;
+          if (d.lstm_seq != nullptr && n0 == d.amax_cols) d.lstm_seq[(size_t)(m0 + tid) * d.lstm_T + d.lstm_t] = tok;
+        }
+      }
+      __syncthreads();
+      const int Hd4 = d.N - d.amax_cols, Hd = Hd4 >> 2;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int ml = wm * 32 * TM + i * 32 + r;
+        const int m = m0 + ml;
+        if (m >= Meff) continue;
+        const int tok = tok_s[ml];
+        const float* xrow = tok > 0 ? d.lstm_xg + (size_t)(tok - 1) * Hd4 : nullptr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int nb = n0 + wn * 32 * TN + j * 32 + 8 * q4 + 4 * hsel - d.amax_cols;     // gate column 4u of this register group
+            if (nb + 3 >= Hd4) continue;
+            const int u = nb >> 2;
+            float gi = acc[i][j][q4 * 4 + 0], gf = acc[i][j][q4 * 4 + 1], go = acc[i][j][q4 * 4 + 2], gg = acc[i][j][q4 * 4 + 3];
+            if (d.bias != nullptr && d.lstm_fixed_tok >= 0) {     // image step: gates = (b + enc.Wx): the bias rides in the GEMM
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(d.bias + nb);
+              gi = gi + bv[0]; gf = gf + bv[1]; go = go + bv[2]; gg = gg + bv[3];
+            }
+            if (xrow != nullptr) {                                // (b + x.Wx) + h.Wh, torch-rnn's association
+              const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + nb);
+              gi = xv[0] + gi; gf = xv[1] + gf; go = xv[2] + go; gg = xv[3] + gg;
+            }
+            const size_t ci = (size_t)m * Hd + u;
+            const float cprev = d.lstm_zero_c ? 0.f : d.lstm_c[ci];
+            float cn, hn;
+            lstm_unit(gi, gf, go, gg, cprev, cn, hn);
+            d.lstm_c[ci] = cn;
+            d.lstm_h[ci] = hn;
+          }
+      }
+      return;
+    }
     if (d.amax_cols > 0 && n0 >= d.amax_cols) {
       // ---- columns past the arg-max prefix (the h.Wh half of the next step's gates): raw store of the transposed
       // blocks; a lane owns row m and writes 16-byte runs of 4 consecutive columns
@@ -422,9 +512,34 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
       const int oi = red_i[BM + tid];
       if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
       const int m = m0 + tid;
-      if (m < Meff) {
+      if (d.lstm_best != nullptr) {
+        // fused decode step: merge this tile's maximum into the row's key (nothing to merge for a tile without a comparable value)
+        if (m < Meff && bi != 0x7fffffff) __hip_atomic_fetch_max(d.lstm_best + m, amax_key(best, bi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (m < Meff) {
         d.amax_val[(size_t)m * d.amax_ld + tile_n] = best;
         d.amax_idx[(size_t)m * d.amax_ld + tile_n] = bi;
+      }
+    }
+    if (d.lstm_best != nullptr) {
+      // arrival: the merges of this tile's rows are ordered before the counter (release), one count per 64-row block.
+      // Without gate tiles in the launch (last step) the LAST tile to arrive at a block writes its tokens.
+      __syncthreads();
+      int* const s_last = reinterpret_cast<int*>(smem + 4 * BM);
+      if (tid == 0) {
+        const int nwait = (d.amax_cols > 0 ? d.amax_cols : ((d.N + 63) / 64) * 64) / 64;
+        int lastmask = 0;
+        for (int b = m0 >> 6, k = 0; b <= ((min(m0 + BM, Meff) - 1) >> 6); ++b, ++k) {
+          const int old = __hip_atomic_fetch_add(d.lstm_done + b, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+          if (old == nwait - 1) lastmask |= 1 << k;
+        }
+        *s_last = lastmask;
+      }
+      if (d.lstm_c == nullptr && d.lstm_seq != nullptr) {
+        __syncthreads();
+        const int lastmask = *s_last;
+        if (tid < BM && m0 + tid < Meff && ((lastmask >> (tid >> 6)) & 1))
+          d.lstm_seq[(size_t)(m0 + tid) * d.lstm_T + d.lstm_t] =
+              amax_token(__hip_atomic_load(d.lstm_best + m0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       }
     }
     return;
@@ -498,7 +613,15 @@ template <int TM, int TN, bool CONV, int NS, bool AMAX = false>
 __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   start_stagger(d);
-  const int bid = xcd_remap(blockIdx.x, ntm * ntn);
+  int bid;
+  if (AMAX && d.lstm_c != nullptr) {
+    // fused decode step: the arg-max tiles first (XCD-aware among themselves), the gate tiles that wait for them LAST
+    // (m-fastest order: tile index < TA <=> arg-max column tile)
+    const int TA = ntm * (d.amax_cols / (64 * TN)), b = blockIdx.x;
+    bid = b < TA ? xcd_remap(b, TA) : TA + xcd_remap(b - TA, ntm * ntn - TA);
+  } else {
+    bid = xcd_remap(blockIdx.x, ntm * ntn);
+  }
   int tile_m, tile_n;
   if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
   else           { tile_n = bid % ntn; tile_m = bid / ntn; }
@@ -530,7 +653,13 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_mixed_kernel(GemmDesc d, int
   }
   const int b = blockIdx.x;
   if (b < nbig) {
-    const int bid = xcd_remap(b, nbig);
+    int bid;
+    if (AMAX && d.lstm_c != nullptr) {                 // fused decode step: arg-max tiles first, gate tiles last (see v2_kernel)
+      const int TA = ntm * (d.amax_cols / 64);
+      bid = b < TA ? xcd_remap(b, min(nbig, TA)) : TA + xcd_remap(b - TA, nbig - TA);
+    } else {
+      bid = xcd_remap(b, nbig);
+    }
     int tile_m, tile_n;
     if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
     else           { tile_n = bid % ntn; tile_m = bid / ntn; }
@@ -1054,6 +1183,9 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   if (d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0) return hipErrorInvalidValue;   // K-split kernel features
   if constexpr (!CONV && TN == 1) {
     if (d.amax_val != nullptr) {
+      if (d.lstm_c != nullptr && (!m_fastest || d.amax_cols % 64 || (d.N - d.amax_cols) % 64 || d.lstm_h == nullptr ||
+                                  (d.lstm_fixed_tok < 0 && (d.lstm_best == nullptr || d.lstm_done == nullptr || d.lstm_xg == nullptr))))
+        return hipErrorInvalidValue;                   // gate tiles must come after the arg-max tiles they wait for
       if (d.amax_cols % BN != 0 || (d.amax_cols > 0 && (d.C == nullptr || d.amax_n > d.amax_cols || d.amax_cols > d.N)))
         return hipErrorInvalidValue;
       const size_t lds3 = (size_t)3 * (BM + BN) * BK * sizeof(float);
