@@ -51,16 +51,18 @@ struct GemmDesc {
   // Fused decode step (round 4; LanguageModel.lua:316-335 between two vocabulary projections): with lstm_c set, the columns
   // [amax_cols, N) are LSTM GATE tiles -- W rows gate-interleaved (row amax_cols + 4u + g = gate g of hidden unit u, g in
   // i,f,o,g), so that a lane of the transposed accumulator holds the four gates of a unit -- and their epilogue is the
-  // step's row-wise tail: token of the row (lstm_fixed_tok, or the arg-max this launch's own vocabulary tiles merged into
-  // lstm_best by 64-bit atomic max: the gate tiles are enqueued LAST and wait on lstm_done), gates = xg[tok] + h.Wh,
-  // c' = f*c + i*g, h' = o*tanh(c') written to lstm_h (not the A operand: h ping-pongs), token to lstm_seq.
-  // lstm_best alone (no lstm_c): arg-max tiles only (last step); the last tile to arrive at a row block writes the tokens.
+  // step's row-wise tail: token of the row (lstm_fixed_tok, or lstm_tok[m] once lstm_ready says the row's block is reduced),
+  // gates = xg[tok] + h.Wh, c' = f*c + i*g, h' = o*tanh(c') written to lstm_h (not the A operand: h ping-pongs).
+  // The vocabulary tiles write their (value, column) partials as always and count their arrival per 64-row block in
+  // lstm_done; the LAST tile to arrive at a block reduces its rows' partials to tokens (lstm_tok, lstm_seq) and raises
+  // lstm_ready.  The gate tiles are enqueued after the vocabulary tiles.  lstm_done without lstm_c: last step (tokens only).
   const float* lstm_xg = nullptr;            // (V+2, 4Hd) b + Emb.Wx per token, gate-interleaved columns 4u + g
   float* lstm_c = nullptr;                   // (M, Hd) cell state, in place
   float* lstm_h = nullptr;                   // (M, Hd) h_{t+1}
-  unsigned long long* lstm_best = nullptr;   // (M) packed (orderable logit << 32 | ~column); zero before the launch
-  int* lstm_done = nullptr;                  // (ceil(M/64)) arg-max tiles that have merged their 64 rows; zero before the launch
-  int32_t* lstm_seq = nullptr;               // seq[m * lstm_T + lstm_t] = token (1-based); null = not recorded
+  int32_t* lstm_tok = nullptr;               // (M) this step's tokens (1-based)
+  int* lstm_done = nullptr;                  // (ceil(M/64)) vocabulary tiles that have stored their partials; zero before the launch
+  int* lstm_ready = nullptr;                 // (ceil(M/64)) 1 = the block's tokens are in lstm_tok; zero before the launch
+  int32_t* lstm_seq = nullptr;               // seq[m * lstm_T + lstm_t] = token; null = not recorded
   int lstm_T = 0, lstm_t = 0;
   int lstm_fixed_tok = -1;                   // >= 0: the rows' token is this constant (0 = no xg row): nothing to wait for
   int lstm_zero_c = 0;                       // c = 0 on entry (image step)

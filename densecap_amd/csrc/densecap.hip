@@ -51,7 +51,7 @@ struct Lane {
   float *obj = nullptr, *final_trans = nullptr, *final_boxes = nullptr, *final_xyxy = nullptr;
   float *enc = nullptr, *gates = nullptr, *hstate = nullptr, *cstate = nullptr, *logits = nullptr;
   float* hstate2 = nullptr;     // fused decode step: h ping-pongs (the gate tiles write h_{t+1} while arg-max tiles still read h_t)
-  char* lm_sync = nullptr;      // fused decode step: per decode block [T][rows] packed arg-max keys + [T][rows/64] arrival counters
+  char* lm_sync = nullptr;      // fused decode step: per decode block [T][rows] tokens + [T][2][rows/64] arrival counters / ready flags
   int32_t *tok = nullptr, *seq = nullptr;
   float *out_boxes = nullptr, *out_scores = nullptr, *out_feats = nullptr;
   float* splitk_ws = nullptr;   // split-K partial tiles (<= 256 tiles of 128x128)
@@ -312,9 +312,10 @@ int conv3x3_pool(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, co
 
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 // fused decode step: a block of rows [r0, r0+n) (r0 a multiple of 128) owns bytes [lm_sync_off(r0,T), +lm_sync_bytes(n,T))
-// = [T][n] 64-bit arg-max keys, then [T][ceil(n/64)] arrival counters; zeroed once per decode of that block
-size_t lm_sync_off(size_t r0, int T) { return r0 * T * 8 + (r0 / 64) * T * 4; }
-size_t lm_sync_bytes(size_t n, int T) { return n * T * 8 + ((n + 63) / 64 + 2) * T * 4 + 64; }
+// = [T][n] int32 tokens, then [T][2][ceil(n/64)] arrival counters and ready flags; zeroed once per decode of that block
+size_t lm_sync_off(size_t r0, int T) { return r0 * T * 4 + (r0 / 64) * 2 * T * 4; }
+size_t lm_sync_used(size_t n, int T) { return n * T * 4 + ((n + 63) / 64) * 2 * T * 4; }      // <= off(r0 + roundup(n, 64)) - off(r0)
+size_t lm_sync_bytes(size_t n, int T) { return lm_sync_used((n + 127) / 128 * 128, T) + 256; }
 // num_proposals = -1 (LocalizationLayer.lua:322-324: uncapped RPN NMS): capacity = every anchor of this image size
 int effective_proposals(const dc_ctx* ctx, int H, int W);
 constexpr size_t kSplitkWsFloats = (size_t)3200 * 128 * 128;  // 200 MiB per lane: split-K partial outputs (up to 8 x a four-image group's 4 x 384 x 4096 fc6 rows), tail plans, stream-K slots
@@ -483,7 +484,7 @@ int lm_sample_parts(dc_ctx* ctx, Lane& L, const float* codes, const LmPart* part
     DCCHK(ensure_fault_word(ctx));
     for (int pi = 0; pi < nparts; ++pi) {
       const LmPart& p = parts[pi];
-      HIPCHK(hipMemsetAsync(L.lm_sync + lm_sync_off(p.r0, T), 0, lm_sync_bytes(p.n, T), p.s));
+      HIPCHK(hipMemsetAsync(L.lm_sync + lm_sync_off(p.r0, T), 0, lm_sync_used(p.n, T), p.s));
     }
     for (int t = 0; t < T; ++t) {
       const bool last = t == T - 1;
@@ -494,9 +495,12 @@ int lm_sample_parts(dc_ctx* ctx, Lane& L, const float* codes, const LmPart* part
         const int nb = (p.n + 63) / 64;
         GemmDesc v;
         v.A = hbuf[t & 1]; v.W = ctx->dec_wp; v.bias = ctx->out_b; v.M = p.n; v.K = Hd; v.m_dev = n_dev; v.plan_M = plan;
-        v.amax_val = L.logits; v.amax_idx = reinterpret_cast<int32_t*>(L.logits); v.amax_ld = ntn;     // (route selectors: nothing is written there)
-        v.lstm_best = reinterpret_cast<unsigned long long*>(sync) + (size_t)t * p.n;
-        v.lstm_done = reinterpret_cast<int*>(sync + (size_t)p.n * T * 8) + (size_t)t * nb;
+        v.amax_val = L.logits + (size_t)p.r0 * 2 * ntn;
+        v.amax_idx = reinterpret_cast<int32_t*>(v.amax_val + (size_t)p.n * ntn);
+        v.amax_ld = ntn;
+        v.lstm_tok = reinterpret_cast<int32_t*>(sync) + (size_t)t * p.n;
+        v.lstm_done = reinterpret_cast<int*>(sync + (size_t)p.n * T * 4) + (size_t)t * 2 * nb;
+        v.lstm_ready = v.lstm_done + nb;
         v.lstm_seq = seq_out + (size_t)p.r0 * T; v.lstm_T = T; v.lstm_t = t; v.lstm_fault = ctx->fault_dev;
         if (last) {
           v.N = V1; v.ldc = V1;

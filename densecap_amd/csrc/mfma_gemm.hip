@@ -86,18 +86,6 @@ __device__ __forceinline__ float pool_window(const GemmDesc& d, int win, float v
 }
 
 // ---- fused decode step helpers -------------------------------------------------------------------------------------------
-// arg-max key: larger logit wins, then the LOWER column (torch.max's first maximum); -0 == +0 like a float compare
-__device__ __forceinline__ unsigned long long amax_key(float v, int col) {
-  if (v == 0.f) v = 0.f;
-  unsigned u = __float_as_uint(v);
-  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-  return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)col);
-}
-// token of a merged key: 1 + column; a row whose logits held no comparable value (all NaN) keeps what the two-level
-// reduction of the unfused route produces for it: column 0x7fffffff, i.e. token INT_MIN (never a valid id)
-__device__ __forceinline__ int amax_token(unsigned long long key) {
-  return key != 0ull ? 1 + (int)(0xffffffffu - (unsigned)(key & 0xffffffffull)) : (int)0x80000000;
-}
 // torch-rnn nn.LSTM point-wise step on one hidden unit, the arithmetic of lstm_step_tail_kernel operation for operation
 // (every product and sum rounded on its own: no contraction)
 __device__ __forceinline__ float lstm_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
@@ -387,12 +375,12 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
       if (d.lstm_fixed_tok >= 0) {
         if (tid < BM) tok_s[tid] = d.lstm_fixed_tok;
       } else {
-        // the arg-max tiles of these rows were enqueued before this tile; wait until all of them have merged their maxima
+        // the arg-max tiles of these rows were enqueued before this tile; the last of them to finish reduces the rows'
+        // partial maxima to tokens and raises the block's flag
         if (tid == 0) {
-          const int nwait = d.amax_cols / 64;
           for (int b = m0 >> 6; b <= ((min(m0 + BM, Meff) - 1) >> 6); ++b) {
             unsigned spins = 0;
-            while (__hip_atomic_load(d.lstm_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwait) {
+            while (__hip_atomic_load(d.lstm_ready + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
               __builtin_amdgcn_s_sleep(2);
               if (++spins > LSTM_SPIN_LIMIT) {               // report, do not hang (the host falls back to the unfused route)
                 if (d.lstm_fault != nullptr) __hip_atomic_store(d.lstm_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -403,11 +391,7 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
-        if (tid < BM && m0 + tid < Meff) {
-          const int tok = amax_token(__hip_atomic_load(d.lstm_best + m0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          tok_s[tid] = tok;
-          if (d.lstm_seq != nullptr && n0 == d.amax_cols) d.lstm_seq[(size_t)(m0 + tid) * d.lstm_T + d.lstm_t] = tok;
-        }
+        if (tid < BM && m0 + tid < Meff) tok_s[tid] = d.lstm_tok[m0 + tid];
       }
       __syncthreads();
       const int Hd4 = d.N - d.amax_cols, Hd = Hd4 >> 2;
@@ -512,34 +496,60 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
       const int oi = red_i[BM + tid];
       if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
       const int m = m0 + tid;
-      if (d.lstm_best != nullptr) {
-        // fused decode step: merge this tile's maximum into the row's key (nothing to merge for a tile without a comparable value)
-        if (m < Meff && bi != 0x7fffffff) __hip_atomic_fetch_max(d.lstm_best + m, amax_key(best, bi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else if (m < Meff) {
+      if (m < Meff) {
         d.amax_val[(size_t)m * d.amax_ld + tile_n] = best;
         d.amax_idx[(size_t)m * d.amax_ld + tile_n] = bi;
       }
     }
-    if (d.lstm_best != nullptr) {
-      // arrival: the merges of this tile's rows are ordered before the counter (release), one count per 64-row block.
-      // Without gate tiles in the launch (last step) the LAST tile to arrive at a block writes its tokens.
-      __syncthreads();
+    if (d.lstm_done != nullptr) {
+      // ---- fused decode step: arrival.  This tile's partial maxima are ordered before the counter (release: the per-XCD
+      // L2s are not coherent); the LAST tile to arrive at a 64-row block reduces the block's partials to tokens -- ascending
+      // column tiles, first maximum on ties: lstm_step_tail_kernel's rule -- and raises the block's flag for the gate tiles.
       int* const s_last = reinterpret_cast<int*>(smem + 4 * BM);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
       if (tid == 0) {
         const int nwait = (d.amax_cols > 0 ? d.amax_cols : ((d.N + 63) / 64) * 64) / 64;
         int lastmask = 0;
-        for (int b = m0 >> 6, k = 0; b <= ((min(m0 + BM, Meff) - 1) >> 6); ++b, ++k) {
-          const int old = __hip_atomic_fetch_add(d.lstm_done + b, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-          if (old == nwait - 1) lastmask |= 1 << k;
-        }
+        for (int b = m0 >> 6, k = 0; b <= ((min(m0 + BM, Meff) - 1) >> 6); ++b, ++k)
+          if (__hip_atomic_fetch_add(d.lstm_done + b, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == nwait - 1) lastmask |= 1 << k;
+        if (lastmask) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         *s_last = lastmask;
       }
-      if (d.lstm_c == nullptr && d.lstm_seq != nullptr) {
+      __syncthreads();
+      const int lastmask = *s_last;
+      if (lastmask == 0) return;
+      const int ntiles = (d.amax_cols > 0 ? d.amax_cols : ((d.N + 63) / 64) * 64) / 64;
+      for (int k = 0; k < BM / 64; ++k) {
+        if (!((lastmask >> k) & 1)) continue;
+        const int m = m0 + 64 * k + (tid >> 2), sub = tid & 3;          // four threads per row
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        if (m < Meff) {
+          for (int j = sub; j < ntiles; j += 4) {
+            const float v = d.amax_val[(size_t)m * d.amax_ld + j];
+            const int i = d.amax_idx[(size_t)m * d.amax_ld + j];
+            if (bi == 0x7fffffff || v > best) { best = v; bi = i; }
+          }
+        }
+#pragma unroll
+        for (int o = 1; o <= 2; o <<= 1) {
+          const float ov = __shfl_xor(best, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+        }
+        if (m < Meff && sub == 0) {
+          const int tok = bi + 1;
+          d.lstm_tok[m] = tok;
+          if (d.lstm_seq != nullptr) d.lstm_seq[(size_t)m * d.lstm_T + d.lstm_t] = tok;
+        }
+      }
+      if (d.lstm_ready != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int lastmask = *s_last;
-        if (tid < BM && m0 + tid < Meff && ((lastmask >> (tid >> 6)) & 1))
-          d.lstm_seq[(size_t)(m0 + tid) * d.lstm_T + d.lstm_t] =
-              amax_token(__hip_atomic_load(d.lstm_best + m0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (tid == 0)
+          for (int b = m0 >> 6, k = 0; b <= ((min(m0 + BM, Meff) - 1) >> 6); ++b, ++k)
+            if ((lastmask >> k) & 1) __hip_atomic_store(d.lstm_ready + b, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     return;
@@ -1184,7 +1194,7 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   if constexpr (!CONV && TN == 1) {
     if (d.amax_val != nullptr) {
       if (d.lstm_c != nullptr && (!m_fastest || d.amax_cols % 64 || (d.N - d.amax_cols) % 64 || d.lstm_h == nullptr ||
-                                  (d.lstm_fixed_tok < 0 && (d.lstm_best == nullptr || d.lstm_done == nullptr || d.lstm_xg == nullptr))))
+                                  (d.lstm_fixed_tok < 0 && (d.lstm_tok == nullptr || d.lstm_done == nullptr || d.lstm_ready == nullptr || d.lstm_xg == nullptr))))
         return hipErrorInvalidValue;                   // gate tiles must come after the arg-max tiles they wait for
       if (d.amax_cols % BN != 0 || (d.amax_cols > 0 && (d.C == nullptr || d.amax_n > d.amax_cols || d.amax_cols > d.N)))
         return hipErrorInvalidValue;
