@@ -520,28 +520,51 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
       const int lastmask = *s_last;
       if (lastmask == 0) return;
       const int ntiles = (d.amax_cols > 0 ? d.amax_cols : ((d.N + 63) / 64) * 64) / 64;
+      // a wave takes 16 rows of the block, eight at a time: a row's partials are contiguous (lane l reads column tiles l,
+      // l + 64, l + 128: coalesced), all loads of the eight rows are in flight together -- they come from the other XCDs'
+      // write-backs, i.e. from the Infinity Cache, and a dependent chain of them would cost a microsecond per link
       for (int k = 0; k < BM / 64; ++k) {
         if (!((lastmask >> k) & 1)) continue;
-        const int m = m0 + 64 * k + (tid >> 2), sub = tid & 3;          // four threads per row
-        float best = -INFINITY;
-        int bi = 0x7fffffff;
-        if (m < Meff) {
-          for (int j = sub; j < ntiles; j += 4) {
-            const float v = d.amax_val[(size_t)m * d.amax_ld + j];
-            const int i = d.amax_idx[(size_t)m * d.amax_ld + j];
-            if (bi == 0x7fffffff || v > best) { best = v; bi = i; }
-          }
-        }
+        for (int rb = 0; rb < 16; rb += 8) {
+          float best[8];
+          int bi[8];
 #pragma unroll
-        for (int o = 1; o <= 2; o <<= 1) {
-          const float ov = __shfl_xor(best, o, 64);
-          const int oi = __shfl_xor(bi, o, 64);
-          if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
-        }
-        if (m < Meff && sub == 0) {
-          const int tok = bi + 1;
-          d.lstm_tok[m] = tok;
-          if (d.lstm_seq != nullptr) d.lstm_seq[(size_t)m * d.lstm_T + d.lstm_t] = tok;
+          for (int q = 0; q < 8; ++q) { best[q] = -INFINITY; bi[q] = 0x7fffffff; }
+          for (int c0 = 0; c0 < ntiles; c0 += 192) {
+            float v[8][3];
+            int ix[8][3];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int m = m0 + 64 * k + 16 * wid + rb + q;
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                const int j = c0 + lane + 64 * c;
+                const bool ok = m < Meff && j < ntiles;
+                v[q][c] = ok ? d.amax_val[(size_t)m * d.amax_ld + j] : -INFINITY;
+                ix[q][c] = ok ? d.amax_idx[(size_t)m * d.amax_ld + j] : 0x7fffffff;
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+              for (int c = 0; c < 3; ++c)
+                if (ix[q][c] != 0x7fffffff && (bi[q] == 0x7fffffff || v[q][c] > best[q])) { best[q] = v[q][c]; bi[q] = ix[q][c]; }   // ascending tiles: the first maximum stays
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+              const float ov = __shfl_xor(best[q], o, 64);
+              const int oi = __shfl_xor(bi[q], o, 64);
+              if (oi != 0x7fffffff && (bi[q] == 0x7fffffff || ov > best[q] || (ov == best[q] && oi < bi[q]))) { best[q] = ov; bi[q] = oi; }
+            }
+            const int m = m0 + 64 * k + 16 * wid + rb + q;
+            if (m < Meff && lane == 0) {
+              const int tok = bi[q] + 1;
+              d.lstm_tok[m] = tok;
+              if (d.lstm_seq != nullptr) d.lstm_seq[(size_t)m * d.lstm_T + d.lstm_t] = tok;
+            }
+          }
         }
       }
       if (d.lstm_ready != nullptr) {
