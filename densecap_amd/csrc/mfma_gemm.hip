@@ -388,10 +388,9 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
               }
             }
           }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
-        if (tid < BM && m0 + tid < Meff) tok_s[tid] = d.lstm_tok[m0 + tid];
+        if (tid < BM && m0 + tid < Meff) tok_s[tid] = __hip_atomic_load(d.lstm_tok + m0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
       const int Hd4 = d.N - d.amax_cols, Hd = Hd4 >> 2;
@@ -496,7 +495,13 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
       const int oi = red_i[BM + tid];
       if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
       const int m = m0 + tid;
-      if (m < Meff) {
+      if (m < Meff && d.lstm_done != nullptr) {
+        // fused decode step: write-through stores (agent-scope atomics = sc1): the partials are read by a workgroup on
+        // another XCD, whose L2 is not coherent with this one -- and NO release fence: an L2 write-back per tile (1320 a step,
+        // serialised per XCD) cost ~90 us a step when this was first written with release / acquire orderings
+        __hip_atomic_store(d.amax_val + (size_t)m * d.amax_ld + tile_n, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(d.amax_idx + (size_t)m * d.amax_ld + tile_n, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (m < Meff) {
         d.amax_val[(size_t)m * d.amax_ld + tile_n] = best;
         d.amax_idx[(size_t)m * d.amax_ld + tile_n] = bi;
       }
@@ -512,9 +517,8 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
         const int nwait = (d.amax_cols > 0 ? d.amax_cols : ((d.N + 63) / 64) * 64) / 64;
         int lastmask = 0;
         for (int b = m0 >> 6, k = 0; b <= ((min(m0 + BM, Meff) - 1) >> 6); ++b, ++k)
-          if (__hip_atomic_fetch_add(d.lstm_done + b, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == nwait - 1) lastmask |= 1 << k;
-        if (lastmask) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        *s_last = lastmask;
+          if (__hip_atomic_fetch_add(d.lstm_done + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwait - 1) lastmask |= 1 << k;
+        *s_last = lastmask;                              // (the stores above were acknowledged -- s_waitcnt vmcnt(0) -- before the count)
       }
       __syncthreads();
       const int lastmask = *s_last;
@@ -540,8 +544,9 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
               for (int c = 0; c < 3; ++c) {
                 const int j = c0 + lane + 64 * c;
                 const bool ok = m < Meff && j < ntiles;
-                v[q][c] = ok ? d.amax_val[(size_t)m * d.amax_ld + j] : -INFINITY;
-                ix[q][c] = ok ? d.amax_idx[(size_t)m * d.amax_ld + j] : 0x7fffffff;
+                // agent-scope loads (sc1): past this XCD's L2, where another XCD's write-through stores are not seen
+                v[q][c] = ok ? __hip_atomic_load(d.amax_val + (size_t)m * d.amax_ld + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
+                ix[q][c] = ok ? __hip_atomic_load(d.amax_idx + (size_t)m * d.amax_ld + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
               }
             }
 #pragma unroll
@@ -561,7 +566,7 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
             const int m = m0 + 64 * k + 16 * wid + rb + q;
             if (m < Meff && lane == 0) {
               const int tok = bi[q] + 1;
-              d.lstm_tok[m] = tok;
+              __hip_atomic_store(d.lstm_tok + m, tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               if (d.lstm_seq != nullptr) d.lstm_seq[(size_t)m * d.lstm_T + d.lstm_t] = tok;
             }
           }
@@ -572,7 +577,7 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
         __syncthreads();
         if (tid == 0)
           for (int b = m0 >> 6, k = 0; b <= ((min(m0 + BM, Meff) - 1) >> 6); ++b, ++k)
-            if ((lastmask >> k) & 1) __hip_atomic_store(d.lstm_ready + b, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if ((lastmask >> k) & 1) __hip_atomic_store(d.lstm_ready + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     return;
