@@ -444,6 +444,16 @@ def main():
 
     # ---- setup (not a step): lane workspaces, lane-count trial, warm-up incl. the collective ------------------
     lane_trials = None
+    sched_trials = None
+    if args.lanes <= 0 and args.group < 0 and on_gpu:
+        # both scheduling knobs together (results are bit-identical for every pair): the best lane count depends on the group size
+        sched_trials = model.autotuneSchedule(imgs, min(n_img, 16), H, W)
+        args.lanes, args.group = max(sched_trials, key=sched_trials.get)
+        if dist is not None:
+            lt = torch.tensor([args.lanes, args.group], dtype=torch.int32, device=coll_device)
+            dist.broadcast(lt, src=0)
+            args.lanes, args.group = int(lt[0].item()), int(lt[1].item())
+        model.setLanes(args.lanes); model.setGroup(args.group)
     if args.lanes <= 0:
         # scheduling knob only (results are bit-identical for any lanes >= 2): which count overlaps best differs
         # between otherwise identical boxes, so it is chosen by a short untimed trial on this device
@@ -770,6 +780,8 @@ def main():
                 out["lanes_trial_images_per_s"] = {str(k): v for k, v in lane_trials.items()}
             if group_trials is not None:
                 out["group_trial_images_per_s"] = {str(k): v for k, v in group_trials.items()}
+            if sched_trials is not None:
+                out["schedule_trial_images_per_s"] = {"lanes%d_group%d" % k: v for k, v in sched_trials.items()}
             if alt is not None:
                 out["value_captions_after_final_nms"] = alt   # same outputs, decode only final-NMS survivors
             out["stage_ms_serial_image"] = stage

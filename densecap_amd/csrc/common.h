@@ -48,25 +48,6 @@ struct GemmDesc {
   // entries; columns [amax_cols, N) are stored raw to C[m*ldc + (n - amax_cols)].  amax_cols = 0: every column.
   int amax_cols = 0;
   int amax_n = 0;
-  // Fused decode step (round 4; LanguageModel.lua:316-335 between two vocabulary projections): with lstm_c set, the columns
-  // [amax_cols, N) are LSTM GATE tiles -- W rows gate-interleaved (row amax_cols + 4u + g = gate g of hidden unit u, g in
-  // i,f,o,g), so that a lane of the transposed accumulator holds the four gates of a unit -- and their epilogue is the
-  // step's row-wise tail: token of the row (lstm_fixed_tok, or lstm_tok[m] once lstm_ready says the row's block is reduced),
-  // gates = xg[tok] + h.Wh, c' = f*c + i*g, h' = o*tanh(c') written to lstm_h (not the A operand: h ping-pongs).
-  // The vocabulary tiles write their (value, column) partials as always and count their arrival per 64-row block in
-  // lstm_done; the LAST tile to arrive at a block reduces its rows' partials to tokens (lstm_tok, lstm_seq) and raises
-  // lstm_ready.  The gate tiles are enqueued after the vocabulary tiles.  lstm_done without lstm_c: last step (tokens only).
-  const float* lstm_xg = nullptr;            // (V+2, 4Hd) b + Emb.Wx per token, gate-interleaved columns 4u + g
-  float* lstm_c = nullptr;                   // (M, Hd) cell state, in place
-  float* lstm_h = nullptr;                   // (M, Hd) h_{t+1}
-  int32_t* lstm_tok = nullptr;               // (M) this step's tokens (1-based)
-  int* lstm_done = nullptr;                  // (ceil(M/64)) vocabulary tiles that have stored their partials; zero before the launch
-  int* lstm_ready = nullptr;                 // (ceil(M/64)) 1 = the block's tokens are in lstm_tok; zero before the launch
-  int32_t* lstm_seq = nullptr;               // seq[m * lstm_T + lstm_t] = token; null = not recorded
-  int lstm_T = 0, lstm_t = 0;
-  int lstm_fixed_tok = -1;                   // >= 0: the rows' token is this constant (0 = no xg row): nothing to wait for
-  int lstm_zero_c = 0;                       // c = 0 on entry (image step)
-  unsigned* lstm_fault = nullptr;            // sticky word raised when a gate tile gives up waiting (checked with the results)
   // optional device-side row count: effective M = min(M, *m_dev); workgroups past it exit at once
   const int32_t* m_dev = nullptr;
   // split-K (K-split 128x128 kernel only): `splitk` workgroups share one tile, each sums a contiguous K range
@@ -159,9 +140,6 @@ hipError_t launch_iota_count(int32_t* idx, int32_t* count_out, const int32_t* co
 hipError_t launch_lstm_step_tail(const float* pval, const int32_t* pidx, int ntiles, int ld, int fixed_tok,
                                  const float* xg, const float* gates_pre, float* c, float* h, int n,
                                  const int32_t* n_dev, int Hd, int zero_c, int32_t* seq, int T, int t, hipStream_t s);
-// gate-interleaved copies for the fused decode step (GemmDesc::lstm_*): dst row / column 4u + g = src row / column g*Hd + u
-hipError_t launch_permute_gate_rows(const float* src, float* dst, int Hd, int K, hipStream_t s);
-hipError_t launch_permute_gate_cols(const float* src, float* dst, size_t rows, int Hd, hipStream_t s);
 // objectness + box regression heads + final ApplyBoxTransform (DenseCapModel.lua:134,139-140)
 hipError_t launch_recog_heads(const float* codes, const float* w5 /*(5,D): obj, 4 boxreg*/, const float* b5,
                               const float* roi_boxes, float* obj, float* trans, float* final_boxes, int n, int D,

@@ -50,8 +50,6 @@ struct Lane {
   float *roi_boxes = nullptr, *roi_feats = nullptr, *fc6_out = nullptr, *codes = nullptr;
   float *obj = nullptr, *final_trans = nullptr, *final_boxes = nullptr, *final_xyxy = nullptr;
   float *enc = nullptr, *gates = nullptr, *hstate = nullptr, *cstate = nullptr, *logits = nullptr;
-  float* hstate2 = nullptr;     // fused decode step: h ping-pongs (the gate tiles write h_{t+1} while arg-max tiles still read h_t)
-  char* lm_sync = nullptr;      // fused decode step: per decode block [T][rows] tokens + [T][2][rows/64] arrival counters / ready flags
   int32_t *tok = nullptr, *seq = nullptr;
   float *out_boxes = nullptr, *out_scores = nullptr, *out_feats = nullptr;
   float* splitk_ws = nullptr;   // split-K partial tiles (<= 256 tiles of 128x128)
@@ -116,10 +114,6 @@ struct dc_ctx {
   float *out_w = nullptr, *out_b = nullptr, *anchors = nullptr;
   float* dec_w = nullptr;   // (V1pad + 4Hd, Hd): rows [0,V+1) = lm_out_w, zero rows up to V1pad (multiple of 64), then Wh^T
   int V1pad = 0;
-  // fused decode step (round 4): the same operand with the Wh^T rows gate-interleaved (row V1pad + 4u + g = gate g of unit u)
-  // and the xg table with its columns interleaved the same way, so that one lane of a gate tile holds i,f,o,g of a unit
-  float *dec_wp = nullptr, *xg_p = nullptr;
-  bool decode_fused = true;  // dc_debug_set "decode_fused": 0 = step GEMM + row kernel (the round-3 route, kept as the reference)
   std::vector<std::unique_ptr<Lane>> lanes;
   // MFMA profile
   bool prof = false;
@@ -183,16 +177,6 @@ hipEvent_t prof_event(dc_ctx* ctx) {
   return e;
 }
 
-// sticky device word raised by a workgroup that gave up waiting for another one (stream-K owner, gate tile of a fused decode
-// step); copied to the host with the results
-int ensure_fault_word(dc_ctx* ctx) {
-  if (ctx->fault_dev != nullptr) return DC_OK;
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&ctx->fault_dev), 64));
-  ctx->owned.push_back(ctx->fault_dev);
-  HIPCHK(hipMemset(ctx->fault_dev, 0, 64));
-  return DC_OK;
-}
-
 // every MFMA contraction goes through here (optionally bracketed by HIP events).  `ws` (optional) is a
 // scratch buffer of ws_floats floats on the same stream: problems with few tiles and a long K are split
 // along K over several workgroups per tile and finished by a small reduce kernel.
@@ -237,7 +221,10 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, const Ws& w = Ws(
     if (e == hipSuccess) {
       GemmDesc b = d;
       b.m_begin = m_split; b.a_rows = d.M;
-      (void)ensure_fault_word(ctx);
+      if (ctx->fault_dev == nullptr && hipMalloc(reinterpret_cast<void**>(&ctx->fault_dev), 64) == hipSuccess) {
+        ctx->owned.push_back(ctx->fault_dev);
+        (void)hipMemset(ctx->fault_dev, 0, 64);
+      }
       b.sk_fault = ctx->fault_dev;
       e = launch_mfma_gemm_sk(b, pl.sk_wgs, pl.sk_np, ws, s);
     }
@@ -311,11 +298,6 @@ int conv3x3_pool(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, co
 }
 
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
-// fused decode step: a block of rows [r0, r0+n) (r0 a multiple of 128) owns bytes [lm_sync_off(r0,T), +lm_sync_bytes(n,T))
-// = [T][n] int32 tokens, then [T][2][ceil(n/64)] arrival counters and ready flags; zeroed once per decode of that block
-size_t lm_sync_off(size_t r0, int T) { return r0 * T * 4 + (r0 / 64) * 2 * T * 4; }
-size_t lm_sync_used(size_t n, int T) { return n * T * 4 + ((n + 63) / 64) * 2 * T * 4; }      // <= off(r0 + roundup(n, 64)) - off(r0)
-size_t lm_sync_bytes(size_t n, int T) { return lm_sync_used((n + 127) / 128 * 128, T) + 256; }
 // num_proposals = -1 (LocalizationLayer.lua:322-324: uncapped RPN NMS): capacity = every anchor of this image size
 int effective_proposals(const dc_ctx* ctx, int H, int W);
 constexpr size_t kSplitkWsFloats = (size_t)3200 * 128 * 128;  // 200 MiB per lane: split-K partial outputs (up to 8 x a four-image group's 4 x 384 x 4096 fc6 rows), tail plans, stream-K slots
@@ -383,8 +365,6 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P, int G) {
       {(void**)&L.enc, GP * E * 4},
       {(void**)&L.gates, GP * 4 * Hd * 4},
       {(void**)&L.hstate, GP * Hd * 4},
-      {(void**)&L.hstate2, GP * Hd * 4},
-      {(void**)&L.lm_sync, lm_sync_bytes(GP, Tn)},
       {(void**)&L.cstate, GP * Hd * 4},
       {(void**)&L.logits, GP * V1 * 4},
       {(void**)&L.tok, GP * 4},
@@ -473,45 +453,6 @@ int lm_sample_parts(dc_ctx* ctx, Lane& L, const float* codes, const LmPart* part
       DCCHK(run_gemm(ctx, g, s));
     }
     KCHK(launch_lstm_step_tail(nullptr, nullptr, 0, 0, V1, ctx->xg, gates, cstate, hstate, p.n, n_dev, Hd, 0, nullptr, T, 0, s));
-  }
-  // ---- fused steps (round 4): ONE launch per step.  The vocabulary tiles merge their row maxima into a 64-bit key per row
-  // (atomic max), the gate tiles -- enqueued after them -- wait for the keys of their rows and run the step's row-wise tail in
-  // their epilogue: token, xg[token] + h.Wh, LSTM point-wise, h_{t+1} (ping-pong), c, seq.  Same arithmetic per element as
-  // the GEMM + row-kernel route below (kept as the reference: dc_debug_set "decode_fused" 0); bit-identical tokens.
-  bool fused = ctx->decode_fused && L.hstate2 != nullptr && L.lm_sync != nullptr;
-  for (int pi = 0; pi < nparts; ++pi) fused = fused && parts[pi].n <= 16384 && parts[pi].r0 % 128 == 0;
-  if (fused) {
-    DCCHK(ensure_fault_word(ctx));
-    for (int pi = 0; pi < nparts; ++pi) {
-      const LmPart& p = parts[pi];
-      HIPCHK(hipMemsetAsync(L.lm_sync + lm_sync_off(p.r0, T), 0, lm_sync_used(p.n, T), p.s));
-    }
-    for (int t = 0; t < T; ++t) {
-      const bool last = t == T - 1;
-      for (int pi = 0; pi < nparts; ++pi) {
-        const LmPart& p = parts[pi];
-        float* const hbuf[2] = {L.hstate + (size_t)p.r0 * Hd, L.hstate2 + (size_t)p.r0 * Hd};
-        char* const sync = L.lm_sync + lm_sync_off(p.r0, T);
-        const int nb = (p.n + 63) / 64;
-        GemmDesc v;
-        v.A = hbuf[t & 1]; v.W = ctx->dec_wp; v.bias = ctx->out_b; v.M = p.n; v.K = Hd; v.m_dev = n_dev; v.plan_M = plan;
-        v.amax_val = L.logits + (size_t)p.r0 * 2 * ntn;
-        v.amax_idx = reinterpret_cast<int32_t*>(v.amax_val + (size_t)p.n * ntn);
-        v.amax_ld = ntn;
-        v.lstm_tok = reinterpret_cast<int32_t*>(sync) + (size_t)t * p.n;
-        v.lstm_done = reinterpret_cast<int*>(sync + (size_t)p.n * T * 4) + (size_t)t * 2 * nb;
-        v.lstm_ready = v.lstm_done + nb;
-        v.lstm_seq = seq_out + (size_t)p.r0 * T; v.lstm_T = T; v.lstm_t = t; v.lstm_fault = ctx->fault_dev;
-        if (last) {
-          v.N = V1; v.ldc = V1;
-        } else {
-          v.N = V1pad + 4 * Hd; v.amax_cols = V1pad; v.amax_n = V1; v.C = L.gates + (size_t)p.r0 * 4 * Hd; v.ldc = 4 * Hd;
-          v.lstm_xg = ctx->xg_p; v.lstm_c = L.cstate + (size_t)p.r0 * Hd; v.lstm_h = hbuf[(t & 1) ^ 1];
-        }
-        DCCHK(run_gemm(ctx, v, p.s));
-      }
-    }
-    return DC_OK;
   }
   for (int t = 0; t < T; ++t) {
     const bool last = t == T - 1;
@@ -806,11 +747,9 @@ int harvest(dc_ctx* ctx, Lane& L) {
     if (*reinterpret_cast<const uint32_t*>(hs + 68) != 0u) {
       (void)hipMemset(ctx->fault_dev, 0, 64);
       ctx->tail_mode = 1;           // stop sharing tiles between workgroups on this ctx
-      ctx->decode_fused = false;    // ... and stop waiting inside the decode step
       L.pending = nullptr;
-      return ctx->fail(DC_E_HIP, "a workgroup gave up waiting for another one of its launch within the spin bound (stream-K partner / "
-                                 "fused decode step; GPU shared with another job?); this ctx now uses the K-split tail plan and the "
-                                 "GEMM + row-kernel decode -- repeat the call");
+      return ctx->fail(DC_E_HIP, "stream-K: a workgroup's partner never published its partial tile within the spin bound (GPU "
+                                 "shared with another job?); this ctx now uses the K-split tail plan -- repeat the call");
     }
     int K = *reinterpret_cast<const int32_t*>(hs);
     if (L.pending_feats) {
@@ -1069,13 +1008,6 @@ int dc_load_weights(dc_ctx* ctx, const dc_weights* w) {
     HIPCHK(hipMemcpy(ctx->dec_w, w->lm_out_w, (size_t)(V + 1) * Hd * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->dec_w + (size_t)ctx->V1pad * Hd, ctx->whT, (size_t)4 * Hd * Hd * 4, hipMemcpyDeviceToDevice));
     ctx->out_w = ctx->dec_w;
-    // gate-interleaved twins for the fused decode step
-    DCCHK(dev_alloc(ctx, (void**)&ctx->dec_wp, rows * Hd * 4));
-    HIPCHK(hipMemcpy(ctx->dec_wp, ctx->dec_w, (size_t)ctx->V1pad * Hd * 4, hipMemcpyDeviceToDevice));
-    KCHK(launch_permute_gate_rows(ctx->whT, ctx->dec_wp + (size_t)ctx->V1pad * Hd, Hd, Hd, s));
-    DCCHK(dev_alloc(ctx, (void**)&ctx->xg_p, (size_t)(V + 2) * 4 * Hd * 4));
-    KCHK(launch_permute_gate_cols(ctx->xg, ctx->xg_p, (size_t)V + 2, Hd, s));
-    HIPCHK(hipStreamSynchronize(s));
   }
   DCCHK(upload(ctx, &ctx->out_b, w->lm_out_b, (size_t)V + 1));
   DCCHK(upload(ctx, &ctx->anchors, w->anchors, (size_t)2 * k));
@@ -1336,11 +1268,6 @@ int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value) {
     ctx->force_cfg = (int)value;
     return DC_OK;
   }
-  if (strcmp(name, "decode_fused") == 0) {
-    if (value != 0 && value != 1) return ctx->fail(DC_E_INVALID, "dc_debug_set: decode_fused must be 0 or 1");
-    ctx->decode_fused = value != 0;
-    return DC_OK;
-  }
   if (strcmp(name, "plan_mode") == 0) {
     if (value < -1 || value > 1) return ctx->fail(DC_E_INVALID, "dc_debug_set: plan_mode must be -1, 0 or 1");
     ctx->plan_mode = (int)value;
@@ -1397,8 +1324,7 @@ static int check_sk_fault(dc_ctx* ctx, const char* who) {
   if (f == 0) return DC_OK;
   (void)hipMemset(ctx->fault_dev, 0, 64);
   ctx->tail_mode = 1;
-  ctx->decode_fused = false;
-  return ctx->fail(DC_E_HIP, "%s: a workgroup gave up waiting for another one of its launch within the spin bound", who);
+  return ctx->fail(DC_E_HIP, "%s: stream-K partner never published its partial tile within the spin bound", who);
 }
 
 // ---- per-op entry points --------------------------------------------------------------------
@@ -1530,9 +1456,9 @@ int dc_op_lm_sample(dc_ctx* ctx, const float* codes, int n, int32_t* tokens) {
   Lane& L = lane0(ctx);
   // private scratch for n rows
   const int E = ctx->E, Hd = ctx->Hd, V1 = ctx->V + 1;
-  struct Sav { float *enc, *gates, *h, *c, *logits, *h2; char* sync; int32_t* tok; } sv{L.enc, L.gates, L.hstate, L.cstate, L.logits, L.hstate2, L.lm_sync, L.tok};
-  const size_t bytes = al((size_t)n * E * 4) + al((size_t)n * 4 * Hd * 4) + 3 * al((size_t)n * Hd * 4) +
-                       al((size_t)n * V1 * 4) + al((size_t)n * 4) + al(lm_sync_bytes(n, ctx->T));
+  struct Sav { float *enc, *gates, *h, *c, *logits; int32_t* tok; } sv{L.enc, L.gates, L.hstate, L.cstate, L.logits, L.tok};
+  const size_t bytes = al((size_t)n * E * 4) + al((size_t)n * 4 * Hd * 4) + 2 * al((size_t)n * Hd * 4) +
+                       al((size_t)n * V1 * 4) + al((size_t)n * 4);
   char* base = nullptr;
   HIPCHK(hipMalloc((void**)&base, bytes));
   char* p = base;
@@ -1541,18 +1467,15 @@ int dc_op_lm_sample(dc_ctx* ctx, const float* codes, int n, int32_t* tokens) {
   L.hstate = (float*)p; p += al((size_t)n * Hd * 4);
   L.cstate = (float*)p; p += al((size_t)n * Hd * 4);
   L.logits = (float*)p; p += al((size_t)n * V1 * 4);
-  L.tok = (int32_t*)p; p += al((size_t)n * 4);
-  L.hstate2 = (float*)p; p += al((size_t)n * Hd * 4);
-  L.lm_sync = p;
+  L.tok = (int32_t*)p;
   int rc = ctx->beam_size > 0 ? lm_beamsearch(ctx, L, codes, n, tokens, s) : lm_sample(ctx, L, codes, n, 0, nullptr, tokens);
   hipError_t e2 = hipStreamSynchronize(s);
   L.enc = sv.enc; L.gates = sv.gates; L.hstate = sv.h; L.cstate = sv.c; L.logits = sv.logits; L.tok = sv.tok;
-  L.hstate2 = sv.h2; L.lm_sync = sv.sync;
   hipFree(base);
   prof_collect(ctx);
   if (rc != DC_OK) return rc;
   if (e2 != hipSuccess) return ctx->fail(DC_E_HIP, "lm_sample sync: %s", hipGetErrorString(e2));
-  return check_sk_fault(ctx, "dc_op_lm_sample");
+  return DC_OK;
 }
 
 }  // extern "C"

@@ -470,31 +470,6 @@ hipError_t launch_lstm_pointwise(const float* gates, float* c, float* h, int n, 
                      zero_c);
   return hipGetLastError();
 }
-// gate-interleaved copies for the fused decode step: row (or column) 4u + g of dst = row (column) g*Hd + u of src
-__global__ void permute_gate_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int Hd, int K) {
-  const size_t total = (size_t)4 * Hd * K;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int rp = (int)(i / K), k = (int)(i - (size_t)rp * K);
-    dst[i] = src[(size_t)((rp & 3) * Hd + (rp >> 2)) * K + k];
-  }
-}
-__global__ void permute_gate_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t rows, int Hd) {
-  const size_t total = rows * 4 * Hd;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t row = i / (4 * Hd);
-    const int cp = (int)(i - row * 4 * Hd);
-    dst[i] = src[row * 4 * Hd + (cp & 3) * Hd + (cp >> 2)];
-  }
-}
-hipError_t launch_permute_gate_rows(const float* src, float* dst, int Hd, int K, hipStream_t s) {
-  hipLaunchKernelGGL(permute_gate_rows_kernel, dim3(grid_for((size_t)4 * Hd * K)), dim3(256), 0, s, src, dst, Hd, K);
-  return hipGetLastError();
-}
-hipError_t launch_permute_gate_cols(const float* src, float* dst, size_t rows, int Hd, hipStream_t s) {
-  hipLaunchKernelGGL(permute_gate_cols_kernel, dim3(grid_for(rows * 4 * Hd)), dim3(256), 0, s, src, dst, rows, Hd);
-  return hipGetLastError();
-}
-
 hipError_t launch_lstm_step_tail(const float* pval, const int32_t* pidx, int ntiles, int ld, int fixed_tok,
                                  const float* xg, const float* gates_pre, float* c, float* h, int n,
                                  const int32_t* n_dev, int Hd, int zero_c, int32_t* seq, int T, int t, hipStream_t s) {

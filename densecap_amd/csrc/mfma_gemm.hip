@@ -85,19 +85,6 @@ __device__ __forceinline__ float pool_window(const GemmDesc& d, int win, float v
   return best;
 }
 
-// ---- fused decode step helpers -------------------------------------------------------------------------------------------
-// torch-rnn nn.LSTM point-wise step on one hidden unit, the arithmetic of lstm_step_tail_kernel operation for operation
-// (every product and sum rounded on its own: no contraction)
-__device__ __forceinline__ float lstm_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
-__device__ __forceinline__ void lstm_unit(float gi, float gf, float go, float gg, float cprev, float& c_out, float& h_out) {
-  const float ig = lstm_sigmoid(gi), fg = lstm_sigmoid(gf), og = lstm_sigmoid(go);
-  const float gt = tanhf(gg);
-  const float cn = __fadd_rn(__fmul_rn(fg, cprev), __fmul_rn(ig, gt));
-  c_out = cn;
-  h_out = __fmul_rn(og, tanhf(cn));
-}
-constexpr unsigned LSTM_SPIN_LIMIT = 1u << 22;
-
 // =========================================================================================
 // v2: LDS-DMA (buffer_load ... lds) ring of three stages (two for the 128x64 tiles of launches with >= 3 tiles per CU:
 // three workgroups per CU), fragment double-buffering, ONE barrier per K-tile placed in the MIDDLE of the tile's MFMA
@@ -367,66 +354,6 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
     // acc[i][j] is the transposed block: this lane's row is m = m0 + wm*32*TM + i*32 + (lane&31); register e is column
     // n = n0 + wn*32*TN + j*32 + 8*(e>>2) + 4*hsel + (e&3), ascending in (j, e).  Ties: lower column (first max).
     const int an = d.amax_cols > 0 ? d.amax_n : d.N;           // real vocabulary columns
-    if (d.lstm_c != nullptr && n0 >= d.amax_cols) {
-      // ---- LSTM gate tile of a fused decode step: this lane owns rows m (one per 32-row block i) and, per group of four
-      // consecutive registers, the gates i,f,o,g of hidden unit u = (column - amax_cols) / 4
-      __syncthreads();                                         // the operand ring is reused for the rows' tokens
-      int* const tok_s = reinterpret_cast<int*>(smem);         // [BM]
-      if (d.lstm_fixed_tok >= 0) {
-        if (tid < BM) tok_s[tid] = d.lstm_fixed_tok;
-      } else {
-        // the arg-max tiles of these rows were enqueued before this tile; the last of them to finish reduces the rows'
-        // partial maxima to tokens and raises the block's flag
-        if (tid == 0) {
-          for (int b = m0 >> 6; b <= ((min(m0 + BM, Meff) - 1) >> 6); ++b) {
-            unsigned spins = 0;
-            while (__hip_atomic_load(d.lstm_ready + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-              __builtin_amdgcn_s_sleep(2);
-              if (++spins > LSTM_SPIN_LIMIT) {               // report, do not hang (the host falls back to the unfused route)
-                if (d.lstm_fault != nullptr) __hip_atomic_store(d.lstm_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-              }
-            }
-          }
-        }
-        __syncthreads();
-        if (tid < BM && m0 + tid < Meff) tok_s[tid] = __hip_atomic_load(d.lstm_tok + m0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __syncthreads();
-      const int Hd4 = d.N - d.amax_cols, Hd = Hd4 >> 2;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int ml = wm * 32 * TM + i * 32 + r;
-        const int m = m0 + ml;
-        if (m >= Meff) continue;
-        const int tok = tok_s[ml];
-        const float* xrow = tok > 0 ? d.lstm_xg + (size_t)(tok - 1) * Hd4 : nullptr;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const int nb = n0 + wn * 32 * TN + j * 32 + 8 * q4 + 4 * hsel - d.amax_cols;     // gate column 4u of this register group
-            if (nb + 3 >= Hd4) continue;
-            const int u = nb >> 2;
-            float gi = acc[i][j][q4 * 4 + 0], gf = acc[i][j][q4 * 4 + 1], go = acc[i][j][q4 * 4 + 2], gg = acc[i][j][q4 * 4 + 3];
-            if (d.bias != nullptr && d.lstm_fixed_tok >= 0) {     // image step: gates = (b + enc.Wx): the bias rides in the GEMM
-              const f32x4 bv = *reinterpret_cast<const f32x4*>(d.bias + nb);
-              gi = gi + bv[0]; gf = gf + bv[1]; go = go + bv[2]; gg = gg + bv[3];
-            }
-            if (xrow != nullptr) {                                // (b + x.Wx) + h.Wh, torch-rnn's association
-              const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + nb);
-              gi = xv[0] + gi; gf = xv[1] + gf; go = xv[2] + go; gg = xv[3] + gg;
-            }
-            const size_t ci = (size_t)m * Hd + u;
-            const float cprev = d.lstm_zero_c ? 0.f : d.lstm_c[ci];
-            float cn, hn;
-            lstm_unit(gi, gf, go, gg, cprev, cn, hn);
-            d.lstm_c[ci] = cn;
-            d.lstm_h[ci] = hn;
-          }
-      }
-      return;
-    }
     if (d.amax_cols > 0 && n0 >= d.amax_cols) {
       // ---- columns past the arg-max prefix (the h.Wh half of the next step's gates): raw store of the transposed
       // blocks; a lane owns row m and writes 16-byte runs of 4 consecutive columns
@@ -495,89 +422,9 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
       const int oi = red_i[BM + tid];
       if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
       const int m = m0 + tid;
-      if (m < Meff && d.lstm_done != nullptr) {
-        // fused decode step: write-through stores (agent-scope atomics = sc1): the partials are read by a workgroup on
-        // another XCD, whose L2 is not coherent with this one -- and NO release fence: an L2 write-back per tile (1320 a step,
-        // serialised per XCD) cost ~90 us a step when this was first written with release / acquire orderings
-        __hip_atomic_store(d.amax_val + (size_t)m * d.amax_ld + tile_n, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(d.amax_idx + (size_t)m * d.amax_ld + tile_n, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else if (m < Meff) {
+      if (m < Meff) {
         d.amax_val[(size_t)m * d.amax_ld + tile_n] = best;
         d.amax_idx[(size_t)m * d.amax_ld + tile_n] = bi;
-      }
-    }
-    if (d.lstm_done != nullptr) {
-      // ---- fused decode step: arrival.  This tile's partial maxima are ordered before the counter (release: the per-XCD
-      // L2s are not coherent); the LAST tile to arrive at a 64-row block reduces the block's partials to tokens -- ascending
-      // column tiles, first maximum on ties: lstm_step_tail_kernel's rule -- and raises the block's flag for the gate tiles.
-      int* const s_last = reinterpret_cast<int*>(smem + 4 * BM);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        const int nwait = (d.amax_cols > 0 ? d.amax_cols : ((d.N + 63) / 64) * 64) / 64;
-        int lastmask = 0;
-        for (int b = m0 >> 6, k = 0; b <= ((min(m0 + BM, Meff) - 1) >> 6); ++b, ++k)
-          if (__hip_atomic_fetch_add(d.lstm_done + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwait - 1) lastmask |= 1 << k;
-        *s_last = lastmask;                              // (the stores above were acknowledged -- s_waitcnt vmcnt(0) -- before the count)
-      }
-      __syncthreads();
-      const int lastmask = *s_last;
-      if (lastmask == 0) return;
-      const int ntiles = (d.amax_cols > 0 ? d.amax_cols : ((d.N + 63) / 64) * 64) / 64;
-      // a wave takes 16 rows of the block, eight at a time: a row's partials are contiguous (lane l reads column tiles l,
-      // l + 64, l + 128: coalesced), all loads of the eight rows are in flight together -- they come from the other XCDs'
-      // write-backs, i.e. from the Infinity Cache, and a dependent chain of them would cost a microsecond per link
-      for (int k = 0; k < BM / 64; ++k) {
-        if (!((lastmask >> k) & 1)) continue;
-        for (int rb = 0; rb < 16; rb += 8) {
-          float best[8];
-          int bi[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) { best[q] = -INFINITY; bi[q] = 0x7fffffff; }
-          for (int c0 = 0; c0 < ntiles; c0 += 192) {
-            float v[8][3];
-            int ix[8][3];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              const int m = m0 + 64 * k + 16 * wid + rb + q;
-#pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                const int j = c0 + lane + 64 * c;
-                const bool ok = m < Meff && j < ntiles;
-                // agent-scope loads (sc1): past this XCD's L2, where another XCD's write-through stores are not seen
-                v[q][c] = ok ? __hip_atomic_load(d.amax_val + (size_t)m * d.amax_ld + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
-                ix[q][c] = ok ? __hip_atomic_load(d.amax_idx + (size_t)m * d.amax_ld + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
-              }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-#pragma unroll
-              for (int c = 0; c < 3; ++c)
-                if (ix[q][c] != 0x7fffffff && (bi[q] == 0x7fffffff || v[q][c] > best[q])) { best[q] = v[q][c]; bi[q] = ix[q][c]; }   // ascending tiles: the first maximum stays
-          }
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-              const float ov = __shfl_xor(best[q], o, 64);
-              const int oi = __shfl_xor(bi[q], o, 64);
-              if (oi != 0x7fffffff && (bi[q] == 0x7fffffff || ov > best[q] || (ov == best[q] && oi < bi[q]))) { best[q] = ov; bi[q] = oi; }
-            }
-            const int m = m0 + 64 * k + 16 * wid + rb + q;
-            if (m < Meff && lane == 0) {
-              const int tok = bi[q] + 1;
-              __hip_atomic_store(d.lstm_tok + m, tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (d.lstm_seq != nullptr) d.lstm_seq[(size_t)m * d.lstm_T + d.lstm_t] = tok;
-            }
-          }
-        }
-      }
-      if (d.lstm_ready != nullptr) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0)
-          for (int b = m0 >> 6, k = 0; b <= ((min(m0 + BM, Meff) - 1) >> 6); ++b, ++k)
-            if ((lastmask >> k) & 1) __hip_atomic_store(d.lstm_ready + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     return;
@@ -651,15 +498,7 @@ template <int TM, int TN, bool CONV, int NS, bool AMAX = false>
 __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   start_stagger(d);
-  int bid;
-  if (AMAX && d.lstm_c != nullptr) {
-    // fused decode step: the arg-max tiles first (XCD-aware among themselves), the gate tiles that wait for them LAST
-    // (m-fastest order: tile index < TA <=> arg-max column tile)
-    const int TA = ntm * (d.amax_cols / (64 * TN)), b = blockIdx.x;
-    bid = b < TA ? xcd_remap(b, TA) : TA + xcd_remap(b - TA, ntm * ntn - TA);
-  } else {
-    bid = xcd_remap(blockIdx.x, ntm * ntn);
-  }
+  const int bid = xcd_remap(blockIdx.x, ntm * ntn);
   int tile_m, tile_n;
   if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
   else           { tile_n = bid % ntn; tile_m = bid / ntn; }
@@ -691,13 +530,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_mixed_kernel(GemmDesc d, int
   }
   const int b = blockIdx.x;
   if (b < nbig) {
-    int bid;
-    if (AMAX && d.lstm_c != nullptr) {                 // fused decode step: arg-max tiles first, gate tiles last (see v2_kernel)
-      const int TA = ntm * (d.amax_cols / 64);
-      bid = b < TA ? xcd_remap(b, min(nbig, TA)) : TA + xcd_remap(b - TA, nbig - TA);
-    } else {
-      bid = xcd_remap(b, nbig);
-    }
+    const int bid = xcd_remap(b, nbig);
     int tile_m, tile_n;
     if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
     else           { tile_n = bid % ntn; tile_m = bid / ntn; }
@@ -1221,9 +1054,6 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   if (d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0) return hipErrorInvalidValue;   // K-split kernel features
   if constexpr (!CONV && TN == 1) {
     if (d.amax_val != nullptr) {
-      if (d.lstm_c != nullptr && (!m_fastest || d.amax_cols % 64 || (d.N - d.amax_cols) % 64 || d.lstm_h == nullptr ||
-                                  (d.lstm_fixed_tok < 0 && (d.lstm_tok == nullptr || d.lstm_done == nullptr || d.lstm_ready == nullptr || d.lstm_xg == nullptr))))
-        return hipErrorInvalidValue;                   // gate tiles must come after the arg-max tiles they wait for
       if (d.amax_cols % BN != 0 || (d.amax_cols > 0 && (d.C == nullptr || d.amax_n > d.amax_cols || d.amax_cols > d.N)))
         return hipErrorInvalidValue;
       const size_t lds3 = (size_t)3 * (BM + BN) * BK * sizeof(float);

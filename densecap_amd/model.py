@@ -182,6 +182,27 @@ class DenseCapModel:
         self.setLanes(max(rates, key=rates.get))
         return rates
 
+    def autotuneSchedule(self, dev_ptr, n, H, W, lanes=(2, 3, 4), groups=(1, 2, 4), reps=2):
+        """Pick the lane count AND the images per group together (both are pure scheduling knobs: results are bit-identical
+        for any lanes >= 2 and any group): the best lane count depends on the group size -- 300 proposals: 2 lanes x groups
+        of four 312 images/s, 4 lanes x groups of four 299, 2 lanes x single images 285.  Returns {(lanes, group): images/s};
+        the best pair is left set."""
+        import time
+        rates = {}
+        for l in lanes:
+            for g in groups:
+                self.setLanes(l); self.setGroup(g)
+                self.forward_batch_device(dev_ptr, min(n, l * g), H, W)      # workspaces of this shape exist before timing
+                best = 0.0
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    self.forward_batch_device(dev_ptr, n, H, W)
+                    best = max(best, n / (time.perf_counter() - t0))
+                rates[(l, g)] = best
+        l, g = max(rates, key=rates.get)
+        self.setLanes(l); self.setGroup(g)
+        return rates
+
     def autotuneGroup(self, dev_ptr, n, H, W, candidates=(1, 2, 4), reps=2):
         """Pick the images-per-group setting (dc_set_group: a scheduling knob like the lane count -- results are
         bit-identical) at the current lane count.  With few proposals per image the RoI stages of one image leave the

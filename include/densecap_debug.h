@@ -41,10 +41,6 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
  *                        128x128 / 128x64 / 64x64 tiles and no split-K, 4 = planned tiles, no split-K, 5 = 128x128 tiles on the 2x2-wave kernel
  *                        with a two-stage ring (two workgroups per CU), 6 = the K-split 128x128 kernel whatever K.  Changes the fp32
  *                        summation order with the kernel family; never set by the product path.
- *   "decode_fused"       1 (default) = one launch per greedy decode step: the vocabulary tiles merge their row maxima with a
- *                        64-bit atomic max, the LSTM gate tiles of the same launch (enqueued last) wait for the keys of their
- *                        rows and run the step's row-wise tail in their epilogue; 0 = the step GEMM followed by a row kernel
- *                        (the round-3 route, kept as the reference).  Bit-identical tokens either way.
  *   "plan_mode"          -1 (default) = contraction planning follows dc_set_lanes (1 lane = single-image planning: stream-K /
  *                        tail plans over partial last rounds); 0 / 1 force multi-lane / single-image planning whatever the lane
  *                        count -- lets a one-stream profiler pass run exactly the kernels of the multi-lane schedule.

@@ -774,45 +774,3 @@ def test_beam_scratch_is_recarved_when_beam_or_chunk_grows():
         np.testing.assert_array_equal(got, want)
         np.testing.assert_array_equal(again, want)
         assert want.min() >= 1 and want.max() <= 301
-
-
-def test_fused_decode_step_equals_gemm_plus_row_kernel(model, weights):
-    """Round 4: one launch per decode step -- the vocabulary tiles merge their row maxima by 64-bit atomic max, the gate tiles
-    of the same launch wait for their rows' keys and run the step's tail (token, xg[token] + h.Wh, LSTM point-wise, h ping-pong)
-    in their epilogue -- against the round-3 route (step GEMM + row kernel; dc_debug_set "decode_fused" 0): IDENTICAL tokens
-    over all 15 steps at row counts either side of every tile boundary, call after call (keys and counters are re-zeroed per
-    decode), on both tile routes (64x64 below ~190 rows, 128x64 with a 64x64 last round above)."""
-    from densecap_amd._lib import check
-    ctx = model.ctx
-    rng = np.random.default_rng(21)
-    try:
-        for n in (1, 7, 50, 64, 65, 127, 128, 129, 190, 300, 1000, 1500, 2100):
-            codes = np.maximum(rng.standard_normal((n, 4096)), 0).astype(np.float32)
-            cd = ctx.to_device(codes); td = ctx.empty((n, 15), np.int32)
-            outs = {}
-            for fused in (0, 1, 1, 0, 1):
-                check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_fused", fused), "dc_debug_set")
-                check(ctx.h, ctx.lib.dc_op_lm_sample(ctx.h, cd.ptr, n, td.ptr), "dc_op_lm_sample")
-                outs.setdefault(fused, []).append(td.numpy().copy())
-            for t in outs[1] + outs[0][1:]:
-                np.testing.assert_array_equal(t, outs[0][0], err_msg="fused decode != GEMM + row kernel at %d rows" % n)
-            assert outs[0][0].min() >= 1 and outs[0][0].max() <= weights["vocab_size"] + 1
-            cd.free(); td.free()
-        # whole images, both schedules (two-stream decode in single-image mode, device-side row counts with captions after
-        # the final NMS, groups of images): fused == unfused bit for bit
-        from densecap_amd.weights import make_synthetic_image
-        imgs = np.stack([make_synthetic_image(224, 288, 60 + s) for s in range(3)])
-        for lanes, order, group in ((1, False, 1), (3, False, 2), (3, True, 1), (1, True, 1)):
-            model.setLanes(lanes); model.setCaptionOrder(order); model.setGroup(group)
-            model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=300)
-            res = {}
-            for fused in (0, 1):
-                check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_fused", fused), "dc_debug_set")
-                res[fused] = model.forward_batch(imgs)
-            for a, b in zip(res[0], res[1]):
-                for x, y in zip(a, b):
-                    np.testing.assert_array_equal(x, y)
-                assert len(a[0]) > 0
-    finally:
-        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"decode_fused", 1), "dc_debug_set")
-        model.setLanes(3); model.setCaptionOrder(False); model.setGroup(0)
