@@ -38,8 +38,9 @@ struct GemmDesc {
   const float* rowterm = nullptr;
   const int32_t* rowidx = nullptr;   // values are 1-based token ids -> row = id-1
   int rowterm_ld = 0;
-  // optional fused row arg-max (vocab projection): instead of storing C, every (row, N-tile) writes its
-  // best (value, column) to amax_val/amax_idx[(m * amax_ld) + tile_n]; C may be null.
+  // optional fused row arg-max (vocab projection): instead of storing C, every (row, 32-column half of a 64-column tile)
+  // writes its best (value, column) to amax_val/amax_idx[m * amax_ld + 2 * tile_n + half] (columns ascend with the slot);
+  // amax_ld >= 2 * ceil(N / 64); C may be null.
   float* amax_val = nullptr;
   int32_t* amax_idx = nullptr;
   int amax_ld = 0;

@@ -426,7 +426,7 @@ int lm_sample_parts(dc_ctx* ctx, Lane& L, const float* codes, const LmPart* part
   // precomputed xg = b + Emb.Wx table) is added where the token is produced.  Per element the arithmetic and its order
   // are those of torch-rnn's nn.LSTM: (b + x.Wx) + h.Wh, sigmoid/tanh, c' = f*c + i*g, h' = o*tanh(c').
   const int E = ctx->E, Hd = ctx->Hd, V1 = ctx->V + 1, T = ctx->T, D = ctx->D;
-  const int V1pad = ctx->V1pad, ntn = V1pad / 64;       // arg-max partials per row: one (value, column) per 64-column tile
+  const int V1pad = ctx->V1pad, ntn = V1pad / 32;       // arg-max partials per row: one (value, column) per 32-column half of a 64-column tile
   for (int pi = 0; pi < nparts; ++pi) {
     const LmPart& p = parts[pi];
     hipStream_t s = p.s;

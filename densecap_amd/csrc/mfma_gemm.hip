@@ -34,6 +34,12 @@
 namespace {
 
 constexpr int BK = 32;
+// timing-only ablation build ABL_EPI_NO_STORE: the 2x2-wave kernel computes its epilogue but does not store it
+#if defined(ABL_EPI_NO_STORE) && defined(__HIP_DEVICE_COMPILE__)
+#define EPI_STORE(lhs, val) asm volatile("" ::"v"(val))
+#else
+#define EPI_STORE(lhs, val) (lhs) = (val)
+#endif
 // K-tiles from which the K-split 128x128 kernel (one workgroup per CU) beats the 128x64 kernel.  32 while the latter ran two
 // workgroups per CU; with the two-stage ring's three (round 3) the crossover moved past K = 2304: conv2_2 (K = 1152)
 // 340 -> 285 us, conv3_1 185 -> 152, conv3_2 / conv3_3 (K = 2304) 332 -> 285 / 315 -> 277 in the multi-lane planning,
@@ -276,8 +282,33 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
 #pragma unroll
   for (int p = 0; p < (NS == 2 ? 2 : NS - 1); ++p)
     if (p < nkt) issue(p, p);
+  // Arg-max tiles: this lane's 4 x 4 bias values per column block are requested NOW, behind the first operand tiles, and
+  // wait in registers: the epilogue then starts with nothing to fetch.  (Round 4: a tile's epilogue is NOT hidden by its two
+  // co-resident workgroups -- a build without epilogues ran the decode step 10 % faster -- so every dependent memory round
+  // trip and barrier in it costs the launch.)
+  f32x4 amax_bias[AMAX ? TN : 1][4];
+  if constexpr (AMAX) {
+    const int an = d.amax_cols > 0 ? d.amax_n : d.N;
+    const bool amax_tile = !(d.amax_cols > 0 && n0 >= d.amax_cols);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int nb = n0 + wn * 32 * TN + j * 32 + 8 * q4 + 4 * (lane >> 5);
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (amax_tile && d.bias != nullptr) {
+          if (nb + 3 < an) bv = *reinterpret_cast<const f32x4*>(d.bias + nb);
+          else
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bv[c] = nb + c < an ? d.bias[nb + c] : 0.f;
+        }
+        amax_bias[j][q4] = bv;
+      }
+  }
+#ifndef ABL_NO_PROLOGUE_WAIT                              // timing-only ablation: the first K-tile is multiplied before it has landed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#endif
   __builtin_amdgcn_sched_barrier(0);
   read_frag(0, 0, 0);
 #ifdef ABL_NO_READS
@@ -349,6 +380,17 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
   for (; kt + NS <= nkt; kt += NS) ring_round(kt, false);
   if (kt < nkt) ring_round(kt, true);
 
+#ifdef ABL_NO_EPILOGUE                                     // timing-only ablation: nothing after the K loop (the asm keeps the MFMAs alive)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" ::"v"(acc[i][j]));
+#endif
+    }
+  return;
+#endif
   if constexpr (AMAX) {
     // ---- fused row arg-max epilogue (vocab projection + torch.max, LanguageModel.lua:326-329) ----
     // acc[i][j] is the transposed block: this lane's row is m = m0 + wm*32*TM + i*32 + (lane&31); register e is column
@@ -368,8 +410,8 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
           for (int q4 = 0; q4 < 4; ++q4) {
             const int nb = n0 + wn * 32 * TN + j * 32 + 8 * q4 + 4 * hsel;
             if (nb + 3 < d.N) {
-              *reinterpret_cast<f32x4*>(crow + nb) =
-                  f32x4{acc[i][j][q4 * 4 + 0], acc[i][j][q4 * 4 + 1], acc[i][j][q4 * 4 + 2], acc[i][j][q4 * 4 + 3]};
+              EPI_STORE(*reinterpret_cast<f32x4*>(crow + nb),
+                        (f32x4{acc[i][j][q4 * 4 + 0], acc[i][j][q4 * 4 + 1], acc[i][j][q4 * 4 + 2], acc[i][j][q4 * 4 + 3]}));
             } else {
 #pragma unroll
               for (int c = 0; c < 4; ++c)
@@ -379,9 +421,9 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
       }
       return;
     }
-    __syncthreads();                        // everyone is done reading the operand ring (reused below)
-    float* red_v = smem;                    // [2 (wn)][BM]
-    int* red_i = reinterpret_cast<int*>(smem + 2 * BM);
+    // One partial per (row, 32-column half of the tile): partial slot 2 * tile_n + wn, columns ascending with the slot.
+    // Every wave finishes on its own: a compare chain inside the lane, one exchange between the two lane halves, two stores
+    // -- no LDS, no workgroup barrier (the row kernel that reduces the partials reads twice as many of them: 2.6 KB a row).
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       float best = -INFINITY;
@@ -391,13 +433,7 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
           const int nb = n0 + wn * 32 * TN + j * 32 + 8 * q4 + 4 * hsel;     // 4 consecutive columns, 16-byte aligned
-          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-          if (d.bias != nullptr) {
-            if (nb + 3 < an) bv = *reinterpret_cast<const f32x4*>(d.bias + nb);
-            else
-#pragma unroll
-              for (int c = 0; c < 4; ++c) bv[c] = nb + c < an ? d.bias[nb + c] : 0.f;
-          }
+          const f32x4 bv = amax_bias[j][q4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const float v = nb + c < an ? acc[i][j][q4 * 4 + c] + bv[c] : -INFINITY;
@@ -408,23 +444,11 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
       const float ov = __shfl_xor(best, 32, 64);
       const int oi = __shfl_xor(bi, 32, 64);
       if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-      if (hsel == 0) {
-        const int row = wm * 32 * TM + i * 32 + r;
-        red_v[wn * BM + row] = best;
-        red_i[wn * BM + row] = bi;
-      }
-    }
-    __syncthreads();
-    if (tid < BM) {
-      float best = red_v[tid];
-      int bi = red_i[tid];
-      const float ov = red_v[BM + tid];
-      const int oi = red_i[BM + tid];
-      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-      const int m = m0 + tid;
-      if (m < Meff) {
-        d.amax_val[(size_t)m * d.amax_ld + tile_n] = best;
-        d.amax_idx[(size_t)m * d.amax_ld + tile_n] = bi;
+      const int m = m0 + wm * 32 * TM + i * 32 + r;
+      if (hsel == 0 && m < Meff) {
+        const size_t slot = (size_t)m * d.amax_ld + 2 * tile_n + wn;
+        EPI_STORE(d.amax_val[slot], best);
+        EPI_STORE(d.amax_idx[slot], bi);
       }
     }
     return;
@@ -444,8 +468,8 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
           for (int q = 0; q < 4; ++q) {
             const int mrow = mb + 8 * q;
             if (n_ok && mrow < Meff)
-              d.C[(size_t)(mrow >> 2) * d.ldc + n] = pool_window(d, mrow >> 2, acc[i][j][4 * q], acc[i][j][4 * q + 1],
-                                                                  acc[i][j][4 * q + 2], acc[i][j][4 * q + 3], bv);
+              EPI_STORE(d.C[(size_t)(mrow >> 2) * d.ldc + n], pool_window(d, mrow >> 2, acc[i][j][4 * q], acc[i][j][4 * q + 1],
+                                                                            acc[i][j][4 * q + 2], acc[i][j][4 * q + 3], bv));
           }
         }
       }
@@ -470,7 +494,7 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
           if (d.rowterm != nullptr) v = d.rowterm[(size_t)(d.rowidx[m] - 1) * d.rowterm_ld + n] + acc[i][j][e];
           else v = acc[i][j][e] + bv;
           if (d.relu) v = v > 0.f ? v : 0.f;
-          d.C[(size_t)m * d.ldc + n] = v;
+          EPI_STORE(d.C[(size_t)m * d.ldc + n], v);
         }
       }
     }

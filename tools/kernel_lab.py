@@ -208,7 +208,7 @@ def steady(tag):
             print("%-14s %-12s %8d %10.1f %8.1f" % (tag, "decode_%d" % n, stag, best[1] * 1e3, best[2] / best[1] / 1e9), flush=True)
         cd.free(); td.free()
     dset(c2, "stagger", 0)
-    if tag in ("base", "V2_AGPR_ACC"):            # builds with RIGHT results: also the end-to-end rate
+    if not tag.startswith("ABL"):            # builds with RIGHT results: also the end-to-end rate
         from densecap_amd.weights import make_synthetic_image
         H, Wd, nimg = 600, 720, 16
         dev = c2.to_device(np.stack([make_synthetic_image(H, Wd, i) for i in range(nimg)]))
