@@ -380,6 +380,9 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
   for (; kt + NS <= nkt; kt += NS) ring_round(kt, false);
   if (kt < nkt) ring_round(kt, true);
 
+#ifdef ABL_EPI_SLEEP                                       // timing-only ablation: the wave idles ~2 us (4800 cycles) before its epilogue
+  __builtin_amdgcn_s_sleep(75);
+#endif
 #ifdef ABL_NO_EPILOGUE                                     // timing-only ablation: nothing after the K loop (the asm keeps the MFMAs alive)
 #pragma unroll
   for (int i = 0; i < TM; ++i)

@@ -158,7 +158,14 @@ def main(argv=None):
         from . import t7
         if not os.path.exists(opt.checkpoint):
             raise SystemExit("checkpoint %s not found (use -synthetic_weights 1 for random weights)" % opt.checkpoint)
-        weights = t7.weights_from_checkpoint(t7.load(opt.checkpoint))
+        try:
+            ck = t7.load(opt.checkpoint)
+        except t7.T7FormatError as e:
+            # the two checks that rest on torch.save's habits (object numbering, nothing after the object) must not lock a
+            # user out of an unusual but well-formed file: say so and read it again with only the bounds checks on
+            print("warning: %s -- reading %s again without the writer-habit checks" % (e, opt.checkpoint), file=sys.stderr)
+            ck = t7.load(opt.checkpoint, strict=False)
+        weights = t7.weights_from_checkpoint(ck)
     model = DenseCapModel(weights, device=opt.gpu)                      # utils.setup_gpus + model:convert
     paths = get_input_images(opt)
     num = min(len(paths), opt.max_images)

@@ -87,9 +87,10 @@ class T7Reader:
       * `load` requires the top-level object to end exactly at the end of the file."""
     MAX_DIMS = 16
 
-    def __init__(self, f):
+    def __init__(self, f, strict=True):
         self.f = f
         self.memo = {}
+        self.strict = strict          # False: the two checks that rest on torch.save's habits (index sequence, single object) are off
         pos = f.tell()
         f.seek(0, 2)
         self.size = f.tell()
@@ -131,7 +132,7 @@ class T7Reader:
 
     def _new_index(self, idx):
         """File.lua gives the objects of one file the indices 1, 2, 3 ... in the order of their first appearance."""
-        if idx != len(self.memo) + 1:
+        if self.strict and idx != len(self.memo) + 1:
             raise T7FormatError("t7: object index %d at offset %d is neither a back-reference nor the next new index (%d)"
                                 % (idx, self.f.tell() - 4, len(self.memo) + 1))
 
@@ -239,10 +240,12 @@ class T7Reader:
 
 
 def load(path, strict=True):
-    """torch.load(path) for the binary format.  strict: the file must hold exactly one object (what torch.save writes);
-    bytes after it mean the structure was not what it claimed to be."""
+    """torch.load(path) for the binary format.  strict: the file must hold exactly one object whose parts are numbered 1, 2, 3
+    ... in order of first appearance (what torch.save writes); anything else means the structure was not what it claimed to
+    be.  strict=False keeps every bounds check but drops those two habits-of-the-writer checks (a file appended to by hand, or
+    written through an already-used File object, still loads)."""
     with open(path, "rb") as f:
-        r = T7Reader(f)
+        r = T7Reader(f, strict=strict)
         obj = r.read_object()
         if strict and r._left() != 0:
             raise T7FormatError("t7: %d bytes follow the top-level object" % r._left())
