@@ -95,6 +95,7 @@ struct dc_ctx {
   uint32_t* fault_dev = nullptr;   // sticky device word: a stream-K owner gave up waiting for its partner (checked with the results)
   int force_cfg = 0;         // measurement hook: tile configuration of plain launches (dc_debug_set "force_cfg")
   int stagger = 0;           // measurement hook: start-up stagger of a launch's workgroups (dc_debug_set "stagger")
+  int walk = 0;              // measurement hook: 128x64 launches as one workgroup per slot walking its tiles (dc_debug_set "walk")
   int plan_mode = -1;        // measurement hook "plan_mode": -1 = planning follows the lane count, 0 = multi-lane planning, 1 = single-image planning
   int v2_stages = 0;         // LDS ring depth of the 128x64-tile kernel (dc_debug_set "v2_stages": 0 by tile count, 2 or 3 forced)
   int tail_mode = 0;         // partial last round in single-image mode: 0 stream-K, 1 K-split tail plan, 2 whole tiles (dc_debug_set)
@@ -193,6 +194,7 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, const Ws& w = Ws(
   d.stages = ctx->v2_stages;
   d.force_cfg = ctx->force_cfg;
   d.stagger = ctx->stagger;
+  d.walk = ctx->walk;
   ProfEvt pe{nullptr, nullptr, gemm_flops(d)};
   if (ctx->prof) {
     pe.a = prof_event(ctx); pe.b = prof_event(ctx);
@@ -1276,6 +1278,11 @@ int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value) {
   if (strcmp(name, "stagger") == 0) {
     if (value < 0 || value > 4096) return ctx->fail(DC_E_INVALID, "dc_debug_set: stagger must be 0..4096 (64-cycle sleeps)");
     ctx->stagger = (int)value;
+    return DC_OK;
+  }
+  if (strcmp(name, "walk") == 0) {
+    if (value < 0 || value > 1) return ctx->fail(DC_E_INVALID, "dc_debug_set: walk must be 0 or 1");
+    ctx->walk = (int)value;
     return DC_OK;
   }
   if (strcmp(name, "tail_mode") == 0) {

@@ -136,13 +136,53 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
     const size_t bytes = conv_input_pixels(d, Meff) * d.Cin * 4;
     rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : bytes), 0x00020000);
     const int hw = d.H * d.Wd;
+    // Round 4: an instruction issued at a tile's edges costs the launch about as much as one in its K loop (idle time is
+    // covered by the co-resident workgroups, issued instructions are not), and a row's pixel costs two integer divisions
+    // (~100 VALU instructions).  Interior tiles divide once per lane: the next row pass is 32 rows on -- a step of 32
+    // pixels (8 pool windows) that wraps the image row at most once.
+    const bool step_ok = m0 + BM <= Meff && (d.pool ? ((d.Wd + 1) >> 1) >= 8 : d.Wd >= 32);
+    if (step_ok) {
+      if (d.pool) {
+        const int Wo = (d.Wd + 1) >> 1, Ho = (d.H + 1) >> 1, per = Ho * Wo;
+        const int m = m0 + lrow, win = m >> 2;
+        int img = win / per;
+        const int wi = win - img * per;
+        int wy = wi / Wo, wx = wi - wy * Wo;
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      int m = m0 + lrow + 32 * i;
-      a_ok[i] = m < Meff;
-      if (m >= Meff) m = Meff - 1;
-      conv_pixel(d, m, hw, a_y[i], a_x[i], a_ok[i], a_off[i]);
-      a_off[i] += (unsigned)lchunk * 16u;
+        for (int i = 0; i < PA; ++i) {
+          const int y = 2 * wy + ((m >> 1) & 1), x = 2 * wx + (m & 1);
+          a_y[i] = y; a_x[i] = x;
+          a_ok[i] = y < d.H && x < d.Wd;
+          a_off[i] = (a_ok[i] ? (unsigned)(img * hw + y * d.Wd + x) * (unsigned)d.Cin * 4u : 0u) + (unsigned)lchunk * 16u;
+          wx += 8;
+          if (wx >= Wo) {
+            wx -= Wo;
+            if (++wy >= Ho) { wy = 0; ++img; }
+          }
+        }
+      } else {
+        const int m = m0 + lrow, img = m / hw, rem = m - img * hw;
+        int y = rem / d.Wd, x = rem - y * d.Wd;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          a_y[i] = y; a_x[i] = x; a_ok[i] = true;
+          a_off[i] = (unsigned)(m + 32 * i) * (unsigned)d.Cin * 4u + (unsigned)lchunk * 16u;
+          x += 32;
+          if (x >= d.Wd) {
+            x -= d.Wd;
+            if (++y >= d.H) y = 0;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        int m = m0 + lrow + 32 * i;
+        a_ok[i] = m < Meff;
+        if (m >= Meff) m = Meff - 1;
+        conv_pixel(d, m, hw, a_y[i], a_x[i], a_ok[i], a_off[i]);
+        a_off[i] += (unsigned)lchunk * 16u;
+      }
     }
   } else {
     const float* baseA = d.A + (size_t)m0 * d.K;
@@ -305,6 +345,15 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
         amax_bias[j][q4] = bv;
       }
   }
+  // the other epilogues' bias values (one per column block and lane) travel the same way
+  float bias_r[AMAX ? 1 : TN];
+  if constexpr (!AMAX) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * 32 * TN + j * 32 + r;
+      bias_r[j] = (d.bias != nullptr && n < d.N) ? d.bias[n] : 0.f;
+    }
+  }
 #ifndef ABL_NO_PROLOGUE_WAIT                              // timing-only ablation: the first K-tile is multiplied before it has landed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -456,17 +505,60 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
     }
     return;
   }
+  // Interior tiles (every row and column live, no gathered row term) leave through straight-line code: the row part of a
+  // store's address is wave-uniform (scalar unit), the lane part one 32-bit offset for the whole tile, bounds tests gone.
+  // The general path below tests and addresses every element on its own (~25 instructions and two branches per store).
+  const bool interior = m0 + BM <= Meff && n0 + BN <= d.N;
+  const int mw = m0 + wm * 32 * TM, nw = n0 + wn * 32 * TN;          // wave-uniform: this wave's first row / column
   if constexpr (CONV) {
     if (d.pool) {
       // ---- fused 2x2/2 ceil-mode max-pool: registers 4q..4q+3 of a lane are the four pixels of pool window (mb+8q)>>2
+      const int Wo = (d.Wd + 1) >> 1, Ho = (d.H + 1) >> 1;
+      if (interior && Wo >= 2) {
+        // this lane's windows: (mw >> 2) + hsel + 2 * (4 * i + q) -- a walk in steps of two windows, one division pair
+        const int per = Ho * Wo, win0 = (mw >> 2) + hsel;
+        const int wi = win0 % per;
+        int wy = wi / Wo, wx = wi - wy * Wo;
+        float* cw = d.C + (size_t)(mw >> 2) * d.ldc + nw;
+        const unsigned lane_off = (unsigned)(hsel * d.ldc + r);
+        auto walk = [&](auto RELU) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const bool hx = 2 * wx + 1 < d.Wd, hy = 2 * wy + 1 < d.H;
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                const float bv = bias_r[j];
+                float t0 = acc[i][j][4 * q] + bv, t1 = acc[i][j][4 * q + 1] + bv, t2 = acc[i][j][4 * q + 2] + bv,
+                      t3 = acc[i][j][4 * q + 3] + bv;
+                if constexpr (decltype(RELU)::value) {
+                  t0 = t0 > 0.f ? t0 : 0.f; t1 = t1 > 0.f ? t1 : 0.f; t2 = t2 > 0.f ? t2 : 0.f; t3 = t3 > 0.f ? t3 : 0.f;
+                }
+                float best = t0;
+                if (hx) best = t1 > best ? t1 : best;
+                if (hy) best = t2 > best ? t2 : best;
+                if (hx && hy) best = t3 > best ? t3 : best;
+                EPI_STORE(cw[(size_t)(2 * (4 * i + q)) * d.ldc + j * 32 + lane_off], best);
+              }
+              wx += 2;
+              if (wx >= Wo) {
+                wx -= Wo;
+                if (++wy >= Ho) wy = 0;
+              }
+            }
+        };
+        if (d.relu) walk(std::true_type{}); else walk(std::false_type{});
+        return;
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * 32 * TN + j * 32 + r;
+        const int n = nw + j * 32 + r;
         const bool n_ok = n < d.N;
-        const float bv = (d.bias != nullptr && n_ok) ? d.bias[n] : 0.f;
+        const float bv = bias_r[j];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const int mb = m0 + wm * 32 * TM + i * 32 + 4 * hsel;
+          const int mb = mw + i * 32 + 4 * hsel;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int mrow = mb + 8 * q;
@@ -481,14 +573,32 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
   }
   // ---- epilogue: bias (+ gathered row term) + ReLU, channels-last store -------------------
   // C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  if (interior && d.rowterm == nullptr) {
+    float* cw = d.C + (size_t)mw * d.ldc + nw;
+    const unsigned lane_off = (unsigned)(4 * hsel * d.ldc + r);
+    auto flush = [&](auto RELU) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            float v = acc[i][j][e] + bias_r[j];
+            if constexpr (decltype(RELU)::value) v = v > 0.f ? v : 0.f;
+            EPI_STORE(cw[(size_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * d.ldc + j * 32 + lane_off], v);
+          }
+    };
+    if (d.relu) flush(std::true_type{}); else flush(std::false_type{});
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * 32 * TN + j * 32 + r;
+    const int n = nw + j * 32 + r;
     const bool n_ok = n < d.N;
-    const float bv = (d.bias != nullptr && n_ok) ? d.bias[n] : 0.f;
+    const float bv = bias_r[j];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int mb = m0 + wm * 32 * TM + i * 32 + 4 * hsel;
+      const int mb = mw + i * 32 + 4 * hsel;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = mb + (e & 3) + 8 * (e >> 2);
@@ -547,7 +657,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
 // duration in the ragged round.  An element's K order does not depend on the tile it falls in (same fragment/lane walk
 // for every v2 shape), so results are bit-identical to the plain launch.
 template <bool CONV, int NS, bool AMAX>
-__global__ __launch_bounds__(256) void mfma_gemm_v2_mixed_kernel(GemmDesc d, int ntm, int ntn, int m_fastest, int nbig) {
+__global__ __launch_bounds__(256) void mfma_gemm_v2_mixed_kernel(GemmDesc d, int ntm, int ntn, int m_fastest, int nbig,
+                                                                 int nwalk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   start_stagger(d);
   int Meff = d.M;
@@ -556,17 +667,22 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_mixed_kernel(GemmDesc d, int
     if (me < Meff) Meff = me;
   }
   const int b = blockIdx.x;
-  if (b < nbig) {
-    const int bid = xcd_remap(b, nbig);
-    int tile_m, tile_n;
-    if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
-    else           { tile_n = bid % ntn; tile_m = bid / ntn; }
-    if (tile_m * 128 >= Meff) return;
-    // a row tile with <= 64 live rows (the last 44 of a 300-proposal decode): the 64x64 variant does half the MFMAs
-    if (Meff - tile_m * 128 <= 64) v2_tile<1, 1, CONV, NS, AMAX>(d, tile_m * 128, tile_n * 64, tile_n, Meff, smem);
-    else v2_tile<2, 1, CONV, NS, AMAX>(d, tile_m * 128, tile_n * 64, tile_n, Meff, smem);
+  if (b < nwalk) {
+    // nwalk == nbig: one 128x64 tile per workgroup.  nwalk < nbig (tile walk, a multiple of 8): workgroup b takes tiles b,
+    // b + nwalk, ... -- the same XCD every time, walking on through that XCD's run of tile ids.
+    for (int t = b; t < nbig; t += nwalk) {
+      if (t != b) __syncthreads();                    // every wave is done with the previous tile's LDS stages
+      const int bid = xcd_remap(t, nbig);
+      int tile_m, tile_n;
+      if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
+      else           { tile_n = bid % ntn; tile_m = bid / ntn; }
+      if (tile_m * 128 >= Meff) continue;
+      // a row tile with <= 64 live rows (the last 44 of a 300-proposal decode): the 64x64 variant does half the MFMAs
+      if (Meff - tile_m * 128 <= 64) v2_tile<1, 1, CONV, NS, AMAX>(d, tile_m * 128, tile_n * 64, tile_n, Meff, smem);
+      else v2_tile<2, 1, CONV, NS, AMAX>(d, tile_m * 128, tile_n * 64, tile_n, Meff, smem);
+    }
   } else {
-    const int r = b - nbig, bid = nbig + (r >> 1), half = r & 1;
+    const int r = b - nwalk, bid = nbig + (r >> 1), half = r & 1;
     int tile_m, tile_n;
     if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
     else           { tile_n = bid % ntn; tile_m = bid / ntn; }
@@ -1033,18 +1149,19 @@ hipError_t launch_mixed(const GemmDesc& d, hipStream_t stream, int ntm, int ntn,
   const int slots = wg_per_cu * cus;
   int nbig = total / slots * slots, tail = total - nbig;
   if (!v2_split_tail(nbig / slots, tail, slots)) { nbig = total; tail = 0; }     // no ragged round worth splitting
+  const int nwalk = d.walk > 0 && nbig > slots ? slots : nbig;     // measurement hook: one workgroup per slot walks its tiles
   if (stages == 2) {
     const size_t lds2 = lds / 3 * 2;
     const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_mixed_kernel<CONV, 2, AMAX>);
     if (hipError_t e = ensure_dyn_lds(fn, lds2); e != hipSuccess) return e;
-    hipLaunchKernelGGL((mfma_gemm_v2_mixed_kernel<CONV, 2, AMAX>), dim3(nbig + 2 * tail), dim3(256), lds2, stream, d, ntm, ntn,
-                       m_fastest, nbig);
+    hipLaunchKernelGGL((mfma_gemm_v2_mixed_kernel<CONV, 2, AMAX>), dim3(nwalk + 2 * tail), dim3(256), lds2, stream, d, ntm, ntn,
+                       m_fastest, nbig, nwalk);
     return hipGetLastError();
   }
   const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX>);
   if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL((mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX>), dim3(nbig + 2 * tail), dim3(256), lds, stream, d, ntm, ntn,
-                     m_fastest, nbig);
+  hipLaunchKernelGGL((mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX>), dim3(nwalk + 2 * tail), dim3(256), lds, stream, d, ntm, ntn,
+                     m_fastest, nbig, nwalk);
   return hipGetLastError();
 }
 

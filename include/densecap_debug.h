@@ -46,6 +46,8 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
  *                        count -- lets a one-stream profiler pass run exactly the kernels of the multi-lane schedule.
  *   "stagger"            0 (default) .. 4096: every workgroup of a contraction launch first sleeps a pseudo-random number (below
  *                        this value) of 64-cycle periods.  Measurement only (profiles/r04_kernel_lab.md).
+ *   "walk"               0 (default) / 1: 128x64-tile launches run one workgroup per slot that walks its tiles (same XCD, same
+ *                        tile order) instead of one workgroup per tile.  Bit-identical; measurement only (no gain measured).
  *   "v2_stages"          LDS ring depth of the 128x64-tile contraction kernel: 0 = by tile count (default: two stages, three
  *                        workgroups per CU, once a launch has >= 3 tiles per CU; three stages otherwise), 2 or 3 forced.
  *                        Same K order either way: bit-identical results.

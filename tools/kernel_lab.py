@@ -29,6 +29,13 @@ def dset(ctx, name, v):
     check(ctx.h, ctx.lib.dc_debug_set(ctx.h, name.encode(), int(v)), "dc_debug_set(%s)" % name)
 
 
+def preset(ctx):
+    """LAB_SET="walk=1,force_cfg=0": debug knobs held for a whole run (on top of the one being compared)."""
+    for kv in filter(None, os.environ.get("LAB_SET", "").split(",")):
+        k, v = kv.split("=")
+        dset(ctx, k, int(v))
+
+
 def prof(ctx, reset):
     l = C.c_int64(0); ms = C.c_double(0); fl = C.c_double(0)
     ctx.lib.dc_mfma_profile(ctx.h, reset, C.byref(l), C.byref(ms), C.byref(fl))
@@ -228,6 +235,104 @@ def steady(tag):
     json.dump(rows, open(os.path.join(OUT, "lab_steady_%s.json" % tag), "w"), indent=0)
 
 
+def knob_steady(knob, a, b):
+    """One debug knob on the steady-state shapes (same process, interleaved), after checking that the knob does not change a
+    single bit of the results (conv, pooled conv, dense, decode tokens)."""
+    ctx = Context(0)
+    preset(ctx)
+    STAGS = (0, 32) if knob != "stagger" else (-1,)         # the knob IS the stagger: leave it alone
+
+    def stag_set(c, stag):
+        if stag >= 0:
+            dset(c, "stagger", stag)
+    rng = np.random.default_rng(1)
+    H, Wd, Cin, Cout, nimg = 150, 180, 256, 256, 4
+    X = ctx.to_device(rng.standard_normal(nimg * H * Wd * Cin).astype(np.float32))
+    Wc = ctx.to_device(rng.standard_normal(Cout * 9 * Cin).astype(np.float32)); bb = ctx.to_device(rng.standard_normal(Cout).astype(np.float32))
+    Y = ctx.empty((nimg, H, Wd, Cout)); Yp = ctx.empty(((H + 1) // 2, (Wd + 1) // 2, Cout))
+    M, N, K = 108000, 256, 2304
+    A = ctx.to_device(rng.standard_normal(M * K).astype(np.float32)); Cc = ctx.empty((M, N))
+    outs = {}
+    for v in (a, b):
+        dset(ctx, knob, v)
+        check(ctx.h, ctx.lib.dc_op_conv3x3(ctx.h, X.ptr, Wc.ptr, bb.ptr, Y.ptr, nimg, H, Wd, Cin, Cout, 1), "conv")
+        y = Y.numpy().copy()
+        check(ctx.h, ctx.lib.dc_op_conv3x3_relu_pool(ctx.h, X.ptr, Wc.ptr, bb.ptr, Yp.ptr, H, Wd, Cin, Cout), "pool")
+        yp = Yp.numpy().copy()
+        check(ctx.h, ctx.lib.dc_op_linear(ctx.h, A.ptr, Wc.ptr, bb.ptr, Cc.ptr, M, N, K, 1), "linear")
+        outs[v] = (y, yp, Cc.numpy().copy())
+    for i, nm in enumerate(("conv", "pooled conv", "dense")):
+        same = np.array_equal(outs[a][i], outs[b][i])
+        print("bit-identity %s=%d vs %d, %s: %s" % (knob, a, b, nm, same), flush=True)
+        assert same
+    for x in (X, Wc, bb, Y, Yp, A, Cc):
+        x.free()
+    ops = Ops(ctx)
+    rows = []
+    print("%-14s %8s %8s %10s %8s" % ("op", knob, "stagger", "us", "TF"))
+    shapes = [("conv1_2_x4", 4, 600, 720, 64, 64), ("conv1_2_x1", 1, 600, 720, 64, 64), ("conv2_2_x4", 4, 300, 360, 128, 128),
+              ("conv2_2_x1", 1, 300, 360, 128, 128), ("conv3_2_x4", 4, 150, 180, 256, 256), ("conv3_2_x1", 1, 150, 180, 256, 256)]
+    try:
+        for name, ni, h, w, ci, co in shapes:
+            for stag in STAGS:
+                best = {a: 1e30, b: 1e30}
+                for rep in range(3):
+                    for v in (a, b):
+                        dset(ctx, knob, v); stag_set(ctx, stag)
+                        r = ops.run_conv(ni, h, w, ci, co, 5)
+                        if rep > 0 and r["us"] < best[v]:
+                            best[v] = r["us"]; gf = r["gflop"]
+                for v in (a, b):
+                    rows.append(dict(op=name, knob=v, stagger=stag, us=best[v]))
+                    print("%-14s %8d %8d %10.1f %8.1f" % (name, v, stag, best[v], gf / best[v] * 1e-3), flush=True)
+            ops.free()
+        for name, M, N, K in [("dense_c3_2_x4", 108000, 256, 2304), ("dense_c2_2_x4", 432000, 128, 1152)]:
+            for stag in STAGS:
+                best = {a: 1e30, b: 1e30}
+                for rep in range(3):
+                    for v in (a, b):
+                        dset(ctx, knob, v); stag_set(ctx, stag)
+                        r = ops.run_dense(M, N, K, 5)
+                        if rep > 0 and r["us"] < best[v]:
+                            best[v] = r["us"]; gf = r["gflop"]
+                for v in (a, b):
+                    rows.append(dict(op=name, knob=v, stagger=stag, us=best[v]))
+                    print("%-14s %8d %8d %10.1f %8.1f" % (name, v, stag, best[v], gf / best[v] * 1e-3), flush=True)
+            ops.free()
+    finally:
+        dset(ctx, knob, a); dset(ctx, "stagger", 0)
+        ctx.close()
+    from densecap_amd import DenseCapModel
+    from densecap_amd.weights import make_synthetic_weights
+    m = DenseCapModel(make_synthetic_weights(seed=1234), device=0)
+    c2 = m.ctx
+    preset(c2)
+    rng = np.random.default_rng(0)
+    for n in (1000, 4000):
+        codes = np.maximum(rng.standard_normal((n, 4096)), 0).astype(np.float32)
+        cd = c2.to_device(codes); td = c2.empty((n, 15), np.int32)
+        toks = {}
+        for stag in STAGS:
+            best = {a: None, b: None}
+            for rep in range(4):
+                for v in (a, b):
+                    dset(c2, knob, v); stag_set(c2, stag)
+                    prof(c2, 1)
+                    check(c2.h, c2.lib.dc_op_lm_sample(c2.h, cd.ptr, n, td.ptr), "dc_op_lm_sample")
+                    l, ms, fl = prof(c2, -1)
+                    toks[v] = td.numpy().copy()
+                    if rep > 0 and (best[v] is None or ms < best[v][1]):
+                        best[v] = (l, ms, fl)
+            assert np.array_equal(toks[a], toks[b]), "decode tokens differ"
+            for v in (a, b):
+                rows.append(dict(op="decode_%d" % n, knob=v, stagger=stag, us=best[v][1] * 1e3))
+                print("%-14s %8d %8d %10.1f %8.1f" % ("decode_%d" % n, v, stag, best[v][1] * 1e3, best[v][2] / best[v][1] / 1e9), flush=True)
+        cd.free(); td.free()
+    dset(c2, knob, a); dset(c2, "stagger", 0)
+    c2.close()
+    json.dump(rows, open(os.path.join(OUT, "lab_knob_%s.json" % knob), "w"), indent=0)
+
+
 def e2e():
     from densecap_amd import DenseCapModel
     from densecap_amd.weights import make_synthetic_image, make_synthetic_weights
@@ -280,6 +385,7 @@ def ab(knob, a, b):
     from densecap_amd.weights import make_synthetic_image, make_synthetic_weights
     m = DenseCapModel(make_synthetic_weights(seed=1234), device=0)
     ctx = m.ctx
+    preset(ctx)
     H, Wd, n = 600, 720, 24
     dev = ctx.to_device(np.stack([make_synthetic_image(H, Wd, i) for i in range(n)]))
     rows = []
@@ -349,6 +455,8 @@ if __name__ == "__main__":
         e2e()
     elif mode == "ab":
         ab(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
+    elif mode == "knob":
+        knob_steady(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
     elif mode == "steady":
         steady(sys.argv[2] if len(sys.argv) > 2 else "base")
     elif mode == "pmc-target":

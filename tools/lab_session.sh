@@ -15,6 +15,9 @@ for w in $WHAT; do
     ab_*)    # end-to-end A/B of one debug knob: ab_<knob>_<a>_<b>
       k=${w#ab_}; b=${k##*_}; k=${k%_*}; a=${k##*_}; k=${k%_*}
       timeout 600 python tools/kernel_lab.py ab $k $a $b > "$OUT/lab_ab_$k.txt" 2>&1; grep -v amdgpu.ids "$OUT/lab_ab_$k.txt" | tail -12 ;;
+    knob_*)  # steady-state kernels under one debug knob (bit-identity checked first): knob_<knob>_<a>_<b>
+      k=${w#knob_}; b=${k##*_}; k=${k%_*}; a=${k##*_}; k=${k%_*}
+      timeout 600 python tools/kernel_lab.py knob $k $a $b > "$OUT/lab_knob_$k.txt" 2>&1; grep -v amdgpu.ids "$OUT/lab_knob_$k.txt" | tail -60 ;;
     bench)   timeout 600 python bench.py > "$OUT/lab_bench_default.json" 2> "$OUT/lab_bench_default.err"; tail -c 3000 "$OUT/lab_bench_default.json"
              timeout 600 python bench.py --proposals 300 --steps 32 --no-cpu-baseline --sustain-seconds 3 --repeats 5 > "$OUT/lab_bench_p300.json" 2> "$OUT/lab_bench_p300.err"; tail -c 1500 "$OUT/lab_bench_p300.json" ;;
     steady)  # every experiment build of the library (make -C densecap_amd/csrc variants) on the same steady-state shapes
