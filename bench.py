@@ -66,9 +66,9 @@ def mfma_family_bytes(H, W, P, T, V, k=12, R=256, D=4096, E=512, Hd=512):
     total += 4.0 * (P * E + 4 * Hd * E + P * 4 * Hd); launches += 1                  # image step gates
     total += 4.0 * (P * Hd + 4 * Hd * Hd + P * 4 * Hd); launches += 1                # h0.Wh
     v1pad = (V + 1 + 63) // 64 * 64
-    step = 4.0 * (P * Hd + (v1pad + 4 * Hd) * Hd + P * 4 * Hd + 2 * P * (v1pad // 64))   # [Wout; Wh] panel, gates out, arg-max partials
+    step = 4.0 * (P * Hd + (v1pad + 4 * Hd) * Hd + P * 4 * Hd + 2 * P * (v1pad // 32))   # [Wout; Wh] panel, gates out, arg-max partials (value + column per row and 32-column half)
     total += (T - 1) * step; launches += T - 1
-    total += 4.0 * (P * Hd + (V + 1) * Hd + 2 * P * (v1pad // 64)); launches += 1    # last step: arg-max only
+    total += 4.0 * (P * Hd + (V + 1) * Hd + 2 * P * (v1pad // 32)); launches += 1    # last step: arg-max only
     return total, launches
 
 

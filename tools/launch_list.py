@@ -77,9 +77,9 @@ def launches(H=600, W=720, P=1000, T=15, V=10497, serial=0, k=12, R=256, D=4096,
     add("h0.Wh", P, 4 * Hd, Hd)
     v1pad = (V + 1 + 63) // 64 * 64
     for t in range(1, T):
-        add("decode_step_%d" % t, P, v1pad + 4 * Hd, Hd, amax=1, out_bytes=4.0 * (P * 4 * Hd + 2 * P * (v1pad // 64)),
+        add("decode_step_%d" % t, P, v1pad + 4 * Hd, Hd, amax=1, out_bytes=4.0 * (P * 4 * Hd + 2 * P * (v1pad // 32)),
             flops=2.0 * P * (V + 1 + 4 * Hd) * Hd)
-    add("decode_last_argmax", P, V + 1, Hd, amax=1, out_bytes=4.0 * 2 * P * (v1pad // 64))
+    add("decode_last_argmax", P, V + 1, Hd, amax=1, out_bytes=4.0 * 2 * P * (v1pad // 32))
     return out
 
 
