@@ -284,6 +284,55 @@ def test_conv_relu_pool_fused_equals_conv_then_pool(case):
         c.close()
 
 
+@pytest.mark.parametrize("case", [(3, 40, 32), (2, 9, 33), (1, 130, 47), (2, 64, 63), (1, 200, 17), (4, 3, 97)])
+def test_conv_row_pass_walk_wraps_image_rows(case):
+    """Interior tiles derive their other row passes from ONE division pair per lane (a step of 32 pixels that may wrap the
+    image row -- every step at width 32 -- and the image); widths below 32 keep the division per pass."""
+    import torch
+    from densecap_amd import ops
+    N, H, W = case
+    c = ops.Context(0)
+    try:
+        g = torch.Generator().manual_seed(N * 1000 + H * 10 + W)
+        x = torch.randn(N, 64, H, W, generator=g)
+        w = torch.randn(64, 64, 3, 3, generator=g) * (2.0 / (9 * 64)) ** 0.5
+        b = torch.randn(64, generator=g)
+        ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)).float().numpy()
+        out = ops.conv3x3(c, x.numpy(), w.numpy(), b.numpy(), relu=True)
+        _close(out, ref)
+        # the images of a launch are independent: each one alone gives the same bits
+        for i in range(N):
+            one = ops.conv3x3(c, x[i:i + 1].numpy(), w.numpy(), b.numpy(), relu=True)
+            np.testing.assert_array_equal(one[0], out[i])
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("hw", [(40, 16), (33, 17), (21, 15), (64, 12), (300, 3), (300, 2), (301, 4), (19, 64)])
+def test_pooled_conv_window_walk_narrow_images(hw):
+    """The pooled epilogue walks a lane's windows in steps of two from one division pair (a step wraps the window row at
+    most once: every step at two windows per row); the prologue steps eight windows per row pass from widths of 16 on."""
+    import torch
+    from densecap_amd import ops
+    from densecap_amd._lib import check
+    H, W = hw
+    c = ops.Context(0)
+    try:
+        check(c.h, c.lib.dc_set_lanes(c.h, 3), "dc_set_lanes")
+        g = torch.Generator().manual_seed(H * 1000 + W)
+        x = torch.randn(64, H, W, generator=g).numpy()
+        w = (torch.randn(64, 64, 3, 3, generator=g) * (2.0 / (9 * 64)) ** 0.5).numpy()
+        b = torch.randn(64, generator=g).numpy()
+        fused = ops.conv3x3_relu_pool(c, x, w, b)
+        unfused = ops.maxpool2x2_ceil(c, ops.conv3x3(c, x[None], w, b, relu=True))[0]
+        np.testing.assert_array_equal(fused, unfused)
+        ref = torch.relu(torch.nn.functional.conv2d(torch.from_numpy(x)[None].double(), torch.from_numpy(w).double(),
+                                                    torch.from_numpy(b).double(), padding=1))
+        _close(fused, torch.nn.functional.max_pool2d(ref, 2, 2, ceil_mode=True)[0].float().numpy(), rel=2e-5)
+    finally:
+        c.close()
+
+
 def test_lm_encoder_splitk_single_lane():
     """image_encoder Linear(4096,512) at M=1000 (32 tiles, K=4096 -> split-K in single-image mode)."""
     from densecap_amd import ops
