@@ -37,6 +37,8 @@ constexpr int BK = 32;
 // timing-only ablation build ABL_EPI_NO_STORE: the 2x2-wave kernel computes its epilogue but does not store it
 #if defined(ABL_EPI_NO_STORE) && defined(__HIP_DEVICE_COMPILE__)
 #define EPI_STORE(lhs, val) asm volatile("" ::"v"(val))
+#elif defined(EXP_EPI_NT)                                  // experiment build: results leave as non-temporal stores
+#define EPI_STORE(lhs, val) __builtin_nontemporal_store((val), &(lhs))
 #else
 #define EPI_STORE(lhs, val) (lhs) = (val)
 #endif

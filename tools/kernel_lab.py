@@ -421,6 +421,9 @@ PMC_ARMS = {
           ("conv", (1, 150, 180, 256, 256), 0, 0), ("conv", (1, 150, 180, 256, 256), 5, 0), ("conv", (4, 150, 180, 256, 256), 0, 0),
           ("conv", (4, 150, 180, 256, 256), 5, 0), ("conv", (1, 600, 720, 64, 64), 0, 0), ("conv", (1, 600, 720, 64, 64), 5, 0),
           ("conv", (1, 75, 90, 512, 512), 0, 0), ("conv", (1, 75, 90, 512, 512), 5, 0)],
+    # steady-state shapes for comparing library builds (cycles vs wall: DVFS give-back)
+    "b": [("conv", (4, 600, 720, 64, 64), 0, 32), ("conv", (4, 300, 360, 128, 128), 0, 32), ("conv", (4, 150, 180, 256, 256), 0, 32),
+          ("dense", (108000, 256, 2304), 0, 32)],
 }
 
 
@@ -430,7 +433,7 @@ def pmc_target(arm):
     order = []
     for kind, a, cfg, stag in PMC_ARMS[arm]:
         dset(ctx, "force_cfg", cfg); dset(ctx, "stagger", stag)
-        for _ in range(2):
+        for _ in range(int(os.environ.get("LAB_PMC_REPS", "2"))):
             if kind == "dense":
                 M, N, K = a
                 A = ops.buf(("A", M * K), M * K); Wt = ops.buf(("W", N * K), N * K); b = ops.buf(("b", N), N)

@@ -27,6 +27,19 @@ for w in $WHAT; do
         DENSECAP_HIP_LIB=$REPO/$so timeout 300 python tools/kernel_lab.py steady $v >> "$OUT/lab_steady.txt" 2>&1
       done
       grep -v "amdgpu.ids" "$OUT/lab_steady.txt" | tail -120 ;;
+    pmcvar)  # cycles vs wall time of the steady-state shapes for every library build (DVFS give-back of the ablations)
+      cd /tmp
+      export LAB_PMC_REPS=6
+      for so in base $REPO/densecap_amd/lib/libdensecap_hip_*.so; do
+        v=base; [ "$so" != base ] && { v=$(basename $so .so); v=${v#libdensecap_hip_}; export DENSECAP_HIP_LIB=$so; }
+        rm -rf /tmp/rp_var_$v
+        timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/rp_var_$v -o var_$v -- python $REPO/tools/kernel_lab.py pmc-target b > /tmp/rp_var_$v.log 2>&1
+        find /tmp/rp_var_$v -name "var_${v}_counter_collection.csv" -exec cp {} "$OUT"/ \;
+        find /tmp/rp_var_$v -name "var_${v}_kernel_trace.csv" -exec cp {} "$OUT"/ \;
+        tail -1 /tmp/rp_var_$v.log
+      done
+      unset DENSECAP_HIP_LIB
+      cd "$REPO" ;;
     pmc)
       cd /tmp
       rocprofv3 -L > "$OUT/rocprof_counters.txt" 2>&1
