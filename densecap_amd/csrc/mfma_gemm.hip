@@ -579,6 +579,24 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
     float* cw = d.C + (size_t)mw * d.ldc + nw;
     const unsigned lane_off = (unsigned)(4 * hsel * d.ldc + r);
     auto flush = [&](auto RELU) {
+#ifdef ABL_EPI_WIDE                                        // timing-only ablation: the same bytes and lines leave as 16-byte stores
+#pragma unroll                                             // (a quarter of the store instructions; values land in the wrong places)
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              float t = acc[i][j][4 * q + c] + bias_r[j];
+              if constexpr (decltype(RELU)::value) t = t > 0.f ? t : 0.f;
+              v[c] = t;
+            }
+            *reinterpret_cast<f32x4*>(cw + (size_t)(i * 32 + 8 * q + (lane >> 3)) * d.ldc + j * 32 + (lane & 7) * 4) = v;
+          }
+      return;
+#endif
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
