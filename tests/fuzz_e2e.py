@@ -29,14 +29,16 @@ def main(n_cases, seed):
             H = int(rng.integers(420, 760)); Wd = int(rng.integers(520, 1000))
         _ = int(rng.choice([0, 2])); tail = int(rng.choice([0, 1, 2]))          # (first draw: the persistent-decode route of round 3, kept so that seeds reproduce)
         stages_knob = int(rng.choice([0, 2, 3]))                                # LDS ring depth of the 128x64 kernel
+        walk = int(rng.integers(0, 2))                                          # one workgroup per slot walking its tiles
         if os.environ.get("FUZZ_ONLY") and case != int(os.environ["FUZZ_ONLY"]):
             continue                          # re-run ONE case of a seed (the draws above keep the sequence)
         img = make_synthetic_image(H, Wd, 1000 + case)
         m.setLanes(lanes); m.setCaptionOrder(order)
         check(m.ctx.h, m.ctx.lib.dc_debug_set(m.ctx.h, b"tail_mode", tail), "dc_debug_set")
         check(m.ctx.h, m.ctx.lib.dc_debug_set(m.ctx.h, b"v2_stages", stages_knob), "dc_debug_set")
+        check(m.ctx.h, m.ctx.lib.dc_debug_set(m.ctx.h, b"walk", walk), "dc_debug_set")
         rec = dict(case=case, H=H, W=Wd, P=P, rpn_thr=rthr, final_thr=fthr, lanes=lanes, caption_after_nms=order,
-                   tail_mode=tail, v2_stages=stages_knob)
+                   tail_mode=tail, v2_stages=stages_knob, walk=walk)
         try:
             # stage tensors are only inspected in the reference caption order (the device "seq" buffer is filled there)
             rec.update(parity.strict_check(m, W, img, P, rpn_thr=rthr, final_thr=fthr, stages=not order))
