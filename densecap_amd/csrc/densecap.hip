@@ -1064,7 +1064,10 @@ static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, i
     if (outs[i].capacity <= 0) return ctx->fail(DC_E_INVALID, "dc_result.capacity must be > 0");
   // images travel in groups of G through a lane (dc_set_group): the group's dense stages share launches
   int G = std::max(1, std::min(ctx->group > 0 ? ctx->group : 1, n));
-  while (G > 1 && (size_t)G * H * W * 64 * 4 >= 0xffffe000ull) --G;      // a group's conv1_x activation shares one 32-bit offset space
+  // a group's conv1_x activation shares one 32-bit offset space; the pooled conv counts window slots (4 per 2x2 window: a
+  // pixel more per odd side) -- the same count the launch itself checks
+  const size_t rows1 = std::max((size_t)H * W, (size_t)4 * ((H + 1) / 2) * ((W + 1) / 2));
+  while (G > 1 && (size_t)G * rows1 * 64 * 4 >= 0xffffe000ull) --G;
   const int ngroups = (n + G - 1) / G;
   const int nl = std::min(ngroups, ctx->max_lanes);
   while ((int)ctx->lanes.size() < nl) ctx->lanes.emplace_back(new Lane());
