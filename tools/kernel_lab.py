@@ -386,7 +386,7 @@ def ab(knob, a, b):
     m = DenseCapModel(make_synthetic_weights(seed=1234), device=0)
     ctx = m.ctx
     preset(ctx)
-    H, Wd, n = 600, 720, 24
+    H, Wd, n = 600, 720, int(os.environ.get("LAB_N", "24"))
     dev = ctx.to_device(np.stack([make_synthetic_image(H, Wd, i) for i in range(n)]))
     rows = []
     print("%-14s %-5s %-5s %-5s %12s %12s %8s" % ("knob", "P", "lanes", "group", "A images/s", "B images/s", "B/A"))
