@@ -53,7 +53,8 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
  *                        Same K order either way: bit-identical results.
  * Returns DC_OK or DC_E_INVALID for an unknown name / bad value. */
 int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value);
-/* Planning query -- pure (no context, no GPU: a missing device counts as 256 CUs): how the contraction engine carries out
+/* Planning query -- pure (no context, no GPU: a missing device counts as 256 CUs; the environment variable DC_PLAN_CU_COUNT,
+ * read by the planners, lets a test ask what a part with another CU count would be given): how the contraction engine carries out
  * C[M,N] = A[M,K] . W[N,K]^T (conv_cin != 0: the implicit GEMM of a 3x3 convolution with that many input channels,
  * K = 9*conv_cin; argmax != 0: the vocabulary projection with its fused row arg-max; plan_M = rows of ONE image when M
  * holds a group of images, 0 = M; serial_mode = the dc_set_lanes(1) scheduling).  out8 = {kind, route, stages, splitk,
