@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <memory>
 
@@ -74,6 +75,12 @@ struct Lane {
   hipStream_t aux = nullptr;            // single-image mode: second half of the decode rows runs here
   hipStream_t aux2 = nullptr;           // single-image mode: the final NMS runs here, beside the decode
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
+  // graph replay (dc_set_graph_replay): the forward of one (shape, settings) key, captured once and relaunched
+  uint64_t carve_epoch = 0;             // bumped whenever lane_prepare hands out new workspace pointers
+  hipGraphExec_t gexec = nullptr;
+  std::array<int64_t, 28> gkey{}, last_key{};
+  bool last_key_valid = false;          // last_key = the key of the previous (eager) forward on this lane
+  bool ran_graph = false;               // the group in flight was a graph launch (no stage events)
 };
 
 struct ProfEvt { hipEvent_t a, b; double flops; };
@@ -102,6 +109,9 @@ struct dc_ctx {
   bool serial_mode = false;  // lanes == 1: idle CUs in a layer's last round are worth a tail split-K (dc_set_lanes)
   int num_proposals = 300;  // LocalizationLayer default (LocalizationLayer.lua:237); run_model sets 1000
   bool clip_boxes = true;   // LocalizationLayer.test_clip_boxes (LocalizationLayer.lua:235)
+  bool graphs = false;      // dc_set_graph_replay: repeated forwards of one shape are relaunched as a captured hipGraph
+  uint64_t weights_epoch = 0;
+  int graph_launches = 0, graph_captures = 0;    // dc_debug_fetch "graph_launches" / "graph_captures"
   // dims
   int k = 0, R = 0, V = 0, T = 0, E = 0, Hd = 0, D = 0;
   float fc[4] = {0, 0, 0, 0};
@@ -393,6 +403,7 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P, int G) {
   }
   char* p = static_cast<char*>(L.arena.p);
   for (auto& c : cv) { *c.p = p; p += al(c.bytes); }
+  L.carve_epoch += 1;                  // every captured pointer is stale now
   nms_workspace_bind(L.nms, L.nms_base, nms_n);
   const size_t hs = (size_t)G * host_stage_stride(ctx, P);
   if (L.host_stage_bytes < hs) {
@@ -601,14 +612,12 @@ int lm_sample_two_streams(dc_ctx* ctx, Lane& L, const float* codes, int n, int p
 // image); the per-image stages (RPN decode, NMS, RoI pooling, final NMS, gathers) loop over the images.  Every routing
 // decision that changes a sum's order is planned per image (GemmDesc::plan_M), so an image's numbers do not depend on
 // the group it travels in.
-int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_device, bool features_only) {
+// `events`: record the stage events (an eager enqueue; a captured graph carries none -- dc_stage_times then has nothing)
+int enqueue_body(dc_ctx* ctx, Lane& L, int g, bool features_only, bool events) {
   hipStream_t s = L.stream;
   const int H = L.H, W = L.W, P = L.P;
-  const size_t img_elems = (size_t)3 * H * W;
-  if (img_on_device) HIPCHK(hipMemcpyAsync(L.img, img, g * img_elems * 4, hipMemcpyDeviceToDevice, s));
-  else HIPCHK(hipMemcpyAsync(L.img, img, g * img_elems * 4, hipMemcpyHostToDevice, s));
-  L.g = g;
-  HIPCHK(hipEventRecord(L.ev[0], s));
+#define STAGE_EVENT(i) do { if (events) HIPCHK(hipEventRecord(L.ev[i], s)); } while (0)
+  STAGE_EVENT(0);
   // ---- VGG-16 trunk (DenseCapModel.lua:73-76) -------------------------------------------
   int h = H, w = W, cur = 0;
   KCHK(launch_conv3x3_c3(L.img, ctx->conv_w[0], ctx->conv_b[0], L.act[0], g, H, W, 64, 1, s));
@@ -626,7 +635,7 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
   }
   L.feat = L.act[cur];
   const size_t feat_elems = (size_t)h * w * 512;
-  HIPCHK(hipEventRecord(L.ev[1], s));
+  STAGE_EVENT(1);
   // ---- RPN (LocalizationLayer.lua:265, build_rpn :609-690) ----------------------------------
   DCCHK(conv3x3(ctx, s, L.feat, ctx->rpn_w, ctx->rpn_b, L.rpn_hidden, g, h, w, 512, ctx->R, 1, lane_ws(L)));
   DCCHK(linear(ctx, s, L.rpn_hidden, ctx->heads_w, ctx->heads_b, L.heads, g * h * w, 6 * ctx->k, ctx->R, 0, Ws(), h * w));
@@ -635,7 +644,7 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
                            ctx->fc[2], ctx->fc[3], H, W, L.rpn_boxes + (size_t)i * L.A * 4, nullptr, nullptr,
                            L.rpn_xyxy + (size_t)i * L.A * 4, L.rpn_p + (size_t)i * L.A, L.rpn_valid + (size_t)i * L.A,
                            ctx->clip_boxes ? 1 : 0, s));
-  HIPCHK(hipEventRecord(L.ev[2], s));
+  STAGE_EVENT(2);
   // ---- RPN NMS (LocalizationLayer.lua:318-338) ------------------------------------------------
   for (int i = 0; i < g; ++i) {
     KCHK(launch_nms(L.nms, L.rpn_xyxy + (size_t)i * L.A * 4, L.rpn_p + (size_t)i * L.A, L.rpn_valid + (size_t)i * L.A, L.A,
@@ -643,21 +652,21 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
     KCHK(launch_gather_rows(L.rpn_boxes + (size_t)i * L.A * 4, L.picks1 + (size_t)i * P, L.count1 + i * 64, P, 4,
                             L.roi_boxes + (size_t)i * P * 4, s));
   }
-  HIPCHK(hipEventRecord(L.ev[3], s));
+  STAGE_EVENT(3);
   // ---- bilinear RoI pooling (LocalizationLayer.lua:346-349) -----------------------------------
   for (int i = 0; i < g; ++i)
     KCHK(launch_bilinear_roi_pool(L.feat + i * feat_elems, h, w, 512, L.roi_boxes + (size_t)i * P * 4, P, L.count1 + i * 64,
                                   H, W, 7, 7, L.roi_feats + (size_t)i * P * 49 * 512, 1, s));
-  HIPCHK(hipEventRecord(L.ev[4], s));
+  STAGE_EVENT(4);
   // ---- recog_base fc6/fc7 (DenseCapModel.lua:133) ------------------------------------------------
   const int R = g * P;                      // RoI rows of the group
   DCCHK(linear(ctx, s, L.roi_feats, ctx->fc6_w, ctx->fc6_b, L.fc6_out, R, ctx->D, 49 * 512, 1, lane_ws(L), P));
   DCCHK(linear(ctx, s, L.fc6_out, ctx->fc7_w, ctx->fc7_b, L.codes, R, ctx->D, ctx->D, 1, lane_ws(L), P));
-  HIPCHK(hipEventRecord(L.ev[5], s));
+  STAGE_EVENT(5);
   // ---- objectness / box regression / final boxes (DenseCapModel.lua:134,139-140) -----------------
   KCHK(launch_recog_heads(L.codes, ctx->head5_w, ctx->head5_b, L.roi_boxes, L.obj, L.final_trans, L.final_boxes, R,
                           ctx->D, s));
-  HIPCHK(hipEventRecord(L.ev[6], s));
+  STAGE_EVENT(6);
   const bool survivors_only = ctx->captions_after_final_nms && !features_only;
   // single-image mode, reference order: decode (two row blocks on two streams) and final NMS (a third stream) are
   // independent consumers of the heads' outputs.  Per-launch HIP-event profiling wants kernels that do not overlap:
@@ -675,7 +684,7 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
     else if (side_streams) DCCHK(lm_sample_two_streams(ctx, L, L.codes, R, P, L.seq));
     else DCCHK(lm_sample(ctx, L, L.codes, R, P, nullptr, L.seq));
   }
-  HIPCHK(hipEventRecord(L.ev[7], s));
+  STAGE_EVENT(7);
   // ---- final NMS + gather (DenseCapModel.lua:261-275) ----------------------------------------------
   KCHK(launch_xcycwh_to_x1y1x2y2(L.final_boxes, L.final_xyxy, R, sn));
   for (int i = 0; i < g; ++i) {
@@ -710,14 +719,13 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
       KCHK(launch_gather_rows_i32(L.seq + r0 * ctx->T, pk, cnt, P, ctx->T, L.out_tokens + r0 * ctx->T, s));
     }
   }
-  HIPCHK(hipEventRecord(L.ev[8], s));
+  STAGE_EVENT(8);
   // ---- results -> pinned host staging (one slot per image) ------------------------------------------------------
   const size_t stride = host_stage_stride(ctx, P);
   for (int i = 0; i < g; ++i) {
     char* hs = static_cast<char*>(L.host_stage) + i * stride;
     const size_t r0 = (size_t)i * P;
     HIPCHK(hipMemcpyAsync(hs, L.count2 + i * 64, 4, hipMemcpyDeviceToHost, s));
-    *reinterpret_cast<uint32_t*>(hs + 68) = 0;
     if (ctx->fault_dev != nullptr) HIPCHK(hipMemcpyAsync(hs + 68, ctx->fault_dev, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hs + 256, L.out_boxes + r0 * 4, (size_t)P * 16, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hs + 256 + (size_t)P * 16, L.out_scores + r0, (size_t)P * 4, hipMemcpyDeviceToHost, s));
@@ -726,22 +734,91 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
     else
       HIPCHK(hipMemcpyAsync(hs + 256 + (size_t)P * 20, L.out_tokens + r0 * ctx->T, (size_t)P * ctx->T * 4, hipMemcpyDeviceToHost, s));
   }
+#undef STAGE_EVENT
+  return DC_OK;
+}
+
+// Everything a captured forward bakes in: workspace pointers (carve epoch, arena, staging), weights, shape, every setting
+// that reaches a kernel argument, a launch decision or the stream layout.
+std::array<int64_t, 28> graph_key(const dc_ctx* ctx, const Lane& L, int g, bool features_only) {
+  auto f2i = [](float f) { int32_t i; memcpy(&i, &f, 4); return (int64_t)i; };
+  return {1, (int64_t)L.carve_epoch, (int64_t)ctx->weights_epoch, L.H, L.W, L.P, g, features_only ? 1 : 0,
+          f2i(ctx->rpn_nms_thresh), f2i(ctx->final_nms_thresh), ctx->num_proposals, ctx->clip_boxes ? 1 : 0,
+          ctx->captions_after_final_nms ? 1 : 0, ctx->serial_mode ? 1 : 0, ctx->plan_mode, ctx->tail_mode, ctx->force_cfg,
+          ctx->v2_stages, ctx->stagger, ctx->walk, ctx->beam_size, (int64_t)(uintptr_t)ctx->fault_dev,
+          (int64_t)(uintptr_t)L.arena.p, (int64_t)(uintptr_t)L.host_stage, (int64_t)(uintptr_t)L.splitk_ws, 0, 0, 0};
+}
+
+int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_device, bool features_only) {
+  hipStream_t s = L.stream;
+  const size_t img_elems = (size_t)3 * L.H * L.W;
+  if (img_on_device) HIPCHK(hipMemcpyAsync(L.img, img, g * img_elems * 4, hipMemcpyDeviceToDevice, s));
+  else HIPCHK(hipMemcpyAsync(L.img, img, g * img_elems * 4, hipMemcpyHostToDevice, s));
+  L.g = g;
+  const size_t stride = host_stage_stride(ctx, L.P);
+  for (int i = 0; i < g; ++i) *reinterpret_cast<uint32_t*>(static_cast<char*>(L.host_stage) + i * stride + 68) = 0;
+  L.ran_graph = false;
+  // Graph replay (dc_set_graph_replay): the FIRST forward of a key runs eagerly (lazy allocations, kernel attributes and
+  // the stream-K fault word are all in place afterwards), the second is captured and instantiated, later ones are one
+  // hipGraphLaunch.  Per-launch profiling and beam search (which allocates on first use) stay eager.
+  const bool eligible = ctx->graphs && !ctx->prof && ctx->beam_size == 0;
+  if (eligible) {
+    const auto key = graph_key(ctx, L, g, features_only);
+    if (L.gexec != nullptr && key == L.gkey) {
+      HIPCHK(hipGraphLaunch(L.gexec, s));
+      ctx->graph_launches += 1;
+      L.ran_graph = true;
+    } else if (L.last_key_valid && key == L.last_key) {
+      if (L.gexec != nullptr) { (void)hipGraphExecDestroy(L.gexec); L.gexec = nullptr; }
+      hipGraph_t graph = nullptr;
+      HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+      const int rc = enqueue_body(ctx, L, g, features_only, false);
+      const hipError_t e = hipStreamEndCapture(s, &graph);
+      hipError_t e2 = hipSuccess;
+      if (rc == DC_OK && e == hipSuccess && graph != nullptr) e2 = hipGraphInstantiate(&L.gexec, graph, nullptr, nullptr, 0);
+      if (graph != nullptr) (void)hipGraphDestroy(graph);
+      if (rc != DC_OK || e != hipSuccess || e2 != hipSuccess || L.gexec == nullptr) {
+        // a forward that cannot be captured on this runtime: say so once, stay eager on this ctx
+        (void)hipGetLastError();
+        L.gexec = nullptr;
+        ctx->graphs = false;
+        if (rc != DC_OK) return rc;
+        DCCHK(enqueue_body(ctx, L, g, features_only, true));
+      } else {
+        L.gkey = key;
+        ctx->graph_captures += 1;
+        HIPCHK(hipGraphLaunch(L.gexec, s));
+        ctx->graph_launches += 1;
+        L.ran_graph = true;
+      }
+    } else {
+      DCCHK(enqueue_body(ctx, L, g, features_only, true));
+      L.last_key = key;
+      L.last_key_valid = true;
+    }
+  } else {
+    DCCHK(enqueue_body(ctx, L, g, features_only, true));
+    L.last_key_valid = false;
+  }
   L.busy = true;
   L.pending_feats = features_only;
   return DC_OK;
 }
+
 
 // Wait for the lane's in-flight group and hand the results to the caller's buffers.
 int harvest(dc_ctx* ctx, Lane& L) {
   if (!L.busy) return DC_OK;
   HIPCHK(hipStreamSynchronize(L.stream));
   L.busy = false;
-  for (int i = 0; i < ST_COUNT; ++i) {
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, L.ev[i], L.ev[i + 1]);
-    L.stage_ms[i] = ms / (float)std::max(L.g, 1);       // per image of the group
+  if (!L.ran_graph) {
+    for (int i = 0; i < ST_COUNT; ++i) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, L.ev[i], L.ev[i + 1]);
+      L.stage_ms[i] = ms / (float)std::max(L.g, 1);       // per image of the group
+    }
   }
-  L.have_times = true;
+  L.have_times = !L.ran_graph;                            // a replayed graph carries no stage events
   const int P = L.P;
   const size_t stride = host_stage_stride(ctx, P);
   for (int i = 0; i < L.g; ++i) {
@@ -829,6 +906,7 @@ void dc_destroy(dc_ctx* ctx) {
     Lane& L = *lp;
     if (L.arena.p) hipFree(L.arena.p);
     if (L.beam_base) hipFree(L.beam_base);
+    if (L.gexec) (void)hipGraphExecDestroy(L.gexec);
     if (L.host_stage) hipHostFree(L.host_stage);
     for (auto& ev : L.ev) if (ev) hipEventDestroy(ev);
     if (L.ev_fork) hipEventDestroy(L.ev_fork);
@@ -900,6 +978,12 @@ int dc_set_beam_size(dc_ctx* ctx, int beam_size) {
   if (beam_size < 0 || beam_size > 32) return ctx->fail(DC_E_UNSUPPORTED, "dc_set_beam_size: beam_size must be in [0,32] (got %d)", beam_size);
   DCCHK(check_beam_fits(ctx, beam_size));          // before dc_load_weights the check runs there instead
   ctx->beam_size = beam_size;
+  return DC_OK;
+}
+
+int dc_set_graph_replay(dc_ctx* ctx, int on) {
+  if (!ctx) return DC_E_INVALID;
+  ctx->graphs = on != 0;
   return DC_OK;
 }
 
@@ -1016,6 +1100,7 @@ int dc_load_weights(dc_ctx* ctx, const dc_weights* w) {
   HIPCHK(hipStreamSynchronize(s));
   prof_collect(ctx);
   ctx->have_weights = true;
+  ctx->weights_epoch += 1;                 // captured graphs hold the old weight pointers
   if (int rc = check_beam_fits(ctx, ctx->beam_size); rc != DC_OK) {   // dc_set_beam_size came first: validate it now
     ctx->beam_size = 0;
     return rc;
@@ -1219,6 +1304,11 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
   if (strcmp(name, "host_enqueue_us") == 0) {
     if (capacity_bytes < 4) return ctx->fail(DC_E_INVALID, "dc_debug_fetch: buffer too small");
     *static_cast<int32_t*>(host_buf) = (int32_t)(ctx->host_enqueue_ms * 1000.0);
+    return 1;
+  }
+  if (strcmp(name, "graph_launches") == 0 || strcmp(name, "graph_captures") == 0) {
+    if (capacity_bytes < 4) return ctx->fail(DC_E_INVALID, "dc_debug_fetch: buffer too small");
+    *static_cast<int32_t*>(host_buf) = name[6] == 'l' ? ctx->graph_launches : ctx->graph_captures;
     return 1;
   }
   if (strcmp(name, "arena_allocs") == 0) {

@@ -229,6 +229,12 @@ class DenseCapModel:
         self.captions_after_final_nms = bool(after_final_nms)
         return self
 
+    def setGraphReplay(self, on):
+        """dc_set_graph_replay: repeated forwards of one shape on a lane are captured once and relaunched as a hipGraph
+        (bit-identical; pays with one image in flight -- run_model on single images, the webcam daemon)."""
+        check(self.ctx.h, self.lib.dc_set_graph_replay(self.ctx.h, int(bool(on))), "dc_set_graph_replay")
+        return self
+
     def setGroup(self, images):
         """Images per group inside a batch call: 0/1 = every image on its own (default), 2..4 = the images of a group share
         the launches of the dense stages (bit-identical results; 1000 proposals: +4.5 % images/s on one lane, nothing with

@@ -153,6 +153,15 @@ int dc_set_group(dc_ctx* ctx, int images);
  * first and decode only the K surviving rows: LSTM rows are independent, so boxes, scores and tokens
  * are bit-identical, with ~K/num_proposals of the decode work. */
 int dc_set_caption_order(dc_ctx* ctx, int after_final_nms);
+/* Graph replay (0 = off, the default).  1: a lane that is handed the same work again -- same image size, proposal
+ * capacity, group size and settings -- captures its forward once (the second time the key is seen; the first runs
+ * eagerly so that every lazy allocation has happened) and relaunches it afterwards as one hipGraph: ~95 kernel launches
+ * and copies of an image become one call, the gaps between dependent kernels shrink.  A scheduling knob like the lane
+ * count: the kernels and their arguments are the captured ones, results are bit-identical.  Pays in the latency regime
+ * (one image in flight, small proposal counts: the webcam daemon); with two or more lanes the other lane already fills
+ * the gaps.  Stage times (dc_stage_times) are not available for replayed forwards; beam search and per-launch
+ * profiling stay eager. */
+int dc_set_graph_replay(dc_ctx* ctx, int on);
 /* LanguageModel.beam_size (LanguageModel.lua:129-131): 0 (default) = greedy LM:sample; 1..32 = LM:beamsearch
  * (LanguageModel.lua:170-290) with that many beams.  Ties in torch.topk (unspecified in the reference; they occur for
  * finished beams, whose next-word log-probabilities are zeroed) resolve to the lower index. */

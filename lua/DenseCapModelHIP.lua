@@ -171,6 +171,11 @@ end
 function Model:setBeamSize(n)
   hip.check(self.ctx, C.dc_set_beam_size(self.ctx, n or 0), 'dc_set_beam_size')
 end
+-- repeated forwards of one image size relaunched as a captured hipGraph (same results; the webcam daemon's regime)
+function Model:setGraphReplay(on)
+  hip.check(self.ctx, C.dc_set_graph_replay(self.ctx, on and 1 or 0), 'dc_set_graph_replay')
+  return self
+end
 function Model:convert(dtype, use_cudnn) return self end
 function Model:evaluate() return self end
 function Model:type() return self end

@@ -499,6 +499,89 @@ def test_mixed_image_sizes_reuse_the_lane_workspace(model, weights):
     assert a1[0] == a0[0], "lane workspace was re-allocated %d times for smaller images" % (a1[0] - a0[0])
 
 
+def test_graph_replay_is_bit_identical_and_follows_the_inputs(weights):
+    """dc_set_graph_replay: the second forward of a (shape, settings) key is captured, later ones are one hipGraphLaunch.
+    Replayed forwards must give exactly the eager bits for NEW image contents (the input copy stays outside the graph), a
+    changed setting or shape must not reuse a stale graph, and every entry point (single image, batch over lanes, groups,
+    caption order, extractFeatures) must survive replay."""
+    from densecap_amd import DenseCapModel
+    from densecap_amd.weights import make_synthetic_image
+    m = DenseCapModel(weights, device=0)
+    try:
+        def counters():
+            return (int(m.debug_fetch("graph_captures", (1,), np.int32)[0][0]), int(m.debug_fetch("graph_launches", (1,), np.int32)[0][0]))
+        H, W = 224, 288
+        imgs = [make_synthetic_image(H, W, 300 + i) for i in range(6)]
+        m.setLanes(1)
+        m.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=100)
+        eager = [m.forward_raw(im) for im in imgs]
+        m.setGraphReplay(True)
+        c0, l0 = counters()
+        replay = [m.forward_raw(im) for im in imgs]                  # eager, capture + launch, launch, launch ...
+        c1, l1 = counters()
+        assert c1 - c0 == 1 and l1 - l0 == len(imgs) - 1, (c0, l0, c1, l1)
+        for a, b in zip(eager, replay):
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x, y)
+        assert len(eager[0][0]) > 0 and not np.array_equal(eager[0][0], eager[1][0])
+        # a changed setting is a new key: eager once, captured again -- never the old graph
+        m.setTestArgs(rpn_nms_thresh=0.5, final_nms_thresh=0.3, num_proposals=100)
+        r2 = [m.forward_raw(imgs[0]) for _ in range(3)]
+        c2, l2 = counters()
+        assert c2 - c1 == 1 and l2 - l1 == 2
+        m.setGraphReplay(False)
+        ref2 = m.forward_raw(imgs[0])
+        for r in r2:
+            for x, y in zip(r, ref2):
+                np.testing.assert_array_equal(x, y)
+        assert not np.array_equal(ref2[0], eager[0][0]) or len(ref2[0]) != len(eager[0][0])
+        # another shape in between re-carves the workspace: the old graph's pointers are stale and must not be replayed
+        m.setGraphReplay(True)
+        a = [m.forward_raw(imgs[1]) for _ in range(3)]
+        other = m.forward_raw(make_synthetic_image(203, 301, 9))
+        b = [m.forward_raw(imgs[1]) for _ in range(3)]
+        m.setGraphReplay(False)
+        ref = m.forward_raw(imgs[1]); ref_other = m.forward_raw(make_synthetic_image(203, 301, 9))
+        for r in a + b:
+            for x, y in zip(r, ref):
+                np.testing.assert_array_equal(x, y)
+        for x, y in zip(other, ref_other):
+            np.testing.assert_array_equal(x, y)
+        # single-image mode with >= 256 RoI rows: the decode forks onto two streams and the final NMS onto a third --
+        # the capture has to follow the forks and the joins
+        m.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=300)
+        m.setGraphReplay(False)
+        want300 = m.forward_raw(imgs[3])
+        m.setGraphReplay(True)
+        for _ in range(4):
+            for x, y in zip(m.forward_raw(imgs[3]), want300):
+                np.testing.assert_array_equal(x, y)
+        m.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=100)
+        # batches over lanes and groups, both caption orders, and the feature path
+        batch = np.stack(imgs)
+        for lanes, group, order in ((2, 1, False), (2, 2, True), (3, 3, False), (1, 1, True)):
+            m.setLanes(lanes); m.setGroup(group); m.setCaptionOrder(order)
+            m.setGraphReplay(False)
+            want = m.forward_batch(batch)
+            m.setGraphReplay(True)
+            for rep in range(3):
+                got = m.forward_batch(batch)
+                for i in range(len(imgs)):
+                    for x, y in zip(got[i], want[i]):
+                        np.testing.assert_array_equal(x, y, err_msg="lanes %d group %d order %s rep %d image %d" % (lanes, group, order, rep, i))
+        m.setLanes(1); m.setGroup(0); m.setCaptionOrder(False)
+        m.setGraphReplay(False)
+        fb, ff = m.extractFeatures(imgs[2])
+        m.setGraphReplay(True)
+        for _ in range(3):
+            gb, gf = m.extractFeatures(imgs[2])
+            np.testing.assert_array_equal(gb, fb); np.testing.assert_array_equal(gf, ff)
+        c3, l3 = counters()
+        assert c3 > c2 and l3 > l2
+    finally:
+        m.ctx.close()
+
+
 def test_webcam_daemon_with_the_hip_model(tmp_path):
     """webcam/daemon.lua:55-102 end to end with the real model (small vocabulary): a 640x480 frame dropped into the input
     directory is consumed, <id>.json carries boxes rescaled to the ORIGINAL frame, and the result equals what
