@@ -63,6 +63,7 @@ struct GemmDesc {
   int force_cfg = 0;          // measurement hook (dc_debug_set "force_cfg"): 0 = planned, 1 = 128x128, 2 = 128x64, 3 = 64x64 tiles; 4 = planned tiles, no split-K;
                               // 5 = 128x128 tiles on the v2 kernel with a two-stage ring (two workgroups per CU); 6 = the K-split 128x128 kernel whatever K
   int stagger = 0;            // measurement hook (dc_debug_set "stagger"): workgroups start after a pseudo-random pause of up to this many 64-cycle sleeps
+  int epi_wide = 1;           // interior tiles of plain epilogues leave as 16-byte stores staged through the wave's LDS (dc_debug_set "epi_wide": 0 = dword stores)
   int walk = 0;               // measurement hook (dc_debug_set "walk"): 128x64 launches run one workgroup per slot that walks its tiles
   const int* sk_lo = nullptr;
   int sk_np = 0;

@@ -103,6 +103,7 @@ struct dc_ctx {
   int force_cfg = 0;         // measurement hook: tile configuration of plain launches (dc_debug_set "force_cfg")
   int stagger = 0;           // measurement hook: start-up stagger of a launch's workgroups (dc_debug_set "stagger")
   int walk = 0;              // measurement hook: 128x64 launches as one workgroup per slot walking its tiles (dc_debug_set "walk")
+  int epi_wide = 1;          // plain interior epilogues as 16-byte stores staged through LDS (dc_debug_set "epi_wide")
   int plan_mode = -1;        // measurement hook "plan_mode": -1 = planning follows the lane count, 0 = multi-lane planning, 1 = single-image planning
   int v2_stages = 0;         // LDS ring depth of the 128x64-tile kernel (dc_debug_set "v2_stages": 0 by tile count, 2 or 3 forced)
   int tail_mode = 0;         // partial last round in single-image mode: 0 stream-K, 1 K-split tail plan, 2 whole tiles (dc_debug_set)
@@ -205,6 +206,7 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, const Ws& w = Ws(
   d.force_cfg = ctx->force_cfg;
   d.stagger = ctx->stagger;
   d.walk = ctx->walk;
+  d.epi_wide = ctx->epi_wide;
   ProfEvt pe{nullptr, nullptr, gemm_flops(d)};
   if (ctx->prof) {
     pe.a = prof_event(ctx); pe.b = prof_event(ctx);
@@ -745,7 +747,7 @@ std::array<int64_t, 28> graph_key(const dc_ctx* ctx, const Lane& L, int g, bool 
   return {1, (int64_t)L.carve_epoch, (int64_t)ctx->weights_epoch, L.H, L.W, L.P, g, features_only ? 1 : 0,
           f2i(ctx->rpn_nms_thresh), f2i(ctx->final_nms_thresh), ctx->num_proposals, ctx->clip_boxes ? 1 : 0,
           ctx->captions_after_final_nms ? 1 : 0, ctx->serial_mode ? 1 : 0, ctx->plan_mode, ctx->tail_mode, ctx->force_cfg,
-          ctx->v2_stages, ctx->stagger, ctx->walk, ctx->beam_size, (int64_t)(uintptr_t)ctx->fault_dev,
+          ctx->v2_stages, ctx->stagger, ctx->walk + 2 * ctx->epi_wide, ctx->beam_size, (int64_t)(uintptr_t)ctx->fault_dev,
           (int64_t)(uintptr_t)L.arena.p, (int64_t)(uintptr_t)L.host_stage, (int64_t)(uintptr_t)L.splitk_ws, 0, 0, 0};
 }
 
@@ -1371,6 +1373,11 @@ int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value) {
   if (strcmp(name, "stagger") == 0) {
     if (value < 0 || value > 4096) return ctx->fail(DC_E_INVALID, "dc_debug_set: stagger must be 0..4096 (64-cycle sleeps)");
     ctx->stagger = (int)value;
+    return DC_OK;
+  }
+  if (strcmp(name, "epi_wide") == 0) {
+    if (value < 0 || value > 1) return ctx->fail(DC_E_INVALID, "dc_debug_set: epi_wide must be 0 or 1");
+    ctx->epi_wide = (int)value;
     return DC_OK;
   }
   if (strcmp(name, "walk") == 0) {

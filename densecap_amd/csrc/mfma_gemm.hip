@@ -578,6 +578,35 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
   if (interior && d.rowterm == nullptr) {
     float* cw = d.C + (size_t)mw * d.ldc + nw;
     const unsigned lane_off = (unsigned)(4 * hsel * d.ldc + r);
+    // Round 4, last finding of the lab notes: what an epilogue costs the launch is its number of STORE instructions.  A 32x32
+    // block held one column per lane leaves as 16 dword stores; passed through 4 KB of LDS that belong to this wave alone
+    // (the ring stage no K-tile will use again: every wave is past the last rendezvous) it leaves as 4 stores of 16 bytes
+    // per lane -- 8 full 128-byte lines each.  Same values, same addresses.
+    if (d.epi_wide && (d.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(d.C) & 15) == 0) {
+      float* const scr = smem + (nkt % NS) * STAGE + wid * 1024;
+      auto flush_wide = [&](auto RELU) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              float v = acc[i][j][e] + bias_r[j];
+              if constexpr (decltype(RELU)::value) v = v > 0.f ? v : 0.f;
+              scr[((e & 3) + 8 * (e >> 2) + 4 * hsel) * 32 + r] = v;
+            }
+            __builtin_amdgcn_wave_barrier();             // program order is LDS order inside a wave; keep the compiler to it
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(scr + (8 * q + (lane >> 3)) * 32 + (lane & 7) * 4);
+              EPI_STORE(*reinterpret_cast<f32x4*>(cw + (size_t)(i * 32 + 8 * q + (lane >> 3)) * d.ldc + j * 32 + (lane & 7) * 4), v);
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+      };
+      if (d.relu) flush_wide(std::true_type{}); else flush_wide(std::false_type{});
+      return;
+    }
     auto flush = [&](auto RELU) {
 #ifdef ABL_EPI_WIDE                                        // timing-only ablation: the same bytes and lines leave as 16-byte stores
 #pragma unroll                                             // (a quarter of the store instructions; values land in the wrong places)

@@ -46,6 +46,8 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
  *                        count -- lets a one-stream profiler pass run exactly the kernels of the multi-lane schedule.
  *   "stagger"            0 (default) .. 4096: every workgroup of a contraction launch first sleeps a pseudo-random number (below
  *                        this value) of 64-cycle periods.  Measurement only (profiles/r04_kernel_lab.md).
+ *   "epi_wide"           1 (default) / 0: interior tiles of the plain epilogues leave as 16-byte stores staged through the wave's
+ *                        own 4 KB of LDS (8 full lines per instruction) / as dword stores.  Same values, same addresses.
  *   "walk"               0 (default) / 1: 128x64-tile launches run one workgroup per slot that walks its tiles (same XCD, same
  *                        tile order) instead of one workgroup per tile.  Bit-identical; measurement only (no gain measured).
  *   "v2_stages"          LDS ring depth of the 128x64-tile contraction kernel: 0 = by tile count (default: two stages, three
