@@ -244,6 +244,8 @@ class StubComm:
         from densecap_amd import dist as D
         return D.gather_records(self.dist, results, P, T, self.rank, self.world)
 
+    transport = "stub carrier over torch.distributed"
+
     def close(self):
         pass
 
@@ -317,7 +319,9 @@ def main():
     device_index = local_rank % max(ndev, 1)
     if on_gpu and args.dist_backend == "nccl" and world > ndev:
         raise SystemExit("bench.py: %d ranks but %d GPUs visible (RCCL needs one GPU per rank)" % (world, ndev))
-    if world > 1:
+    if world > 1 or "WORLD_SIZE" in os.environ:
+        # (a one-rank job started by torch.distributed.run still builds its process group: torch's RCCL and the library's
+        # dlopen()ed librccl then live in one process, as they do in every rank of an N-GPU run)
         import torch.distributed as dist
         if on_gpu:
             torch.cuda.set_device(device_index)
@@ -421,7 +425,8 @@ def main():
         dist.broadcast(idt, src=0)                       # rendezvous id of the RCCL communicator, out of band
         if all_ranks_ok(err is None):
             idb = bytes(idt.cpu().numpy().tobytes())
-            comm, err = guarded(lambda: D.Comm(ctx, rank, world, idb), "dc_comm_create (ncclCommInitRank)")
+            comm, err = guarded(lambda: D.Comm(ctx, rank, world, idb, self_transport=(world == 1)),
+                                "dc_comm_create (ncclCommInitRank)")
             if isinstance(err, TimeoutError):
                 abandoned.append("dc_comm_create")
         if not all_ranks_ok(comm is not None):
@@ -434,12 +439,24 @@ def main():
             print("bench.py[rank %d]: WARNING: %s -- gathering with torch.distributed.gather instead" % (rank, gather_note),
                   file=sys.stderr, flush=True)
 
+    if dist is None and on_gpu and gather_kind == "abi":
+        # One GPU, no launcher: the end-of-region gather still runs, through the SAME carrier an N-GPU job uses --
+        # dc_gather_results over an RCCL communicator of one rank, rank 0 sending its block to itself (DC_COMM_SELF_TRANSPORT).
+        # Its first execution anywhere must not be the 8-GPU run's; a carrier that fails or hangs here costs the carrier only.
+        from densecap_amd import dist as D
+        comm, err = guarded(lambda: D.Comm(ctx, 0, 1, None, self_transport=True), "dc_comm_create (ncclCommInitRank, one rank)")
+        if isinstance(err, TimeoutError):
+            abandoned.append("dc_comm_create")
+        if comm is None:
+            gather_note = "dc_gather_results over RCCL unavailable at world 1 (%s)" % err
+            print("bench.py: WARNING: %s -- results are taken as returned" % gather_note, file=sys.stderr, flush=True)
+
     def gather(results):
-        if dist is None:
-            return [results]
         from densecap_amd import dist as D
         if comm is not None:                 # (rebound to None below if the RCCL carrier turns out unusable)
             return comm.gather(results, P, model.seq_length)
+        if dist is None:
+            return [results]
         return D.gather_records(dist, results, P, model.seq_length, rank, world, device=coll_device)
 
     # ---- setup (not a step): lane workspaces, lane-count trial, warm-up incl. the collective ------------------
@@ -484,13 +501,13 @@ def main():
         model.mfma_profile(reset=1)
     model.forward_batch_device(imgs, min(args.lanes, n_img), H, W)
     wres = model.forward_batch_device(imgs, max(Wm, 1), H, W)
-    if dist is not None:
+    if dist is not None or comm is not None:
         # communicator / buffer setup of the first collective is not part of a step; a carrier that fails here is replaced
         warm = ([wres[0]] * K)[:K]
         if comm is not None:
             _, err = guarded(lambda: gather(warm), "dc_gather_results (warm-up)")
             stuck = isinstance(err, TimeoutError)
-            if not all_ranks_ok(err is None):
+            if not (all_ranks_ok(err is None) if dist is not None else err is None):
                 if stuck:
                     abandoned.append(comm)        # a thread is still inside it: never touch it again
                 else:
@@ -499,7 +516,7 @@ def main():
                 gather_note = "dc_gather_results failed in the warm-up (%s)" % (err if err is not None else "on another rank")
                 print("bench.py[rank %d]: WARNING: %s -- gathering with torch.distributed.gather instead" % (rank, gather_note),
                       file=sys.stderr, flush=True)
-        if comm is None:
+        if comm is None and dist is not None:
             gather(warm)
     sync()
     if on_gpu and args.lanes == 1:
@@ -675,9 +692,9 @@ def main():
                                    "decode (T=15,V=10497), synthetic weights" % (W, H, P),
                        "images_per_gpu": K, "parallelism": "image-sharded x%d" % world,
                        "total_output_boxes": total_boxes,
-                       "gather": None if dist is None else ("dc_gather_results (RCCL send/recv)" if comm is not None
-                                                             else "torch.distributed.gather (%s)%s" % (
-                                                                 args.dist_backend, "; " + gather_note if gather_note else ""))},
+                       "gather": ("dc_gather_results (%s)" % comm.transport) if comm is not None else
+                                 ((None if gather_note is None else "none; " + gather_note) if dist is None else
+                                  "torch.distributed.gather (%s)%s" % (args.dist_backend, "; " + gather_note if gather_note else ""))},
             "repeats": {"n": nrep, "statistic": "median", "images_per_s": [world * K / e for e in elapsed_all],
                         "timed_seconds_total": sum(elapsed_all)},
             "per_rank_images_per_s": per_rank_rates,
@@ -837,9 +854,10 @@ def main():
         comm.close()
     if dist is not None:
         dist.barrier()
-        if abandoned:
-            sys.stdout.flush(); sys.stderr.flush()
-            os._exit(0)                   # a carrier call never returned on this rank: no orderly teardown possible
+    if abandoned:
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)                   # a carrier call never returned on this rank: no orderly teardown possible
+    if dist is not None:
         dist.destroy_process_group()
 
 

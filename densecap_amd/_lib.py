@@ -67,6 +67,8 @@ _SIGS = {
     "dc_debug_plan_gemm": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, c_int32_p]),
     "dc_comm_unique_id": (C.c_int, [C.c_void_p]),
     "dc_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "dc_comm_create_ex": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "dc_comm_transport": (C.c_char_p, [C.c_void_p]),
     "dc_comm_destroy": (None, [C.c_void_p]),
     "dc_comm_last_error": (C.c_char_p, [C.c_void_p]),
     "dc_gather_results": (C.c_int, [C.c_void_p, C.POINTER(DcResult), C.c_int, C.POINTER(DcResult)]),

@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -283,10 +284,20 @@ int dc_comm_unique_id(void* id_out) {
 
 const char* dc_comm_last_error(const dc_comm* c) { return c ? c->err.c_str() : g_comm_error.c_str(); }
 
-int dc_comm_create(dc_comm** out, dc_ctx* ctx, const void* id, int rank, int world) {
-  if (!out || !ctx || world < 1 || rank < 0 || rank >= world || (world > 1 && !id)) {
+int dc_comm_create_ex(dc_comm** out, dc_ctx* ctx, const void* id, int rank, int world, int flags) {
+  if (!out || !ctx || world < 1 || rank < 0 || rank >= world || (world > 1 && !id) || (flags & ~DC_COMM_SELF_TRANSPORT)) {
     g_comm_error = "dc_comm_create: bad arguments";
     return DC_E_INVALID;
+  }
+  // world == 1 normally needs no carrier at all (a host-side copy).  DC_COMM_SELF_TRANSPORT makes the single rank build
+  // the carrier anyway -- ncclCommInitRank with one rank (its own id when the caller passes none) -- and every gather
+  // then travels through the SAME staging, ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd calls as at world > 1,
+  // with rank 0 as its own peer: the multi-GPU code path can be executed (and is, by the tests and bench.py) on one GPU.
+  const bool self_tp = world == 1 && (flags & DC_COMM_SELF_TRANSPORT) != 0;
+  ncclUniqueId self_id;
+  if (self_tp && !id) {
+    if (int rc = dc_comm_unique_id(&self_id); rc != DC_OK) return rc;
+    id = &self_id;
   }
   dc_comm* c = new dc_comm();
   c->ctx = ctx; c->rank = rank; c->world = world; c->device = dc_ctx_device(ctx);
@@ -297,7 +308,7 @@ int dc_comm_create(dc_comm** out, dc_ctx* ctx, const void* id, int rank, int wor
     delete c;
     return DC_E_HIP;
   }
-  if (world > 1) {
+  if (world > 1 || self_tp) {
     if (memcmp(id, kLoopbackPrefix, sizeof(kLoopbackPrefix) - 1) == 0) {
       const char* p = static_cast<const char*>(id);
       c->tp = new LoopbackTransport(std::string(p, strnlen(p, DC_COMM_ID_BYTES)), rank);
@@ -318,7 +329,7 @@ int dc_comm_create(dc_comm** out, dc_ctx* ctx, const void* id, int rank, int wor
       }
       c->tp = t;
     }
-    if (hipMalloc(reinterpret_cast<void**>(&c->dev_hdr), (size_t)world * 16) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void**>(&c->dev_hdr), (size_t)(world + 1) * 16) != hipSuccess) {
       g_comm_error = "dc_comm_create: hipMalloc failed";
       delete c->tp;
       hipStreamDestroy(c->stream);
@@ -328,6 +339,19 @@ int dc_comm_create(dc_comm** out, dc_ctx* ctx, const void* id, int rank, int wor
   }
   *out = c;
   return DC_OK;
+}
+
+// DC_COMM_FORCE_RCCL=1 in the environment: every world == 1 communicator builds the carrier (see dc_comm_create_ex) --
+// lets an unmodified host (bench.py under torch.distributed.run with one rank, a LuaJIT script) exercise it.
+int dc_comm_create(dc_comm** out, dc_ctx* ctx, const void* id, int rank, int world) {
+  const char* e = getenv("DC_COMM_FORCE_RCCL");
+  return dc_comm_create_ex(out, ctx, id, rank, world, (e && e[0] == '1') ? DC_COMM_SELF_TRANSPORT : 0);
+}
+
+const char* dc_comm_transport(const dc_comm* c) {
+  if (!c) return "";
+  if (!c->tp) return "host copy";
+  return c->world == 1 ? (c->tp->name()[0] == 'r' ? "rccl, self" : "loopback, self") : c->tp->name();
 }
 
 void dc_comm_destroy(dc_comm* c) {
@@ -379,9 +403,10 @@ int dc_gather_results(dc_comm* c, const dc_result* local, int n_local, dc_result
     if (hipHostMalloc(&c->host_buf, need, hipHostMallocDefault) != hipSuccess)
       return c->fail(DC_E_NOMEM, "dc_gather_results: host staging allocation failed");
     c->host_bytes = need;
-    if (c->world > 1) {                                           // world == 1 is a host-side copy: no device buffer
-      if (hipMalloc(&c->dev_buf, need) != hipSuccess) return c->fail(DC_E_NOMEM, "dc_gather_results: device buffer allocation failed");
-      c->dev_bytes = need;
+    if (c->tp != nullptr) {                                       // without a carrier world == 1 is a host-side copy: no device buffer
+      const size_t dneed = c->world == 1 ? 2 * need : need;       // self transport: send block + receive block
+      if (hipMalloc(&c->dev_buf, dneed) != hipSuccess) return c->fail(DC_E_NOMEM, "dc_gather_results: device buffer allocation failed");
+      c->dev_bytes = dneed;
     }
   }
   // pack this rank's records (rank 0: into slot 0 of the gathered layout)
@@ -395,7 +420,33 @@ int dc_gather_results(dc_comm* c, const dc_result* local, int n_local, dc_result
     memcpy(p + 16 + (size_t)cap * 16, local[i].scores, K * 4);
     memcpy(p + 16 + (size_t)cap * 20, local[i].tokens, K * 4 * (size_t)T);
   }
-  if (c->world > 1) {
+  if (c->world == 1 && c->tp != nullptr) {
+    // Self transport: the single rank is sender and receiver of one block.  The same calls in the same order as a peer
+    // and rank 0 make between them at world > 1 -- shape words first (16 bytes there and back), then the payload: H2D
+    // staging, ONE group holding the receive and the send, D2H of the received block -- and the records that come back are
+    // what gets unpacked, so a carrier that drops, reorders or truncates bytes fails the byte-for-byte tests.
+    std::string err;
+    int32_t mine[4] = {n_local, cap, T, kShapeMagic};
+    HCHK(hipMemcpyAsync(c->dev_hdr, mine, 16, hipMemcpyHostToDevice, c->stream));
+    TCHK(c->tp->group_start(err));
+    TCHK(c->tp->recv(c->dev_hdr + 4, 16, 0, c->stream, err));
+    TCHK(c->tp->send(c->dev_hdr, 16, 0, c->stream, err));
+    TCHK(c->tp->group_end(c->stream, err));
+    int32_t back[4] = {0, 0, 0, 0};
+    HCHK(hipMemcpyAsync(back, c->dev_hdr + 4, 16, hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    if (memcmp(back, mine, 16) != 0) return c->fail(DC_E_STATE, "dc_gather_results: the self transport returned other shape words than were sent");
+    char* rx = static_cast<char*>(c->dev_buf) + block;
+    HCHK(hipMemsetAsync(rx, 0xff, block, c->stream));
+    HCHK(hipMemcpyAsync(c->dev_buf, hb, block, hipMemcpyHostToDevice, c->stream));
+    memset(hb, 0xee, block);                                      // what is unpacked below must have travelled
+    TCHK(c->tp->group_start(err));
+    TCHK(c->tp->recv(rx, block, 0, c->stream, err));
+    TCHK(c->tp->send(c->dev_buf, block, 0, c->stream, err));
+    TCHK(c->tp->group_end(c->stream, err));
+    HCHK(hipMemcpyAsync(hb, rx, block, hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+  } else if (c->world > 1) {
     std::string err;
     if (c->rank != 0) {
       HCHK(hipMemcpyAsync(c->dev_buf, hb, block, hipMemcpyHostToDevice, c->stream));

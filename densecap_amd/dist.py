@@ -86,7 +86,11 @@ def gather_records(dist, results, P, T, rank, world, device=None):
 class Comm:
     """dc_comm of the C ABI: RCCL communicator bound to a ctx; gather() is the path's single collective."""
 
-    def __init__(self, ctx, rank=0, world=1, unique_id=None):
+    SELF_TRANSPORT = 1          # DC_COMM_SELF_TRANSPORT (include/densecap.h)
+
+    def __init__(self, ctx, rank=0, world=1, unique_id=None, self_transport=False):
+        """self_transport (world == 1 only): build the carrier for the single rank too, so that gather() travels through
+        ncclSend / ncclRecv to itself -- the multi-GPU code path, executable on one GPU."""
         self.lib = ctx.lib
         self.ctx = ctx
         self.rank, self.world = int(rank), int(world)
@@ -94,11 +98,17 @@ class Comm:
             raise ValueError("world > 1 needs the 128-byte id made by Comm.unique_id() on rank 0")
         h = C.c_void_p()
         idbuf = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
-        rc = self.lib.dc_comm_create(C.byref(h), ctx.h, idbuf, self.rank, self.world)
+        rc = self.lib.dc_comm_create_ex(C.byref(h), ctx.h, idbuf, self.rank, self.world,
+                                        self.SELF_TRANSPORT if self_transport else 0)
         if rc < 0:
             msg = self.lib.dc_comm_last_error(None)
             raise _lib.DenseCapError("dc_comm_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
         self.h = h
+
+    @property
+    def transport(self):
+        t = self.lib.dc_comm_transport(self.h)
+        return t.decode() if t else ""
 
     @staticmethod
     def unique_id(lib=None):

@@ -195,6 +195,16 @@ typedef struct dc_comm dc_comm;
 int dc_comm_unique_id(void* id_out);
 /* Collective over all ranks (blocks until everyone has joined).  world == 1 needs no id and no RCCL. */
 int dc_comm_create(dc_comm** out, dc_ctx* ctx, const void* id, int rank, int world);
+/* The same with flags.  DC_COMM_SELF_TRANSPORT (world == 1 only; ignored otherwise): build the carrier for the single
+ * rank as well -- ncclCommInitRank with one rank (id may be NULL: the library makes one) -- and route every gather through
+ * the staging buffers and one ncclGroupStart / ncclRecv / ncclSend / ncclGroupEnd with rank 0 as its own peer, the calls a
+ * multi-GPU gather makes.  Lets the RCCL path be executed and checked byte for byte on a one-GPU machine.
+ * dc_comm_create behaves like this when the environment holds DC_COMM_FORCE_RCCL=1. */
+#define DC_COMM_SELF_TRANSPORT 1
+int dc_comm_create_ex(dc_comm** out, dc_ctx* ctx, const void* id, int rank, int world, int flags);
+/* What carries this communicator's gathers: "host copy" (world == 1, no carrier), "rccl", "rccl, self", "loopback",
+ * "loopback, self".  Static string. */
+const char* dc_comm_transport(const dc_comm* comm);
 void dc_comm_destroy(dc_comm* comm);
 const char* dc_comm_last_error(const dc_comm* comm);
 /* Gather `n_local` results (as filled by dc_forward_test / dc_forward_batch: same capacity and T on

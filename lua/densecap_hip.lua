@@ -52,6 +52,8 @@ int dc_stage_times(dc_ctx* ctx, const char** names, float* ms, int max_stages);
 typedef struct dc_comm dc_comm;
 int dc_comm_unique_id(void* id_out);
 int dc_comm_create(dc_comm** out, dc_ctx* ctx, const void* id, int rank, int world);
+int dc_comm_create_ex(dc_comm** out, dc_ctx* ctx, const void* id, int rank, int world, int flags);
+const char* dc_comm_transport(const dc_comm* comm);
 void dc_comm_destroy(dc_comm* comm);
 const char* dc_comm_last_error(const dc_comm* comm);
 int dc_gather_results(dc_comm* comm, const dc_result* local, int n_local, dc_result* gathered);
