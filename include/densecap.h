@@ -189,6 +189,7 @@ int dc_stage_times(dc_ctx* ctx, const char** names, float* ms, int max_stages);
  * and every peer one send inside a single group.  librccl is dlopen()ed by dc_comm_create (world > 1)
  * or dc_comm_unique_id; the single-GPU path does not depend on it. */
 #define DC_COMM_ID_BYTES 128
+#define DC_COMM_SELF_TRANSPORT 1 /* dc_comm_create_ex flag */
 typedef struct dc_comm dc_comm;
 /* Rank 0 creates the 128-byte rendezvous id (ncclUniqueId) and hands it to the other ranks out of
  * band (file, environment, launcher). */
@@ -200,7 +201,6 @@ int dc_comm_create(dc_comm** out, dc_ctx* ctx, const void* id, int rank, int wor
  * the staging buffers and one ncclGroupStart / ncclRecv / ncclSend / ncclGroupEnd with rank 0 as its own peer, the calls a
  * multi-GPU gather makes.  Lets the RCCL path be executed and checked byte for byte on a one-GPU machine.
  * dc_comm_create behaves like this when the environment holds DC_COMM_FORCE_RCCL=1. */
-#define DC_COMM_SELF_TRANSPORT 1
 int dc_comm_create_ex(dc_comm** out, dc_ctx* ctx, const void* id, int rank, int world, int flags);
 /* What carries this communicator's gathers: "host copy" (world == 1, no carrier), "rccl", "rccl, self", "loopback",
  * "loopback, self".  Static string. */
