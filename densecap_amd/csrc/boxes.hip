@@ -51,8 +51,8 @@ __global__ void apply_box_transform_kernel(const float* __restrict__ boxes, cons
   f32x4 o;
   o[0] = __fadd_rn(__fmul_rn(t[0], b[2]), b[0]);   // ApplyBoxTransform.lua:85-88
   o[1] = __fadd_rn(__fmul_rn(t[1], b[3]), b[1]);
-  o[2] = __fmul_rn(expf(t[2]), b[2]);
-  o[3] = __fmul_rn(expf(t[3]), b[3]);
+  o[2] = __fmul_rn(th_expf(t[2]), b[2]);
+  o[3] = __fmul_rn(th_expf(t[3]), b[3]);
   *reinterpret_cast<f32x4*>(out + (size_t)i * 4) = o;
 }
 
@@ -154,8 +154,8 @@ __global__ void rpn_decode_kernel(const float* __restrict__ heads, int h, int w,
   f32x4 bx;
   bx[0] = __fadd_rn(__fmul_rn(t[0], wa), xa);
   bx[1] = __fadd_rn(__fmul_rn(t[1], ha), ya);
-  bx[2] = __fmul_rn(expf(t[2]), wa);
-  bx[3] = __fmul_rn(expf(t[3]), ha);
+  bx[2] = __fmul_rn(th_expf(t[2]), wa);
+  bx[3] = __fmul_rn(th_expf(t[3]), ha);
   // "Maybe clip boxes to image boundary" (LocalizationLayer.lua:272-300): with test_clip_boxes = false the boxes stay as
   // transformed and every row is a candidate
   f32x4 cb = bx;
@@ -169,7 +169,7 @@ __global__ void rpn_decode_kernel(const float* __restrict__ heads, int h, int w,
     *reinterpret_cast<f32x4*>(xyxy + (size_t)b * 4) = f32x4{c0, c1, c2, c3};
   }
   if (p_out) {
-    const float e1 = expf(s1), e2 = expf(s2);
+    const float e1 = th_expf(s1), e2 = th_expf(s2);
     p_out[b] = __fmul_rn(__fdiv_rn(1.f, __fadd_rn(e1, e2)), e1);   // pow(-1):cmul (LocalizationLayer.lua:308)
   }
   if (valid) valid[b] = v ? 1 : 0;

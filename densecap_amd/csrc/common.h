@@ -11,6 +11,14 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// TH / THNN of the reference's era compute exp, sigmoid and tanh of a FloatTensor through the C DOUBLE functions and cast
+// the result to float (TH: LAB_IMPLEMENT_BASIC_FUNCTION(exp, exp), TH_sigmoid(double) = 1.0 / (1.0 + exp(-x)), tanh;
+// docs/SEMANTICS.md).  Both sides of the parity tests use this form: a double result is within an ulp of the true value
+// in any libm, so the float it rounds to is the same on the device and in the oracle (bar one case in ~2^29).
+__device__ __forceinline__ float th_expf(float x) { return (float)exp((double)x); }
+__device__ __forceinline__ float th_sigmoidf(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }
+__device__ __forceinline__ float th_tanhf(float x) { return (float)tanh((double)x); }
+
 // ---- ctx accessors for the other translation units (densecap.hip) ------------------
 int dc_ctx_device(const dc_ctx* ctx);
 void dc_ctx_set_error(dc_ctx* ctx, const char* msg);
@@ -122,6 +130,7 @@ hipError_t launch_chw_to_hwc(const float* in, float* out, int C, int H, int W, h
 hipError_t launch_hwc_to_chw(const float* in, float* out, int C, int H, int W, hipStream_t s);
 hipError_t launch_pack_conv3x3(const float* w_oihw, float* w_packed, int Cout, int Cin, hipStream_t s);
 int device_cu_count();      // compute units of the current device (256 on MI355X); cached per device
+void set_planning_cu_override(int cus);   // dc_debug_plan_gemm only: this thread's planners see `cus` CUs until reset with 0
 hipError_t launch_conv3x3_c3(const float* in_chw, const float* w_oihw, const float* bias, float* out_hwc, int nimg,
                              int H, int W, int Cout, int relu, hipStream_t s);
 hipError_t launch_maxpool2x2_ceil(const float* in, float* out, int nimg, int H, int W, int C, hipStream_t s);

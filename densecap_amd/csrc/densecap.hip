@@ -6,6 +6,7 @@
 // (box counts stay on the device); the host waits once, for the result copy.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -113,6 +114,7 @@ struct dc_ctx {
   bool graphs = false;      // dc_set_graph_replay: repeated forwards of one shape are relaunched as a captured hipGraph
   uint64_t weights_epoch = 0;
   int graph_launches = 0, graph_captures = 0;    // dc_debug_fetch "graph_launches" / "graph_captures"
+  std::string graph_note;                        // why replay was dropped, if it was (dc_debug_fetch "graph_replay_on" == 0)
   // dims
   int k = 0, R = 0, V = 0, T = 0, E = 0, Hd = 0, D = 0;
   float fc[4] = {0, 0, 0, 0};
@@ -380,7 +382,7 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P, int G) {
       {(void**)&L.gates, GP * 4 * Hd * 4},
       {(void**)&L.hstate, GP * Hd * 4},
       {(void**)&L.cstate, GP * Hd * 4},
-      {(void**)&L.logits, GP * V1 * 4},
+      {(void**)&L.logits, GP * (size_t)std::max(V1, ctx->V1pad / 16) * 4},   // full logits (beam) or 2 x V1pad/32 arg-max partials per row
       {(void**)&L.tok, GP * 4},
       {(void**)&L.seq, GP * Tn * 4},
       {(void**)&L.out_boxes, GP * 16},
@@ -780,10 +782,17 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
       if (rc == DC_OK && e == hipSuccess && graph != nullptr) e2 = hipGraphInstantiate(&L.gexec, graph, nullptr, nullptr, 0);
       if (graph != nullptr) (void)hipGraphDestroy(graph);
       if (rc != DC_OK || e != hipSuccess || e2 != hipSuccess || L.gexec == nullptr) {
-        // a forward that cannot be captured on this runtime: say so once, stay eager on this ctx
+        // a forward that cannot be captured on this runtime: say so once (stderr + dc_last_error text, no error code:
+        // the forward itself still runs, eagerly), stay eager on this ctx; dc_debug_fetch "graph_replay_on" reads 0 from here on
+        const hipError_t why = e != hipSuccess ? e : e2;
         (void)hipGetLastError();
         L.gexec = nullptr;
         ctx->graphs = false;
+        char note[256];
+        snprintf(note, sizeof note, "dc_set_graph_replay: capture of a %dx%d forward failed (%s); graph replay is now OFF for this ctx",
+                 L.W, L.H, rc != DC_OK ? ctx->err.c_str() : hipGetErrorString(why));
+        fprintf(stderr, "libdensecap_hip: %s\n", note);
+        ctx->graph_note = note;
         if (rc != DC_OK) return rc;
         DCCHK(enqueue_body(ctx, L, g, features_only, true));
       } else {
@@ -1151,6 +1160,9 @@ static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, i
     if (outs[i].capacity <= 0) return ctx->fail(DC_E_INVALID, "dc_result.capacity must be > 0");
   // images travel in groups of G through a lane (dc_set_group): the group's dense stages share launches
   int G = std::max(1, std::min(ctx->group > 0 ? ctx->group : 1, n));
+  // Single-image planning (dc_set_lanes(1)) shares a layer's partial last round along K -- plans made for ONE image's tile
+  // count, which a group does not have: images travel alone there, so that results never depend on the group.
+  if (ctx->plan_mode < 0 ? ctx->serial_mode : ctx->plan_mode == 1) G = 1;
   // a group's conv1_x activation shares one 32-bit offset space; the pooled conv counts window slots (4 per 2x2 window: a
   // pixel more per odd side) -- the same count the launch itself checks
   const size_t rows1 = std::max((size_t)H * W, (size_t)4 * ((H + 1) / 2) * ((W + 1) / 2));
@@ -1313,6 +1325,12 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
     *static_cast<int32_t*>(host_buf) = name[6] == 'l' ? ctx->graph_launches : ctx->graph_captures;
     return 1;
   }
+  if (strcmp(name, "graph_replay_on") == 0) {
+    if (capacity_bytes < 4) return ctx->fail(DC_E_INVALID, "dc_debug_fetch: buffer too small");
+    *static_cast<int32_t*>(host_buf) = ctx->graphs ? 1 : 0;
+    if (!ctx->graphs && !ctx->graph_note.empty()) ctx->err = ctx->graph_note;      // readable through dc_last_error
+    return 1;
+  }
   if (strcmp(name, "arena_allocs") == 0) {
     if (capacity_bytes < 4) return ctx->fail(DC_E_INVALID, "dc_debug_fetch: buffer too small");
     *static_cast<int32_t*>(host_buf) = ctx->arena_allocs;
@@ -1342,7 +1360,15 @@ int dc_debug_plan_gemm(int64_t M, int64_t N, int64_t K, int64_t plan_M, int conv
   if (conv_cin) { d.conv = 1; d.Cin = conv_cin; }
   if (argmax) d.amax_val = &dummy;
   GemmPlan pl;
+  // (DC_PLAN_CU_COUNT: "what would a part with this many CUs be given" -- honoured by THIS query only, never by a launch)
+  int cu_override = 0;
+  if (const char* e = getenv("DC_PLAN_CU_COUNT")) {
+    const int nc = atoi(e);
+    if (nc >= 8 && nc <= 4096) cu_override = nc;
+  }
+  set_planning_cu_override(cu_override);
   mfma_gemm_plan(d, serial_mode != 0, 0, kSplitkWsFloats, &pl);
+  set_planning_cu_override(0);
   const int32_t v[8] = {pl.kind, pl.route, pl.stages, pl.splitk, pl.m_split, pl.sk_wgs, pl.sk_np, pl.tail_splitk};
   memcpy(out8, v, sizeof(v));
   return DC_OK;
@@ -1565,7 +1591,7 @@ int dc_op_lm_sample(dc_ctx* ctx, const float* codes, int n, int32_t* tokens) {
   const int E = ctx->E, Hd = ctx->Hd, V1 = ctx->V + 1;
   struct Sav { float *enc, *gates, *h, *c, *logits; int32_t* tok; } sv{L.enc, L.gates, L.hstate, L.cstate, L.logits, L.tok};
   const size_t bytes = al((size_t)n * E * 4) + al((size_t)n * 4 * Hd * 4) + 2 * al((size_t)n * Hd * 4) +
-                       al((size_t)n * V1 * 4) + al((size_t)n * 4);
+                       al((size_t)n * std::max(V1, ctx->V1pad / 16) * 4) + al((size_t)n * 4);
   char* base = nullptr;
   HIPCHK(hipMalloc((void**)&base, bytes));
   char* p = base;
@@ -1573,7 +1599,7 @@ int dc_op_lm_sample(dc_ctx* ctx, const float* codes, int n, int32_t* tokens) {
   L.gates = (float*)p; p += al((size_t)n * 4 * Hd * 4);
   L.hstate = (float*)p; p += al((size_t)n * Hd * 4);
   L.cstate = (float*)p; p += al((size_t)n * Hd * 4);
-  L.logits = (float*)p; p += al((size_t)n * V1 * 4);
+  L.logits = (float*)p; p += al((size_t)n * std::max(V1, ctx->V1pad / 16) * 4);
   L.tok = (int32_t*)p;
   int rc = ctx->beam_size > 0 ? lm_beamsearch(ctx, L, codes, n, tokens, s) : lm_sample(ctx, L, codes, n, 0, nullptr, tokens);
   hipError_t e2 = hipStreamSynchronize(s);

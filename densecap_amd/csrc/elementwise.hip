@@ -201,7 +201,7 @@ __global__ void maxpool2x2_ceil_kernel(const float* __restrict__ in, float* __re
 }
 
 // ---- LSTM point-wise (torch-rnn nn.LSTM step; gate order i,f,o,g) ----------------------------
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return th_sigmoidf(x); }
 __global__ void lstm_pointwise_kernel(const float* __restrict__ gates, float* __restrict__ c, float* __restrict__ h,
                                       int n, const int32_t* __restrict__ n_dev, int Hd, int zero_c) {
   if (n_dev) n = min(n, *n_dev);
@@ -211,11 +211,11 @@ __global__ void lstm_pointwise_kernel(const float* __restrict__ gates, float* __
     const int j = (int)(i % Hd);
     const float* g = gates + m * 4 * Hd;
     const float ig = sigmoidf_(g[j]), fg = sigmoidf_(g[Hd + j]), og = sigmoidf_(g[2 * Hd + j]);
-    const float gg = tanhf(g[3 * Hd + j]);
+    const float gg = th_tanhf(g[3 * Hd + j]);
     const float cp = zero_c ? 0.f : c[i];
     const float cn = fg * cp + ig * gg;
     c[i] = cn;
-    h[i] = og * tanhf(cn);
+    h[i] = og * th_tanhf(cn);
   }
 }
 
@@ -299,11 +299,11 @@ __global__ __launch_bounds__(256) void lstm_step_tail_kernel(const float* __rest
       float gi = gpre[u][0], gf = gpre[u][1], go = gpre[u][2], gg = gpre[u][3];
       if (x != nullptr) { gi = x[j] + gi; gf = x[Hd + j] + gf; go = x[2 * Hd + j] + go; gg = x[3 * Hd + j] + gg; }
       const float ig = sigmoidf_(gi), fg = sigmoidf_(gf), og = sigmoidf_(go);
-      const float gt = tanhf(gg);
+      const float gt = th_tanhf(gg);
       const size_t i = (size_t)m * Hd + j;
       const float cn = fg * cprev[u] + ig * gt;
       c[i] = cn;
-      h[i] = og * tanhf(cn);
+      h[i] = og * th_tanhf(cn);
     }
   }
 }
@@ -409,8 +409,8 @@ __global__ __launch_bounds__(256) void recog_heads_kernel(const float* __restric
     // nn.ApplyBoxTransform (ApplyBoxTransform.lua:85-88); no FMA contraction to keep op order
     fin[row * 4 + 0] = __fadd_rn(__fmul_rn(s[1], wa), xa);
     fin[row * 4 + 1] = __fadd_rn(__fmul_rn(s[2], ha), ya);
-    fin[row * 4 + 2] = __fmul_rn(expf(s[3]), wa);
-    fin[row * 4 + 3] = __fmul_rn(expf(s[4]), ha);
+    fin[row * 4 + 2] = __fmul_rn(th_expf(s[3]), wa);
+    fin[row * 4 + 3] = __fmul_rn(th_expf(s[4]), ha);
   }
 }
 

@@ -1122,13 +1122,14 @@ __global__ __launch_bounds__(256) void mfma_gemm_sk_kernel(GemmDesc d, int ntn) 
 }  // namespace
 
 // compute units of the current device (256 on MI355X); cached per device
+// Planning tests (tests/test_gemm_plan.py): the planners are pure functions of the problem AND the CU count.
+// dc_debug_plan_gemm -- and nothing else -- may ask what a part with another CU count would be given: the override lives in
+// the calling thread for the duration of that one query (advisor finding, round 4: an environment variable read here
+// reached the launch paths and the stream-K co-residency guard as well).
+static thread_local int g_planning_cus = 0;
+void set_planning_cu_override(int cus) { g_planning_cus = cus; }
 int device_cu_count() {
-  // planning tests (tests/test_gemm_plan.py): the planners are pure functions of the problem AND the CU count; the
-  // environment variable lets a CPU-only test ask what another part would be given (never set by the product)
-  if (const char* e = getenv("DC_PLAN_CU_COUNT")) {
-    const int n = atoi(e);
-    if (n >= 8 && n <= 4096) return n;
-  }
+  if (g_planning_cus > 0) return g_planning_cus;
   static std::mutex mu;
   static std::vector<int> cus;
   int dev = 0;

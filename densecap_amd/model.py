@@ -139,10 +139,18 @@ class DenseCapModel:
         Keys it does not know are ignored (evaluate_model.lua:39-43 passes `max_proposals=`, which the reference never
         reads: that caller runs with 1000 proposals)."""
         kwargs = dict(args or {}, **kw)
-        self.nets.localization_layer.setTestArgs(nms_thresh=getopt(kwargs, "rpn_nms_thresh", 0.7),
-                                                 max_proposals=getopt(kwargs, "num_proposals", 1000))
-        self.opt["final_nms_thresh"] = float(getopt(kwargs, "final_nms_thresh", 0.3))
-        self._push_test_args()
+        ll = self.nets.localization_layer
+        # a value the library refuses (num_proposals = 0, 2000000 ...) must not stay behind in the object: every later
+        # forward would re-raise in _push_test_args (advisor finding, round 4).  The previous state comes back on failure.
+        saved = (ll.test_clip_boxes, ll.test_nms_thresh, ll.test_max_proposals, self.opt["final_nms_thresh"])
+        try:
+            ll.setTestArgs(nms_thresh=getopt(kwargs, "rpn_nms_thresh", 0.7),
+                           max_proposals=getopt(kwargs, "num_proposals", 1000))
+            self.opt["final_nms_thresh"] = float(getopt(kwargs, "final_nms_thresh", 0.3))
+            self._push_test_args()
+        except Exception:
+            ll.test_clip_boxes, ll.test_nms_thresh, ll.test_max_proposals, self.opt["final_nms_thresh"] = saved
+            raise
         return self
 
     def _push_test_args(self):

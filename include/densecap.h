@@ -139,14 +139,15 @@ int dc_forward_images(dc_ctx* ctx, const float* const* imgs, const int* H, const
  * rows advance as two blocks on two streams (same arithmetic per row); per-kernel profiling (dc_mfma_profile)
  * keeps every kernel on one stream.  Results are bit-identical for a given lanes setting however images are batched. */
 int dc_set_lanes(dc_ctx* ctx, int lanes);
-/* Images per GROUP inside dc_forward_batch: with 2, the two images of a group share the launches of the dense stages
- * (the convolutions run over both images, fc6/fc7 and the decode over both images' RoI rows: fuller tile rounds, half
- * the launches per image) while the per-image stages (RPN decode, NMS, RoI pooling, final NMS) follow each other.
- * 0 or 1 (default) = every image on its own.  Measured at 720x600 / 1000 proposals: on ONE lane pairs give 152.6 vs
- * 146.0 images/s (at twice the per-image latency); with two or more lanes the lanes already fill each other's partial
- * rounds and pairs change nothing (173 vs 175).  Every decision that changes a sum's order (kernel route, split-K
- * factor) is planned per image, so an image's results do not depend on the group it travels in (bit-identical, like
- * the lane count). */
+/* Images per GROUP inside dc_forward_batch, 1 .. 4 (0 or 1 = every image on its own, the default): the images of a
+ * group share the launches of the dense stages (the convolutions run over all of them, fc6 / fc7 and the decode over all
+ * their RoI rows: fuller tile rounds, a fraction of the launches per image) and of the batched per-image kernels (RPN
+ * decode, RoI pooling, gathers); the NMS runs follow each other.  Every decision that changes a sum's order (kernel
+ * route, split-K factor) is planned on ONE image's problem, so an image's results do not depend on the group it travels
+ * in (bit-identical, like the lane count; tests/fuzz_groups.py).  In single-image mode (dc_set_lanes(1)) the setting is
+ * ignored and images travel alone: that mode shares a layer's partial last tile round along K, a plan made for one
+ * image's tile count.  Measured at 720x600 / 1000 proposals: 183 images/s with groups of four on two or four lanes against
+ * 182 ungrouped; 317 against 285 at 300 proposals. */
 int dc_set_group(dc_ctx* ctx, int images);
 /* Caption order. 0 (default) = the reference's order: LanguageModel:sample runs on all num_proposals
  * RoIs and the final NMS then keeps K rows (DenseCapModel.lua:127-162,261-275).  1 = run the final NMS
@@ -160,7 +161,9 @@ int dc_set_caption_order(dc_ctx* ctx, int after_final_nms);
  * count: the kernels and their arguments are the captured ones, results are bit-identical.  Pays in the latency regime
  * (one image in flight, small proposal counts: the webcam daemon); with two or more lanes the other lane already fills
  * the gaps.  Stage times (dc_stage_times) are not available for replayed forwards; beam search and per-launch
- * profiling stay eager. */
+ * profiling stay eager.  A forward that this runtime cannot capture turns replay off for the ctx: the forward still runs
+ * (eagerly, DC_OK), one warning goes to stderr, and dc_debug_fetch(ctx, "graph_replay_on") reads 0 with the reason
+ * left in dc_last_error. */
 int dc_set_graph_replay(dc_ctx* ctx, int on);
 /* LanguageModel.beam_size (LanguageModel.lua:129-131): 0 (default) = greedy LM:sample; 1..32 = LM:beamsearch
  * (LanguageModel.lua:170-290) with that many beams.  Ties in torch.topk (unspecified in the reference; they occur for

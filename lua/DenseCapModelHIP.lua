@@ -141,12 +141,22 @@ end
 -- -> 0.7 / 1000 / 0.3), unknown keys are ignored (evaluate_model.lua:39-43 passes `max_proposals=`: that caller runs
 -- with 1000 proposals), and -- the layer's setTestArgs being called without `clip_boxes` -- box clipping is back on.
 function Model:setTestArgs(kwargs)
-  self.nets.localization_layer:setTestArgs{
-    nms_thresh = getopt(kwargs, 'rpn_nms_thresh', 0.7),
-    max_proposals = getopt(kwargs, 'num_proposals', 1000)
-  }
-  self.opt.final_nms_thresh = getopt(kwargs, 'final_nms_thresh', 0.3)
-  self:_push_test_args()
+  local ll = self.nets.localization_layer
+  -- a value the library refuses must not stay behind in the object (every later forward would fail in _push_test_args):
+  -- the previous state comes back before the error travels on
+  local saved = {ll.test_clip_boxes, ll.test_nms_thresh, ll.test_max_proposals, self.opt.final_nms_thresh}
+  local ok, err = pcall(function()
+    self.nets.localization_layer:setTestArgs{
+      nms_thresh = getopt(kwargs, 'rpn_nms_thresh', 0.7),
+      max_proposals = getopt(kwargs, 'num_proposals', 1000)
+    }
+    self.opt.final_nms_thresh = getopt(kwargs, 'final_nms_thresh', 0.3)
+    self:_push_test_args()
+  end)
+  if not ok then
+    ll.test_clip_boxes, ll.test_nms_thresh, ll.test_max_proposals, self.opt.final_nms_thresh = unpack(saved)
+    error(err, 0)
+  end
 end
 -- the current values travel to the library before every forward (LocalizationLayer.lua:250-256 and DenseCapModel.lua:261
 -- read the fields at call time; train.lua:139-143 writes them directly)

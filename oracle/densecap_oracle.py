@@ -211,6 +211,26 @@ def reshape_box_features(x, k):
     return np.ascontiguousarray(x.reshape(k, d, h, w).transpose(0, 2, 3, 1)).reshape(k * h * w, d)
 
 
+def th_exp(x):
+    """torch.exp on a FloatTensor as 2016-era TH computes it: the C double `exp` on every element, result cast to float
+    (TH generic/THTensorMath.c LAB_IMPLEMENT_BASIC_FUNCTION(exp,exp); the TH sources are not in /root/reference --
+    recorded as an assumption in docs/SEMANTICS.md).  Overflow sits where the float result overflows (x > ~88.72 -> inf)."""
+    with np.errstate(over="ignore", invalid="ignore"):
+        return np.exp(np.asarray(x, F32).astype(np.float64)).astype(F32)
+
+
+def th_sigmoid(x):
+    """TH_sigmoid (THMath.h): 1.0 / (1.0 + exp(-x)) in double, cast to float -- torch-rnn's LSTM gates (`:sigmoid()`)."""
+    import torch
+    return (1.0 / (1.0 + torch.exp(-x.double()))).float()
+
+
+def th_tanh(x):
+    """`:tanh()` on a FloatTensor: the C double tanh, cast to float."""
+    import torch
+    return torch.tanh(x.double()).float()
+
+
 def apply_box_transform(boxes, trans):
     """nn.ApplyBoxTransform (ApplyBoxTransform.lua:63-90)."""
     b = np.asarray(boxes, F32).reshape(-1, 4)
@@ -218,8 +238,8 @@ def apply_box_transform(boxes, trans):
     out = np.empty_like(b)
     out[:, 0] = t[:, 0] * b[:, 2] + b[:, 0]
     out[:, 1] = t[:, 1] * b[:, 3] + b[:, 1]
-    out[:, 2] = np.exp(t[:, 2]) * b[:, 2]
-    out[:, 3] = np.exp(t[:, 3]) * b[:, 3]
+    out[:, 2] = th_exp(t[:, 2]) * b[:, 2]
+    out[:, 3] = th_exp(t[:, 3]) * b[:, 3]
     return out.reshape(np.shape(boxes))
 
 
@@ -402,7 +422,7 @@ def rpn_decode(box_head, score_head, img_h, img_w, anchors=DEFAULT_ANCHORS,
     keep = np.nonzero(valid)[0]
     boxes_c = clipped[keep]; anc_c = anc[keep]; trans_c = trans[keep]; sc_c = scores2[keep]
     x1y1x2y2 = xcycwh_to_x1y1x2y2(boxes_c)
-    e = np.exp(sc_c)
+    e = th_exp(sc_c)
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         p = (F32(1) / (e[:, 0] + e[:, 1])) * e[:, 0]   # pow(-1) then cmul (LocalizationLayer.lua:308)
     return dict(boxes=boxes_c, anchors=anc_c, trans=trans_c, scores2=sc_c,
@@ -416,10 +436,10 @@ def lstm_step(x_gates, h, c, Wh):
     import torch
     Hd = h.shape[1]
     g = x_gates + h @ Wh
-    i = torch.sigmoid(g[:, :Hd]); f = torch.sigmoid(g[:, Hd:2 * Hd])
-    o = torch.sigmoid(g[:, 2 * Hd:3 * Hd]); gg = torch.tanh(g[:, 3 * Hd:])
+    i = th_sigmoid(g[:, :Hd]); f = th_sigmoid(g[:, Hd:2 * Hd])
+    o = th_sigmoid(g[:, 2 * Hd:3 * Hd]); gg = th_tanh(g[:, 3 * Hd:])
     c2 = f * c + i * gg
-    h2 = o * torch.tanh(c2)
+    h2 = o * th_tanh(c2)
     return h2, c2
 
 

@@ -26,5 +26,12 @@ for (H, Wd, P, seed) in SETTINGS:
             r[key] = r[key][:4]
     rows.append(r)
     print(json.dumps(r, default=str), flush=True)
+ks = [r[k] for r in rows for k in ("rpn_k_needed", "final_k_needed") if r.get(k) is not None]
+summary = dict(images=len(rows), replayed_lists=len(ks), max_k_needed=max(ks) if ks else None, FLIP_K=parity.FLIP_K,
+               k_ladder=list(parity.K_LADDER),
+               note="k_needed = smallest k at which the flip replay reproduces the HIP list: a flipped decision's oracle margin "
+                    "over the discrepancy observed for its operands; FLIP_K is set to twice the largest value any report has needed")
+print(json.dumps(summary), flush=True)
+rows.append(dict(_summary=summary))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "parity_report.json"), "w"), indent=1, default=str)

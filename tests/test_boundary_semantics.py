@@ -142,6 +142,33 @@ def test_test_args_survive_the_t7_round_trip(tmp_path):
     assert t7.weights_from_checkpoint(t7.load(str(q)))["test_args"] == ta
 
 
+def test_a_refused_setTestArgs_leaves_the_previous_state_usable():
+    """Advisor finding (round 4): setTestArgs wrote num_proposals into the object BEFORE the ABI validated it; a refused value
+    (0, 2000000) then made every later forward re-raise in _push_test_args.  The previous values come back on failure."""
+    from densecap_amd._lib import DenseCapError
+    m, lib = _model()
+    m.setTestArgs(rpn_nms_thresh=0.6, final_nms_thresh=0.2, num_proposals=77)
+    before = _state(lib)
+
+    class _Refusing(_RecordingLib):
+        def __getattr__(self, name):
+            fn = _RecordingLib.__getattr__(self, name)
+            if name == "dc_set_test_args":
+                return lambda *a: -5
+            if name == "dc_last_error":
+                return lambda *a: b"num_proposals must be -1 (uncapped) or in [1,1048576] (got 0)"
+            return fn
+    good = m.lib
+    m.lib = m.ctx.lib = _Refusing()
+    with pytest.raises(DenseCapError):
+        m.setTestArgs(num_proposals=0)
+    m.lib = m.ctx.lib = good
+    ll = m.nets.localization_layer
+    assert (ll.test_nms_thresh, ll.test_max_proposals, m.opt["final_nms_thresh"]) == (0.6, 77, 0.2)
+    m._push_test_args()                                   # what every forward does first: must not raise
+    assert _state(lib) == before
+
+
 # ---- the Lua twin (text checks: no LuaJIT in this image) -----------------------------------------------------------------
 def _lua():
     return open(os.path.join(ROOT, "lua", "DenseCapModelHIP.lua")).read()
@@ -162,7 +189,10 @@ def test_lua_setTestArgs_has_the_reference_defaults_and_no_persistent_merge():
     assert re.search(r"max_proposals\s*=\s*getopt\(kwargs,\s*'num_proposals',\s*1000\)", body)
     assert re.search(r"final_nms_thresh\s*=\s*getopt\(kwargs,\s*'final_nms_thresh',\s*0\.3\)", body)
     assert "pairs(kwargs" not in body                       # round 3 merged the table into persistent state
-    assert "localization_layer:setTestArgs{" in body and "clip_boxes" not in body
+    call = re.search(r"localization_layer:setTestArgs\{(.*?)\}", body, flags=re.S)
+    assert call and "clip_boxes" not in call.group(1)      # no clip_boxes key: the layer's default (true) comes back
+    # a refused value does not stay behind (advisor finding, round 4): the previous state is restored before the error travels on
+    assert "pcall(" in body and "unpack(saved)" in body and "error(err" in body
     layer = _lua_function(src, "function ll.setTestArgs(layer, args)")
     assert re.search(r"getopt\(args,\s*'clip_boxes',\s*true\)", layer)
     assert re.search(r"getopt\(args,\s*'nms_thresh',\s*0\.7\)", layer)

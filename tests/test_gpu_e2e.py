@@ -383,6 +383,19 @@ def test_randomised_shapes_and_thresholds_match_oracle():
     assert "FUZZ OK: 10/10" in p.stdout
 
 
+def test_randomised_groups_and_lanes_are_pure_scheduling():
+    """tests/fuzz_groups.py: random (lanes, group) settings -- including single-image mode with a group setting, which
+    include/densecap.h documents as ignored there -- give every image of a batch the bits it gets alone."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_groups.py"), "12", "3"], capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "GROUP FUZZ OK: 12/12" in p.stdout
+    assert '"lanes": 1' in p.stdout                      # the seed draws single-image cases
+
+
 def test_lane_count_is_a_pure_scheduling_knob(model, weights):
     """Any lanes >= 2 must give bit-identical results (bench.py picks the count by an untimed trial)."""
     from densecap_amd.weights import make_synthetic_image
@@ -818,6 +831,47 @@ def test_clip_boxes_false_matches_oracle(model, weights):
     assert model.nets.localization_layer.test_clip_boxes is True
     valid, _ = model.debug_fetch("rpn_valid", (A,), np.uint8)
     assert r2["matched"] == r2["K_oracle"] and len(unclipped[0]) > 0
+
+
+def test_overflowing_rpn_logits_end_to_end(weights):
+    """a9 end to end: an RPN score head scaled until its logits reach +-60..+-120.  The device's p (inf/NaN/0 rows included)
+    equals the oracle's decode of the device's own head tensor bit for bit, the RPN NMS -- NaN ranked first -- picks the
+    same rows as the oracle on the same inputs, and the forward still returns boxes."""
+    from densecap_amd import DenseCapModel
+    from densecap_amd.weights import make_synthetic_image
+    from oracle import densecap_oracle as O
+    Wt = dict(weights)
+    Wt["rpn_score_w"] = weights["rpn_score_w"] * 400.0
+    Wt["rpn_score_b"] = weights["rpn_score_b"] * 400.0
+    m = DenseCapModel(Wt, device=0)
+    try:
+        H, Wd, P = 224, 288, 100
+        m.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
+        boxes, scores, tokens = m.forward_raw(make_synthetic_image(H, Wd, 3))
+        fh, fw = (H + 15) // 16, (Wd + 15) // 16
+        k = O.DEFAULT_ANCHORS.shape[1]
+        A = k * fh * fw
+        heads, _ = m.debug_fetch("rpn_heads", (fh, fw, 6 * k))
+        sc = heads[..., 4 * k:]
+        assert np.abs(sc).max() > 100 and (np.abs(sc) > 89).mean() > 0.05, float(np.abs(sc).max())
+        chw = heads.transpose(2, 0, 1)
+        o = O.rpn_decode(np.ascontiguousarray(chw[:4 * k]), np.ascontiguousarray(chw[4 * k:]), H, Wd)
+        p, _ = m.debug_fetch("rpn_p", (A,))
+        valid, _ = m.debug_fetch("rpn_valid", (A,), np.uint8)
+        xyxy, _ = m.debug_fetch("rpn_x1y1x2y2", (A, 4))
+        np.testing.assert_array_equal(valid.astype(bool), o["valid"])
+        rows = o["rows"]
+        a, b = p[rows], o["p"]
+        same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+        assert same.mean() >= 1 - 1e-5 and np.isnan(a).sum() > 0, (float(same.mean()), int(np.isnan(a).sum()))
+        idx, _ = m.debug_fetch("rpn_nms_idx", (P,), np.int32)
+        cnt, _ = m.debug_fetch("rpn_nms_count", (1,), np.int32)
+        B = int(cnt[0])
+        tf = O.nms(np.concatenate([xyxy[rows], a[:, None]], 1), 0.7, P)
+        np.testing.assert_array_equal(idx[:B], rows[tf])
+        assert np.isnan(p[idx[0]]) and len(boxes) > 0 and np.isfinite(boxes).all()
+    finally:
+        m.ctx.close()
 
 
 def test_beam_scratch_is_recarved_when_beam_or_chunk_grows():
