@@ -439,6 +439,7 @@ int dc_gather_results(dc_comm* c, const dc_result* local, int n_local, dc_result
     char* rx = static_cast<char*>(c->dev_buf) + block;
     HCHK(hipMemsetAsync(rx, 0xff, block, c->stream));
     HCHK(hipMemcpyAsync(c->dev_buf, hb, block, hipMemcpyHostToDevice, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));                        // (the pinned staging is read by the copy engine until here)
     memset(hb, 0xee, block);                                      // what is unpacked below must have travelled
     TCHK(c->tp->group_start(err));
     TCHK(c->tp->recv(rx, block, 0, c->stream, err));

@@ -833,27 +833,32 @@ def test_clip_boxes_false_matches_oracle(model, weights):
     assert r2["matched"] == r2["K_oracle"] and len(unclipped[0]) > 0
 
 
-def test_overflowing_rpn_logits_end_to_end(weights):
+def test_overflowing_rpn_logits_end_to_end(model, weights):
     """a9 end to end: an RPN score head scaled until its logits reach +-60..+-120.  The device's p (inf/NaN/0 rows included)
     equals the oracle's decode of the device's own head tensor bit for bit, the RPN NMS -- NaN ranked first -- picks the
     same rows as the oracle on the same inputs, and the forward still returns boxes."""
     from densecap_amd import DenseCapModel
     from densecap_amd.weights import make_synthetic_image
     from oracle import densecap_oracle as O
+    H, Wd, P = 224, 288, 100
+    fh, fw = (H + 15) // 16, (Wd + 15) // 16
+    k = O.DEFAULT_ANCHORS.shape[1]
+    A = k * fh * fw
+    # how large the synthetic score logits are as they come: scale the head so that their upper third passes +-100
+    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
+    model.forward_raw(make_synthetic_image(H, Wd, 3))
+    heads0, _ = model.debug_fetch("rpn_heads", (fh, fw, 6 * k))
+    scale = float(100.0 / np.percentile(np.abs(heads0[..., 4 * k:]), 67))
     Wt = dict(weights)
-    Wt["rpn_score_w"] = weights["rpn_score_w"] * 400.0
-    Wt["rpn_score_b"] = weights["rpn_score_b"] * 400.0
+    Wt["rpn_score_w"] = weights["rpn_score_w"] * scale
+    Wt["rpn_score_b"] = weights["rpn_score_b"] * scale
     m = DenseCapModel(Wt, device=0)
     try:
-        H, Wd, P = 224, 288, 100
         m.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
         boxes, scores, tokens = m.forward_raw(make_synthetic_image(H, Wd, 3))
-        fh, fw = (H + 15) // 16, (Wd + 15) // 16
-        k = O.DEFAULT_ANCHORS.shape[1]
-        A = k * fh * fw
         heads, _ = m.debug_fetch("rpn_heads", (fh, fw, 6 * k))
         sc = heads[..., 4 * k:]
-        assert np.abs(sc).max() > 100 and (np.abs(sc) > 89).mean() > 0.05, float(np.abs(sc).max())
+        assert np.abs(sc).max() > 100 and (np.abs(sc) > 89).mean() > 0.2, float(np.abs(sc).max())
         chw = heads.transpose(2, 0, 1)
         o = O.rpn_decode(np.ascontiguousarray(chw[:4 * k]), np.ascontiguousarray(chw[4 * k:]), H, Wd)
         p, _ = m.debug_fetch("rpn_p", (A,))
