@@ -42,6 +42,10 @@ struct GemmDesc {
   // summation order (K-split kernel vs the sequential-K kernels, split-K factor) and the tile shape are planned on this
   // count, so an image's numbers do not depend on how many images share its launches.
   int plan_M = 0;
+  // arithmetic: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, the default and the only mode results are bit-compared in);
+  // 1 = split-bf16 (dc_set_math_mode(1)): both operands split into three bf16 planes in registers, six of the nine partial
+  // products accumulated in fp32 on v_mfma_f32_32x32x16_bf16 -- fp32-class accuracy at 2.67x the matrix rate
+  int bf3 = 0;                // (sits in what was the alignment hole in front of `rowterm`: no other field moved)
   // optional gathered row term (LSTM input gates): C[m][n] += rowterm[rowidx[m]*rowterm_ld + n]
   const float* rowterm = nullptr;
   const int32_t* rowidx = nullptr;   // values are 1-based token ids -> row = id-1

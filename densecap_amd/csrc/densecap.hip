@@ -111,6 +111,7 @@ struct dc_ctx {
   bool serial_mode = false;  // lanes == 1: idle CUs in a layer's last round are worth a tail split-K (dc_set_lanes)
   int num_proposals = 300;  // LocalizationLayer default (LocalizationLayer.lua:237); run_model sets 1000
   bool clip_boxes = true;   // LocalizationLayer.test_clip_boxes (LocalizationLayer.lua:235)
+  int math_mode = 0;        // dc_set_math_mode: 0 = fp32 MFMA (default), 1 = split-bf16 (three planes, six products, fp32 accumulate)
   bool graphs = false;      // dc_set_graph_replay: repeated forwards of one shape are relaunched as a captured hipGraph
   uint64_t weights_epoch = 0;
   int graph_launches = 0, graph_captures = 0;    // dc_debug_fetch "graph_launches" / "graph_captures"
@@ -209,6 +210,7 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, const Ws& w = Ws(
   d.stagger = ctx->stagger;
   d.walk = ctx->walk;
   d.epi_wide = ctx->epi_wide;
+  d.bf3 = ctx->math_mode == 1 ? 1 : 0;
   ProfEvt pe{nullptr, nullptr, gemm_flops(d)};
   if (ctx->prof) {
     pe.a = prof_event(ctx); pe.b = prof_event(ctx);
@@ -750,7 +752,7 @@ std::array<int64_t, 28> graph_key(const dc_ctx* ctx, const Lane& L, int g, bool 
           f2i(ctx->rpn_nms_thresh), f2i(ctx->final_nms_thresh), ctx->num_proposals, ctx->clip_boxes ? 1 : 0,
           ctx->captions_after_final_nms ? 1 : 0, ctx->serial_mode ? 1 : 0, ctx->plan_mode, ctx->tail_mode, ctx->force_cfg,
           ctx->v2_stages, ctx->stagger, ctx->walk + 2 * ctx->epi_wide, ctx->beam_size, (int64_t)(uintptr_t)ctx->fault_dev,
-          (int64_t)(uintptr_t)L.arena.p, (int64_t)(uintptr_t)L.host_stage, (int64_t)(uintptr_t)L.splitk_ws, 0, 0, 0};
+          (int64_t)(uintptr_t)L.arena.p, (int64_t)(uintptr_t)L.host_stage, (int64_t)(uintptr_t)L.splitk_ws, ctx->math_mode, 0, 0};
 }
 
 int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_device, bool features_only) {
@@ -989,6 +991,14 @@ int dc_set_beam_size(dc_ctx* ctx, int beam_size) {
   if (beam_size < 0 || beam_size > 32) return ctx->fail(DC_E_UNSUPPORTED, "dc_set_beam_size: beam_size must be in [0,32] (got %d)", beam_size);
   DCCHK(check_beam_fits(ctx, beam_size));          // before dc_load_weights the check runs there instead
   ctx->beam_size = beam_size;
+  return DC_OK;
+}
+
+int dc_set_math_mode(dc_ctx* ctx, int mode) {
+  if (!ctx) return DC_E_INVALID;
+  if (mode != DC_MATH_FP32 && mode != DC_MATH_SPLIT_BF16)
+    return ctx->fail(DC_E_INVALID, "dc_set_math_mode: 0 (fp32 MFMA) or 1 (split-bf16), got %d", mode);
+  ctx->math_mode = mode;
   return DC_OK;
 }
 

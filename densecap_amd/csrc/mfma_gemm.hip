@@ -50,6 +50,43 @@ constexpr int BK = 32;
 constexpr int KS_MIN_KTILES = 96;
 constexpr unsigned CV_PAD = 0xffffe000u;   // conv padding marker: voffset (+ up to 8 KiB of channel offset) past any descriptor range
 
+// ---- split-bf16 arithmetic (GemmDesc::bf3, dc_set_math_mode(1); opt-in, never the default) -------------------------------
+// An fp32 value is the exact sum of three bf16 values: x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1) (8 + 8 + 8
+// significand bits, round-to-nearest at every level; both residuals are exact in fp32).  A product a*b is then the sum of
+// nine bf16 x bf16 products, each exact in fp32; the six of order <= 2 (a0b0, a0b1, a1b0, a0b2, a1b1, a2b0) carry it to
+// 2^-26 relative -- below the rounding of one fp32 multiply-add -- and run on v_mfma_f32_32x32x16_bf16 at sixteen times the
+// fp32 MFMA rate: 6 instructions of 32 cycles per 16 k against 8 of 64, i.e. 2.67x the matrix throughput at fp32-class
+// accuracy.  Operands stay fp32 in HBM and in LDS (same loads, same im2col assembly); the split happens in registers, on
+// the fragments a lane has just read, with the vector unit that the fp32 loop leaves idle.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Bf3 { u32x4 p[3]; };        // three planes of 8 bf16 (packed pairs), ready as MFMA operands
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {           // v_cvt_pk_bf16_f32: lo = bf16(a), hi = bf16(b), RNE
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+// elements 2i, 2i+1 of the 8 values (lo[0..3], hi[0..3]) -> pair i of the three planes
+__device__ __forceinline__ void split3_pair(const float xa, const float xb, Bf3& out, const int i) {
+  unsigned a0 = pk_bf16(xa, xb);
+  const float ra = xa - __builtin_bit_cast(float, a0 << 16), rb = xb - __builtin_bit_cast(float, a0 & 0xffff0000u);
+  unsigned a1 = pk_bf16(ra, rb);
+  const float sa = ra - __builtin_bit_cast(float, a1 << 16), sb = rb - __builtin_bit_cast(float, a1 & 0xffff0000u);
+  unsigned a2 = pk_bf16(sa, sb);
+  // The split stays where it is written.  Instruction selection places a value without side effects as late as its first
+  // use allows -- every split of a step would land in one block in front of the NEXT step's MFMAs, whatever the program
+  // order and the sched_barriers say (measured: 160 vector instructions, then 16 MFMAs back to back).  An empty volatile
+  // asm that "rewrites" the three results is ordered like a memory operation and costs no instruction.
+  asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));
+  out.p[0][i] = a0;
+  out.p[1][i] = a1;
+  out.p[2][i] = a2;
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 // Implicit-GEMM row m -> input pixel (y, x) and its byte offset in the channels-last activation.  Plain convs walk the
 // pixels in raster order; pooled convs (GemmDesc::pool) walk pool windows, four consecutive m per window.
 __device__ __forceinline__ void conv_pixel(const GemmDesc& d, int m, int hw, int& y, int& x, bool& ok, unsigned& off) {
@@ -114,7 +151,7 @@ __device__ __forceinline__ float pool_window(const GemmDesc& d, int win, float v
 // walk 16 of the block's 32 columns n.  The row arg-max is then a compare chain inside the lane -- no LDS transpose.
 // Each element is the same fp32 fmaf chain over k either way.
 // One output tile [m0, m0+BM) x [n0, n0+BN) (tile_n = n0 / BN indexes the arg-max partials); Meff = rows of the problem.
-template <int TM, int TN, bool CONV, int NS, bool AMAX>
+template <int TM, int TN, bool CONV, int NS, bool AMAX, bool BF3 = false>
 __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const int n0, const int tile_n, const int Meff,
                                         float* const smem) {
   static_assert(!(AMAX && CONV), "arg-max epilogue is for dense GEMMs");
@@ -320,9 +357,9 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
   };
 
   const int nkt = d.K / BK;
-  // prologue: tiles 0..NS-2 in flight (two-stage ring: both stages)
+  // prologue: tiles 0..NS-2 in flight (two-stage ring: both stages; split-bf16 loop: all NS stages, see below)
 #pragma unroll
-  for (int p = 0; p < (NS == 2 ? 2 : NS - 1); ++p)
+  for (int p = 0; p < (NS == 2 || BF3 ? NS : NS - 1); ++p)
     if (p < nkt) issue(p, p);
   // Arg-max tiles: this lane's 4 x 4 bias values per column block are requested NOW, behind the first operand tiles, and
   // wait in registers: the epilogue then starts with nothing to fetch.  (Round 4: a tile's epilogue is NOT hidden by its two
@@ -361,7 +398,7 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
   __builtin_amdgcn_s_barrier();
 #endif
   __builtin_amdgcn_sched_barrier(0);
-  read_frag(0, 0, 0);
+  if constexpr (!BF3) read_frag(0, 0, 0);
 #ifdef ABL_NO_READS
   read_frag(0, 1, 1);
   abl_reads_on = false;
@@ -427,9 +464,112 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
       if (!guarded || kt + 3 < nkt) body(kt + 3, std::integral_constant<int, 3>{});
     }
   };
-  int kt = 0;
-  for (; kt + NS <= nkt; kt += NS) ring_round(kt, false);
-  if (kt < nkt) ring_round(kt, true);
+  if constexpr (!BF3) {
+    int kt = 0;
+    for (; kt + NS <= nkt; kt += NS) ring_round(kt, false);
+    if (kt < nkt) ring_round(kt, true);
+  } else {
+    // ---- split-bf16 K loop ------------------------------------------------------------------------------------------
+    // A K-tile (32 k) is two STEPS of 16 k; step s takes the fragment chunks of groups 2s and 2s+1 (a lane's 8 values:
+    // k = 16s + 4h + {0..3} and 16s + 8 + 4h + {0..3} -- the same set for A and B, which is all a contraction needs).
+    // Software pipeline, one step deep at each level:   step j:  MFMAs on planes[j & 1]
+    //                                                            || split raw (step j+1, read during step j-1) -> planes[(j+1) & 1]
+    //                                                            || then read raw <- step j+2
+    // so ALL LDS reads of tile kt+1 happen during tile kt, and a tile's ring stage is free from the rendezvous of the NEXT
+    // tile on: at the rendezvous of tile kt (middle of its step 0) tile kt+1 must have landed and tile kt+NS is requested
+    // into stage kt % NS -- NS - 1 tiles of lead.
+    constexpr int NMF = 6 * TM * TN;        // MFMAs of a step
+    constexpr int NCV = 4 * (TM + TN);      // pair conversions of a step (4 per 32-row block)
+    constexpr int NRD = 2 * (TM + TN);      // fragment reads of a step (2 chunks per block)
+    constexpr int NDM = PA + PB;            // LDS-DMA pieces of a K-tile
+    Bf3 pl[2][TM + TN];                     // planes: [set][A blocks 0..TM-1, B blocks TM..TM+TN-1]
+    f32x4 raw[TM + TN][2];                  // the fragments of ONE step as read
+    auto read_raw = [&](int st, int s, int k) {           // k in [0, NRD): block k >> 1, chunk k & 1
+      const int p = k >> 1, c = k & 1;
+      const float* base = smem + st * STAGE + foff[2 * s + c];
+      if (p < TM) raw[p][c] = *reinterpret_cast<const f32x4*>(base + a_base + p * 32 * BK);
+      else raw[p][c] = *reinterpret_cast<const f32x4*>(base + b_base + (p - TM) * 32 * BK);
+    };
+    auto convert = [&](int set, int k) {                  // k in [0, NCV): block k >> 2, pair k & 3
+      const int p = k >> 2, i = k & 3;
+      split3_pair(raw[p][i >> 1][2 * (i & 1)], raw[p][i >> 1][2 * (i & 1) + 1], pl[set][p], i);
+    };
+    auto mfma3 = [&](int set, int q) {                    // q in [0, NMF): product q / (TM TN) of block q % (TM TN)
+      constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};      // small terms first: a2b0 a0b2 a1b1 a1b0 a0b1 a0b0
+      const int e = q / (TM * TN), rem = q % (TM * TN), i = rem / TN, j = rem % TN;
+      if constexpr (AMAX) acc[i][j] = mfma_bf16(pl[set][TM + j].p[PB_[e]], pl[set][i].p[PA_[e]], acc[i][j]);
+      else acc[i][j] = mfma_bf16(pl[set][i].p[PA_[e]], pl[set][TM + j].p[PB_[e]], acc[i][j]);
+    };
+    // A step = NMF MFMAs.  Part 1: the first QA MFMAs, the NCV pair conversions spread evenly behind them (about one
+    // conversion = 11 vector instructions per MFMA for the 64x64 wave tile).  Part 2: the other MFMAs, one LDS read or one
+    // LDS-DMA piece behind each.  The order is the program's: memory operations and the pinned splits keep it.
+    constexpr int QA = (2 * NMF) / 3;                     // MFMAs that cover the conversions
+    static_assert(NMF - QA >= 2, "part 2 needs MFMAs");
+    auto region1 = [&](int set, int cset) {
+#pragma unroll
+      for (int q = 0; q < QA; ++q) {
+        mfma3(set, q);
+#pragma unroll
+        for (int k = 0; k < NCV; ++k)
+          if ((k * QA) / NCV == q) convert(cset, k);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // region 2: MFMA q (QA <= q < NMF) followed by its side operations; NRD reads first, then `ndma` LDS-DMA pieces
+    auto region2 = [&](int set, int st_rd, int s_rd, bool more, int kt_dma, int st_dma, int dma0, int ndma) {
+      constexpr int QB = NMF - QA;
+      const int nside = NRD + ndma;
+#pragma unroll
+      for (int q = 0; q < QB; ++q) {
+        mfma3(set, QA + q);
+#pragma unroll
+        for (int k = 0; k < NRD + NDM; ++k)
+          if (k < nside && (k * QB) / nside == q) {
+            if (k < NRD) read_raw(st_rd, s_rd, k);
+            else if (more) issue_piece(kt_dma, st_dma, dma0 + k - NRD);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+    };
+    // prologue: planes of step 0, raw of step 1
+#pragma unroll
+    for (int k = 0; k < NRD; ++k) read_raw(0, 0, k);
+#pragma unroll
+    for (int k = 0; k < NCV; ++k) convert(0, k);
+#pragma unroll
+    for (int k = 0; k < NRD; ++k) read_raw(0, 1, k);
+    __builtin_amdgcn_sched_barrier(0);
+    auto body3 = [&](int kt, auto ST) __attribute__((always_inline)) {
+      constexpr int st = decltype(ST)::value;
+      constexpr int st1 = st == NS - 1 ? 0 : st + 1;
+      // (The reads and splits that run ahead are NOT guarded at the end of K: in the last tile they fetch and split whatever
+      // the next ring stage holds and nobody uses the result.  A guard would be a branch per side operation, and the
+      // compiler merges such same-condition blocks across the MFMAs between them -- the interleave is gone.)
+      const bool more = kt + NS < nkt;                  // tile kt+NS exists (requested into this tile's stage)
+      // step 0: planes[0]; raw holds (kt, step 1) -> planes[1]; rendezvous; raw <- (kt+1, step 0); first half of the LDS-DMA pieces
+      region1(0, 1);
+      if (kt + NS - 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NDM) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) issue_begin();
+      region2(0, st1, 0, more, kt + NS, st, 0, NDM / 2);
+      // step 1: planes[1]; raw holds (kt+1, step 0) -> planes[0]; raw <- (kt+1, step 1); the other LDS-DMA pieces
+      region1(1, 0);
+      region2(1, st1, 1, more, kt + NS, st, NDM / 2, NDM - NDM / 2);
+    };
+    auto ring3 = [&](int kt, bool guarded) __attribute__((always_inline)) {
+      if (!guarded || kt + 0 < nkt) body3(kt + 0, std::integral_constant<int, 0>{});
+      if (!guarded || kt + 1 < nkt) body3(kt + 1, std::integral_constant<int, 1>{});
+      if constexpr (NS >= 3) {
+        if (!guarded || kt + 2 < nkt) body3(kt + 2, std::integral_constant<int, 2>{});
+      }
+    };
+    static_assert(NS == 2 || NS == 3, "split-bf16 loop: two- or three-stage ring");
+    int kt = 0;
+    for (; kt + NS <= nkt; kt += NS) ring3(kt, false);
+    if (kt < nkt) ring3(kt, true);
+  }
 
 #ifdef ABL_EPI_SLEEP                                       // timing-only ablation: the wave idles ~2 us (4800 cycles) before its epilogue
   __builtin_amdgcn_s_sleep(75);
@@ -680,7 +820,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
 }
 
-template <int TM, int TN, bool CONV, int NS, bool AMAX = false>
+template <int TM, int TN, bool CONV, int NS, bool AMAX = false, bool BF3 = false>
 __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   start_stagger(d);
@@ -695,7 +835,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
     if (me < Meff) Meff = me;
     if (m0 >= Meff) return;
   }
-  v2_tile<TM, TN, CONV, NS, AMAX>(d, m0, tile_n * (64 * TN), tile_n, Meff, smem);
+  v2_tile<TM, TN, CONV, NS, AMAX, BF3>(d, m0, tile_n * (64 * TN), tile_n, Meff, smem);
 }
 
 // 128x64-tile launches with a FINER LAST ROUND (the decode-step GEMM, conv1_2 .. conv3_3).  The 128x64 tiles of one launch
@@ -705,7 +845,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
 // are 128x64 and each leftover tile is cut into two 64x64 tiles on the SAME launch -- twice the workgroups at half the
 // duration in the ragged round.  An element's K order does not depend on the tile it falls in (same fragment/lane walk
 // for every v2 shape), so results are bit-identical to the plain launch.
-template <bool CONV, int NS, bool AMAX>
+template <bool CONV, int NS, bool AMAX, bool BF3 = false>
 __global__ __launch_bounds__(256) void mfma_gemm_v2_mixed_kernel(GemmDesc d, int ntm, int ntn, int m_fastest, int nbig,
                                                                  int nwalk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -727,8 +867,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_mixed_kernel(GemmDesc d, int
       else           { tile_n = bid % ntn; tile_m = bid / ntn; }
       if (tile_m * 128 >= Meff) continue;
       // a row tile with <= 64 live rows (the last 44 of a 300-proposal decode): the 64x64 variant does half the MFMAs
-      if (Meff - tile_m * 128 <= 64) v2_tile<1, 1, CONV, NS, AMAX>(d, tile_m * 128, tile_n * 64, tile_n, Meff, smem);
-      else v2_tile<2, 1, CONV, NS, AMAX>(d, tile_m * 128, tile_n * 64, tile_n, Meff, smem);
+      if (Meff - tile_m * 128 <= 64) v2_tile<1, 1, CONV, NS, AMAX, BF3>(d, tile_m * 128, tile_n * 64, tile_n, Meff, smem);
+      else v2_tile<2, 1, CONV, NS, AMAX, BF3>(d, tile_m * 128, tile_n * 64, tile_n, Meff, smem);
     }
   } else {
     const int r = b - nwalk, bid = nbig + (r >> 1), half = r & 1;
@@ -737,7 +877,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_mixed_kernel(GemmDesc d, int
     else           { tile_n = bid % ntn; tile_m = bid / ntn; }
     const int m0 = tile_m * 128 + half * 64;
     if (m0 >= Meff) return;
-    v2_tile<1, 1, CONV, NS, AMAX>(d, m0, tile_n * 64, tile_n, Meff, smem);
+    v2_tile<1, 1, CONV, NS, AMAX, BF3>(d, m0, tile_n * 64, tile_n, Meff, smem);
   }
 }
 
@@ -1193,7 +1333,7 @@ inline int v2_pick_stages(int total, int cus) {
   return 2 * total >= 5 * cus && v2_cost_units(total, 2, cus) < v2_cost_units(total, 3, cus) ? 2 : 3;
 }
 
-template <bool CONV, bool AMAX>
+template <bool CONV, bool AMAX, bool BF3 = false>
 hipError_t launch_mixed(const GemmDesc& d, hipStream_t stream, int ntm, int ntn, int m_fastest, size_t lds) {
   // Ring depth: two stages (48 KiB) put three workgroups on a CU instead of two (72 KiB), which hides more of each tile's
   // prologue / epilogue behind its neighbours' K loops -- measured +5% on conv1_2, conv2_1 and the vocabulary projection --
@@ -1208,15 +1348,15 @@ hipError_t launch_mixed(const GemmDesc& d, hipStream_t stream, int ntm, int ntn,
   const int nwalk = d.walk > 0 && nbig > slots ? slots : nbig;     // measurement hook: one workgroup per slot walks its tiles
   if (stages == 2) {
     const size_t lds2 = lds / 3 * 2;
-    const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_mixed_kernel<CONV, 2, AMAX>);
+    const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_mixed_kernel<CONV, 2, AMAX, BF3>);
     if (hipError_t e = ensure_dyn_lds(fn, lds2); e != hipSuccess) return e;
-    hipLaunchKernelGGL((mfma_gemm_v2_mixed_kernel<CONV, 2, AMAX>), dim3(nwalk + 2 * tail), dim3(256), lds2, stream, d, ntm, ntn,
+    hipLaunchKernelGGL((mfma_gemm_v2_mixed_kernel<CONV, 2, AMAX, BF3>), dim3(nwalk + 2 * tail), dim3(256), lds2, stream, d, ntm, ntn,
                        m_fastest, nbig, nwalk);
     return hipGetLastError();
   }
-  const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX>);
+  const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX, BF3>);
   if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL((mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX>), dim3(nwalk + 2 * tail), dim3(256), lds, stream, d, ntm, ntn,
+  hipLaunchKernelGGL((mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX, BF3>), dim3(nwalk + 2 * tail), dim3(256), lds, stream, d, ntm, ntn,
                      m_fastest, nbig, nwalk);
   return hipGetLastError();
 }
@@ -1231,6 +1371,44 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   // operands are addressed through 32-bit buffer offsets
   const bool fits = CONV ? ((size_t)(d.a_rows > d.M ? d.a_rows : d.M) * d.Cin * 4 < CV_PAD && d.Cin <= 2048) : ((size_t)BM * d.K * 4 < 0xfffffff0ull);
   if (!fits || (size_t)BN * d.K * 4 >= 0xfffffff0ull) return hipErrorInvalidValue;
+  if (d.bf3) {
+    // ---- split-bf16 arithmetic (opt-in): the 2x2-wave kernels only, plain launches only (no K sharing between workgroups)
+    if (d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0) return hipErrorInvalidValue;
+    if constexpr (TM == 2 && TN == 2) {
+      // 128x128 tiles on a two-stage ring: 64 KiB of LDS, two workgroups per CU -- the split's vector work of one wave runs
+      // under the MFMAs of the other
+      if (d.amax_val != nullptr) return hipErrorInvalidValue;
+      const size_t lds2 = (size_t)2 * (BM + BN) * BK * sizeof(float);
+      const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<2, 2, CONV, 2, false, true>);
+      if (hipError_t e = ensure_dyn_lds(fn, lds2); e != hipSuccess) return e;
+      hipLaunchKernelGGL((mfma_gemm_v2_kernel<2, 2, CONV, 2, false, true>), dim3(ntm * ntn), dim3(256), lds2, stream, d, ntm, ntn, m_fastest);
+      return hipGetLastError();
+    } else {
+      const size_t lds3 = (size_t)3 * (BM + BN) * BK * sizeof(float);
+      if (d.amax_val != nullptr) {
+        if constexpr (!CONV) {
+          if (d.amax_cols % BN != 0 || (d.amax_cols > 0 && (d.C == nullptr || d.amax_n > d.amax_cols || d.amax_cols > d.N)))
+            return hipErrorInvalidValue;
+          if constexpr (TM == 2) return launch_mixed<false, true, true>(d, stream, ntm, ntn, m_fastest, lds3);
+          else {
+            const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<1, 1, false, 3, true, true>);
+            if (hipError_t e = ensure_dyn_lds(fn, lds3); e != hipSuccess) return e;
+            hipLaunchKernelGGL((mfma_gemm_v2_kernel<1, 1, false, 3, true, true>), dim3(ntm * ntn), dim3(256), lds3, stream, d, ntm, ntn, m_fastest);
+            return hipGetLastError();
+          }
+        } else {
+          return hipErrorInvalidValue;
+        }
+      }
+      if constexpr (TM == 2) return launch_mixed<CONV, false, true>(d, stream, ntm, ntn, m_fastest, lds3);
+      else {
+        const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<1, 1, CONV, 3, false, true>);
+        if (hipError_t e = ensure_dyn_lds(fn, lds3); e != hipSuccess) return e;
+        hipLaunchKernelGGL((mfma_gemm_v2_kernel<1, 1, CONV, 3, false, true>), dim3(ntm * ntn), dim3(256), lds3, stream, d, ntm, ntn, m_fastest);
+        return hipGetLastError();
+      }
+    }
+  }
   if constexpr (TM == 2 && TN == 2) {
     if (d.amax_val != nullptr) return hipErrorInvalidValue;    // the arg-max epilogue lives in the 64-column v2 variant
     if (d.force_cfg == 5 && d.splitk == 1 && d.m_begin == 0 && d.a_rows == 0) {
@@ -1285,6 +1463,16 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
 // image of a group (plan_M), with the measured exceptions below.  Pure function of the problem (mfma_gemm_plan reports it).
 enum TileCfg { CFG_128x128 = 0, CFG_128x64 = 1, CFG_64x64 = 2 };
 TileCfg pick_cfg(const GemmDesc& d) {
+  if (d.bf3) {
+    // split-bf16 launches: the largest tile with >= 1.5 workgroups per CU for ONE image (plan_M), as below; arg-max and
+    // narrow outputs take 64-column tiles.  No K sharing between workgroups in this mode.
+    if (d.force_cfg >= 1 && d.force_cfg <= 3 && !(d.amax_val != nullptr && d.force_cfg == 1)) return (TileCfg)(d.force_cfg - 1);
+    const int pm = d.plan_M > 0 ? d.plan_M : d.M;
+    auto blocks = [&](int bm, int bn) { return (long)((pm + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
+    const long cus = device_cu_count();
+    if (d.amax_val == nullptr && d.N > 64 && 2 * blocks(128, 128) >= 3 * cus) return CFG_128x128;
+    return 2 * blocks(128, 64) >= 3 * cus ? CFG_128x64 : CFG_64x64;
+  }
   if (d.splitk > 1) return CFG_128x128;
   if (d.force_cfg >= 1 && d.force_cfg <= 3 && !(d.amax_val != nullptr && d.force_cfg == 1)) return (TileCfg)(d.force_cfg - 1);
   if ((d.force_cfg == 5 || d.force_cfg == 6) && d.amax_val == nullptr && d.N > 64) return CFG_128x128;
@@ -1538,6 +1726,19 @@ void mfma_gemm_plan(const GemmDesc& d, bool serial_mode, int tail_mode, size_t w
   *p = GemmPlan();
   const bool ws_ok = ws_floats > 0 && d.ldc % 4 == 0 && d.N % 4 == 0;
   GemmDesc q = d;                                            // the launch that follows the choice (its split factor fixes the route)
+  if (d.bf3) {                                               // split-bf16 mode: plain launches of the 2x2-wave kernels
+    switch (pick_cfg(d)) {
+      case CFG_128x128: p->route = GEMM_ROUTE_V2_128x128; p->stages = 2; break;
+      case CFG_128x64: {
+        const int total = ((d.M + 127) / 128) * ((d.N + 63) / 64);
+        p->route = GEMM_ROUTE_V2_128x64;
+        p->stages = d.stages == 2 || d.stages == 3 ? d.stages : v2_pick_stages(total, device_cu_count());
+        break;
+      }
+      default: p->route = GEMM_ROUTE_V2_64x64;
+    }
+    return;
+  }
   const int sp = ws_ok && d.force_cfg == 0 ? mfma_gemm_splitk(d, ws_floats) : 1;
   if (sp > 1 && (size_t)sp * d.M * d.N <= ws_floats) {
     p->kind = GEMM_PLAN_SPLITK; p->splitk = sp; q.splitk = sp;

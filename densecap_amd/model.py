@@ -237,6 +237,14 @@ class DenseCapModel:
         self.captions_after_final_nms = bool(after_final_nms)
         return self
 
+    def setMathMode(self, mode):
+        """dc_set_math_mode: 0 = fp32 MFMA (default; the arithmetic results are bit-compared in), 1 = split-bf16 (every
+        operand as three bf16 planes, six partial products on the bf16 matrix cores, fp32 accumulate: fp32-class error at
+        2.67x the matrix rate).  Opt-in; may be switched between forwards."""
+        check(self.ctx.h, self.lib.dc_set_math_mode(self.ctx.h, int(mode)), "dc_set_math_mode")
+        self.math_mode = int(mode)
+        return self
+
     def setGraphReplay(self, on):
         """dc_set_graph_replay: repeated forwards of one shape on a lane are captured once and relaunched as a hipGraph
         (bit-identical; pays with one image in flight -- run_model on single images, the webcam daemon)."""

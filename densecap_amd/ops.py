@@ -27,6 +27,10 @@ class Context:
         self.h = h
         self.device = device
 
+    def set_math_mode(self, mode):
+        """dc_set_math_mode (include/densecap.h): 0 = fp32 MFMA, 1 = split-bf16 -- applies to every contraction of this ctx."""
+        check(self.h, self.lib.dc_set_math_mode(self.h, int(mode)), "dc_set_math_mode")
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.dc_destroy(self.h)

@@ -154,6 +154,20 @@ int dc_set_group(dc_ctx* ctx, int images);
  * first and decode only the K surviving rows: LSTM rows are independent, so boxes, scores and tokens
  * are bit-identical, with ~K/num_proposals of the decode work. */
 int dc_set_caption_order(dc_ctx* ctx, int after_final_nms);
+/* Arithmetic of the dense contractions (convolutions, nn.Linear, LSTM / vocabulary products).
+ *   DC_MATH_FP32 (0, the default): fp32 MFMA, v_mfma_f32_32x32x2_f32 -- an exact fp32 multiply-add chain, the arithmetic the
+ *     reference computes in (DenseCapModel.lua:73-76,133) and the only mode whose results are compared bit for bit.
+ *   DC_MATH_SPLIT_BF16 (1, opt-in): every fp32 operand is split, in registers, into three bf16 values that sum to it
+ *     exactly; six of the nine partial products (all but those below 2^-26 of the product) are accumulated in fp32 on
+ *     v_mfma_f32_32x32x16_bf16, which runs at 16x the fp32 MFMA rate -- 2.67x the matrix throughput.  Error against an fp64
+ *     result is of the fp32 path's size (tests: <= 1.5x), but the bits differ: NMS / arg-max decisions that hang on the
+ *     last ulp may fall the other way, as between any two fp32 summation orders.  Non-finite operands give NaN where fp32
+ *     gives inf.  Inputs, outputs and everything between the contractions stay fp32; conv1_1 (3 input channels) and the
+ *     objectness / box-regression heads stay on the fp32 path.
+ * May be changed between forwards; weights need no reloading. */
+#define DC_MATH_FP32 0
+#define DC_MATH_SPLIT_BF16 1
+int dc_set_math_mode(dc_ctx* ctx, int mode);
 /* Graph replay (0 = off, the default).  1: a lane that is handed the same work again -- same image size, proposal
  * capacity, group size and settings -- captures its forward once (the second time the key is seen; the first runs
  * eagerly so that every lazy allocation has happened) and relaunches it afterwards as one hipGraph: ~95 kernel launches

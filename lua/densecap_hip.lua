@@ -37,6 +37,7 @@ int dc_set_test_args(dc_ctx* ctx, float rpn_nms_thresh, float final_nms_thresh, 
 int dc_set_localization_test_args(dc_ctx* ctx, int clip_boxes, float nms_thresh, int max_proposals);
 int dc_set_lanes(dc_ctx* ctx, int lanes);
 int dc_set_caption_order(dc_ctx* ctx, int after_final_nms);
+int dc_set_math_mode(dc_ctx* ctx, int mode);
 int dc_set_graph_replay(dc_ctx* ctx, int on);
 int dc_set_beam_size(dc_ctx* ctx, int beam_size);
 int dc_set_group(dc_ctx* ctx, int images);

@@ -115,6 +115,7 @@ def test_c_harness_runs_on_gpu(tmp_path):
 def _prototypes(text):
     """{name: normalised 'ret name(args)'} of the dc_* prototypes in a C declaration block."""
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"^[ \t]*#.*$", "", text, flags=re.M)          # preprocessor lines are not part of a prototype
     out = {}
     for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(dc_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3)
