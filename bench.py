@@ -276,6 +276,9 @@ def main():
     ap.add_argument("--plan-mode", type=int, default=-1, choices=[-1, 0, 1],
                     help="contraction planning: -1 follows --lanes (default), 0 = multi-lane planning even with --lanes 1 (profiler passes "
                          "that must see the kernels of the timed multi-lane schedule on one stream), 1 = single-image planning")
+    ap.add_argument("--math-mode", type=int, default=0, choices=[0, 1],
+                    help="dc_set_math_mode for the WHOLE run: 0 = fp32 MFMA (default, the headline), 1 = split-bf16 (opt-in mode; the line's "
+                         "dtype / roofline then describe that mode and say so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-pass", action="store_true",
                     help="skip the secondary caption-order measurement (keeps rocprof kernel statistics to one workload)")
@@ -348,6 +351,7 @@ def main():
         model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
         model.setLanes(args.lanes if args.lanes > 0 else 3)
         model.setGroup(max(args.group, 0))
+        model.setMathMode(args.math_mode)
         ctx = model.ctx
         if args.plan_mode >= 0:
             check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"plan_mode", args.plan_mode), "dc_debug_set")

@@ -33,6 +33,25 @@
 
 namespace {
 
+// timing-only ablation builds of the split-bf16 K loop (tools/lab_session.sh; wrong results on purpose, never the product)
+#ifdef BF3_ABL_A            // no split, no LDS-DMA after the first tiles
+#define BF3_ABL_NO_SPLIT
+#define ABL_NO_DMA
+#endif
+#ifdef BF3_ABL_B            // A + no rendezvous
+#define BF3_ABL_NO_SPLIT
+#define ABL_NO_DMA
+#define BF3_ABL_NO_BARRIER
+#endif
+#ifdef BF3_ABL_C            // B + no fragment reads: the MFMAs alone
+#define BF3_ABL_NO_SPLIT
+#define ABL_NO_DMA
+#define BF3_ABL_NO_BARRIER
+#define BF3_ABL_NO_READS
+#endif
+#ifdef BF3_ABL_D            // the real loop without its rendezvous
+#define BF3_ABL_NO_BARRIER
+#endif
 constexpr int BK = 32;
 // timing-only ablation build ABL_EPI_NO_STORE: the 2x2-wave kernel computes its epilogue but does not store it
 #if defined(ABL_EPI_NO_STORE) && defined(__HIP_DEVICE_COMPILE__)
@@ -482,9 +501,25 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
     constexpr int NCV = 4 * (TM + TN);      // pair conversions of a step (4 per 32-row block)
     constexpr int NRD = 2 * (TM + TN);      // fragment reads of a step (2 chunks per block)
     constexpr int NDM = PA + PB;            // LDS-DMA pieces of a K-tile
+    // TWO accumulators per 32x32 block: `acc` takes the leading products a0.b0 only, `lo` the five lower-order ones, and the
+    // two meet once, after the K loop.  The bf16 MFMA aligns its sixteen products to the largest exponent among them and C and
+    // keeps three guard bits (tools/probes/mfma_bf16_numerics.hip: sixteen products of 1/16 ulp(C) vanish, of 1/8 ulp add up):
+    // added straight into a large running sum, the a1.b0 / a0.b1 terms would lose their low bits at EVERY step -- measured
+    // 3.4x the fp32 path's error at K = 4608.  Kept apart, they are aligned against a sum 2^-8 as large, and the main
+    // accumulator is rounded once per 16 k instead of once per k: the error comes out below the fp32 path's.
+    f32x16 lo[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) lo[i][j][e] = 0.f;
     Bf3 pl[2][TM + TN];                     // planes: [set][A blocks 0..TM-1, B blocks TM..TM+TN-1]
     f32x4 raw[TM + TN][2];                  // the fragments of ONE step as read
     auto read_raw = [&](int st, int s, int k) {           // k in [0, NRD): block k >> 1, chunk k & 1
+#ifdef BF3_ABL_NO_READS
+      if (st != 0 || s != 0) return;                      // timing-only ablation build: fragments are read in the prologue only
+#endif
       const int p = k >> 1, c = k & 1;
       const float* base = smem + st * STAGE + foff[2 * s + c];
       if (p < TM) raw[p][c] = *reinterpret_cast<const f32x4*>(base + a_base + p * 32 * BK);
@@ -492,13 +527,20 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
     };
     auto convert = [&](int set, int k) {                  // k in [0, NCV): block k >> 2, pair k & 3
       const int p = k >> 2, i = k & 3;
+#ifdef BF3_ABL_NO_SPLIT                                   // timing-only ablation build: the raw bits go to the MFMAs unsplit (wrong results)
+      pl[set][p].p[0][i] = __builtin_bit_cast(unsigned, raw[p][i >> 1][2 * (i & 1)]);
+      pl[set][p].p[1][i] = __builtin_bit_cast(unsigned, raw[p][i >> 1][2 * (i & 1) + 1]);
+      pl[set][p].p[2][i] = pl[set][p].p[0][i];
+      return;
+#endif
       split3_pair(raw[p][i >> 1][2 * (i & 1)], raw[p][i >> 1][2 * (i & 1) + 1], pl[set][p], i);
     };
     auto mfma3 = [&](int set, int q) {                    // q in [0, NMF): product q / (TM TN) of block q % (TM TN)
-      constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};      // small terms first: a2b0 a0b2 a1b1 a1b0 a0b1 a0b0
+      constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};      // a2b0 a0b2 a1b1 a1b0 a0b1 -> lo;  a0b0 -> acc
       const int e = q / (TM * TN), rem = q % (TM * TN), i = rem / TN, j = rem % TN;
-      if constexpr (AMAX) acc[i][j] = mfma_bf16(pl[set][TM + j].p[PB_[e]], pl[set][i].p[PA_[e]], acc[i][j]);
-      else acc[i][j] = mfma_bf16(pl[set][i].p[PA_[e]], pl[set][TM + j].p[PB_[e]], acc[i][j]);
+      f32x16& dst = e == 5 ? acc[i][j] : lo[i][j];
+      if constexpr (AMAX) dst = mfma_bf16(pl[set][TM + j].p[PB_[e]], pl[set][i].p[PA_[e]], dst);
+      else dst = mfma_bf16(pl[set][i].p[PA_[e]], pl[set][TM + j].p[PB_[e]], dst);
     };
     // A step = NMF MFMAs.  Part 1: the first QA MFMAs, the NCV pair conversions spread evenly behind them (about one
     // conversion = 11 vector instructions per MFMA for the 64x64 wave tile).  Part 2: the other MFMAs, one LDS read or one
@@ -548,9 +590,11 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
       const bool more = kt + NS < nkt;                  // tile kt+NS exists (requested into this tile's stage)
       // step 0: planes[0]; raw holds (kt, step 1) -> planes[1]; rendezvous; raw <- (kt+1, step 0); first half of the LDS-DMA pieces
       region1(0, 1);
+#ifndef BF3_ABL_NO_BARRIER
       if (kt + NS - 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NDM) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+#endif
       __builtin_amdgcn_sched_barrier(0);
       if (more) issue_begin();
       region2(0, st1, 0, more, kt + NS, st, 0, NDM / 2);
@@ -569,6 +613,12 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
     int kt = 0;
     for (; kt + NS <= nkt; kt += NS) ring3(kt, false);
     if (kt < nkt) ring3(kt, true);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += lo[i][j][e];
   }
 
 #ifdef ABL_EPI_SLEEP                                       // timing-only ablation: the wave idles ~2 us (4800 cycles) before its epilogue
@@ -879,6 +929,27 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_mixed_kernel(GemmDesc d, int
     if (m0 >= Meff) return;
     v2_tile<1, 1, CONV, NS, AMAX, BF3>(d, m0, tile_n * 64, tile_n, Meff, smem);
   }
+}
+
+// Split-bf16 launches of 128x128 tiles: the same tile function on a two-stage ring (64 KiB), compiled for TWO workgroups per CU.
+// The two accumulator sets of that mode (128 registers) put the wave at ~264 registers; two waves per SIMD need 256, which the
+// compiler reaches by parking the im2col bookkeeping that is touched once per tap (a handful of spills outside the K-tile
+// body).  Worth it: one wave's split (vector unit) runs under the other wave's MFMAs.
+template <bool CONV>
+__global__ __launch_bounds__(256, 2) void mfma_gemm_bf3_128_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int bid = xcd_remap(blockIdx.x, ntm * ntn);
+  int tile_m, tile_n;
+  if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
+  else           { tile_n = bid % ntn; tile_m = bid / ntn; }
+  const int m0 = tile_m * 128;
+  int Meff = d.M;
+  if (d.m_dev != nullptr) {
+    const int me = *d.m_dev;
+    if (me < Meff) Meff = me;
+    if (m0 >= Meff) return;
+  }
+  v2_tile<2, 2, CONV, 2, false, true>(d, m0, tile_n * 128, tile_n, Meff, smem);
 }
 
 // =========================================================================================
@@ -1379,9 +1450,9 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
       // under the MFMAs of the other
       if (d.amax_val != nullptr) return hipErrorInvalidValue;
       const size_t lds2 = (size_t)2 * (BM + BN) * BK * sizeof(float);
-      const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<2, 2, CONV, 2, false, true>);
+      const void* fn = reinterpret_cast<const void*>(&mfma_gemm_bf3_128_kernel<CONV>);
       if (hipError_t e = ensure_dyn_lds(fn, lds2); e != hipSuccess) return e;
-      hipLaunchKernelGGL((mfma_gemm_v2_kernel<2, 2, CONV, 2, false, true>), dim3(ntm * ntn), dim3(256), lds2, stream, d, ntm, ntn, m_fastest);
+      hipLaunchKernelGGL((mfma_gemm_bf3_128_kernel<CONV>), dim3(ntm * ntn), dim3(256), lds2, stream, d, ntm, ntn, m_fastest);
       return hipGetLastError();
     } else {
       const size_t lds3 = (size_t)3 * (BM + BN) * BK * sizeof(float);
@@ -1470,7 +1541,10 @@ TileCfg pick_cfg(const GemmDesc& d) {
     const int pm = d.plan_M > 0 ? d.plan_M : d.M;
     auto blocks = [&](int bm, int bn) { return (long)((pm + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
     const long cus = device_cu_count();
-    if (d.amax_val == nullptr && d.N > 64 && 2 * blocks(128, 128) >= 3 * cus) return CFG_128x128;
+    // 128x128 tiles from three quarters of a round on: the operand traffic per FLOP of a 128x64 tile is 1.5x a 128x128 tile's,
+    // and at this mode's MFMA rate the L2 -> LDS path is what a tile waits for (measured, 1000 x 4096 x 25088: 154 vs 134 TF
+    // fp32-equivalent; 6840 x 512 x 4608: 148 vs 134; few-tile problems keep the fine tiles: 1710 x 512 x 4608 84 vs 44)
+    if (d.amax_val == nullptr && d.N > 64 && 4 * blocks(128, 128) >= 3 * cus) return CFG_128x128;
     return 2 * blocks(128, 64) >= 3 * cus ? CFG_128x64 : CFG_64x64;
   }
   if (d.splitk > 1) return CFG_128x128;

@@ -14,6 +14,10 @@ lib = ctx.lib
 if "--serial" in sys.argv:          # single-image mode: tail plans (K-split last round) are active, as in `bench.py --lanes 1`
     check(ctx.h, lib.dc_set_lanes(ctx.h, 1))
 for a in sys.argv:
+    if a.startswith("--math-mode="):      # 1 = split-bf16 contraction mode (dc_set_math_mode)
+        check(ctx.h, lib.dc_set_math_mode(ctx.h, int(a.split("=")[1])))
+    if a.startswith("--force-cfg="):      # dc_debug_set force_cfg (tile configuration of plain launches)
+        check(ctx.h, lib.dc_debug_set(ctx.h, b"force_cfg", int(a.split("=")[1])))
     if a.startswith("--stages="):         # LDS ring depth of the 128x64-tile kernel (2 = three workgroups per CU)
         check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"v2_stages", int(a.split("=")[1])))
     if a.startswith("--tail-mode="):      # 0 stream-K (default), 1 K-split tail plan, 2 whole tiles
