@@ -16,16 +16,6 @@ namespace {
 
 typedef unsigned long long u64;
 
-__device__ __forceinline__ void corners(float xc, float yc, float w, float h, float& x1, float& y1, float& x2,
-                                        float& y2) {
-  // box_utils.xcycwh_to_x1y1x2y2 (box_utils.lua:288-291): x0 = ((w-1)/2)*-1 + xc ; x1 = (w-1)/2 + xc
-  const float hw = __fdiv_rn(__fsub_rn(w, 1.f), 2.f);
-  const float hh = __fdiv_rn(__fsub_rn(h, 1.f), 2.f);
-  x1 = __fadd_rn(-hw, xc);
-  y1 = __fadd_rn(-hh, yc);
-  x2 = __fadd_rn(hw, xc);
-  y2 = __fadd_rn(hh, yc);
-}
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 __global__ void make_anchors_kernel(float* __restrict__ out, int h, int w, float x0, float y0, float sx, float sy,
@@ -136,6 +126,7 @@ __global__ void box_iou_kernel(const float* __restrict__ b1, const float* __rest
 // Fused MakeAnchors + ReshapeBoxFeatures + ApplyBoxTransform + clip_boxes + corners + p(pos)
 // (LocalizationLayer.lua:265-308).  heads: (h,w,6k) channels-last, box channels a*4+d, then
 // score channels 4k + a*2 + d.  Row b = a*h*w + y*w + x (ReshapeBoxFeatures.lua:24-33).
+// blockIdx.y = image of a group: every per-image tensor is `total` rows further on (heads: h*w pixels further on).
 __global__ void rpn_decode_kernel(const float* __restrict__ heads, int h, int w, int k,
                                   const float* __restrict__ anchors, float x0, float y0, float sx, float sy,
                                   float img_h, float img_w, float* __restrict__ boxes, float* __restrict__ anc_out,
@@ -144,6 +135,16 @@ __global__ void rpn_decode_kernel(const float* __restrict__ heads, int h, int w,
   const int total = k * h * w;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= total) return;
+  {
+    const size_t img = blockIdx.y;
+    heads += img * (size_t)h * w * 6 * k;
+    if (boxes) boxes += img * total * 4;
+    if (anc_out) anc_out += img * total * 4;
+    if (trans_out) trans_out += img * total * 4;
+    if (xyxy) xyxy += img * total * 4;
+    if (p_out) p_out += img * total;
+    if (valid) valid += img * total;
+  }
   const int a = b / (h * w), rem = b - a * h * w, y = rem / w, x = rem - y * w;
   const float* px = heads + (size_t)rem * (6 * k);
   const f32x4 t = *reinterpret_cast<const f32x4*>(px + a * 4);
@@ -541,6 +542,38 @@ __global__ void gather_rows_i32_kernel(const int32_t* __restrict__ src, const in
   out[t] = i < *count ? src[(size_t)idx[i] * width + c] : 0;
 }
 
+// The results of a group in ONE launch (round 5; three gathers per image before): image = blockIdx.y.  A record is laid out
+// exactly as the pinned host staging expects it -- {int32 K at byte 0, uint32 fault word at byte 68 | 256: boxes (P,4) |
+// scores (P) | int32 tokens (P,T) or fc7 codes (P,D)} -- so that the whole group leaves in one device-to-host copy.
+// Row r < K of image i is row picks[i*P + r] of the per-RoI tensors (box_utils.nms order, DenseCapModel.lua:261-275);
+// tok_gather = 0: the token rows are already in final order (captions decoded after the final NMS).
+__global__ void final_pack_kernel(const float* __restrict__ final_boxes, const float* __restrict__ obj,
+                                  const int32_t* __restrict__ tokens, int tok_gather, const float* __restrict__ codes,
+                                  const int32_t* __restrict__ picks, const int32_t* __restrict__ count, int count_stride,
+                                  const uint32_t* __restrict__ fault, int P, int T, int D, char* __restrict__ pack,
+                                  size_t stride) {
+  const int img = blockIdx.y;
+  const int W = 5 + (codes != nullptr ? D : T);               // 4-byte words of a row: box, score, tokens | codes
+  const int K = min(count[(size_t)img * count_stride], P);
+  char* rec = pack + (size_t)img * stride;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *reinterpret_cast<int32_t*>(rec) = K;
+    *reinterpret_cast<uint32_t*>(rec + 68) = fault != nullptr ? *fault : 0u;
+  }
+  float* ob = reinterpret_cast<float*>(rec + 256);
+  float* os = ob + (size_t)P * 4;
+  uint32_t* ot = reinterpret_cast<uint32_t*>(os + P);
+  const size_t r0 = (size_t)img * P;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < (long)K * W; t += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(t / W), c = (int)(t - (long)r * W);
+    const size_t src = r0 + (size_t)picks[r0 + r];
+    if (c < 4) ob[(size_t)r * 4 + c] = final_boxes[src * 4 + c];
+    else if (c == 4) os[r] = obj[src];
+    else if (codes != nullptr) ot[(size_t)r * D + (c - 5)] = __float_as_uint(codes[src * D + (c - 5)]);
+    else ot[(size_t)r * T + (c - 5)] = (uint32_t)tokens[(tok_gather ? src : r0 + r) * T + (c - 5)];
+  }
+}
+
 }  // namespace
 
 #define LAUNCH1D(kern, n, s, ...)                                                        \
@@ -570,11 +603,13 @@ hipError_t launch_box_iou(const float* b1, const float* b2, float* out, int B1, 
   hipLaunchKernelGGL(box_iou_kernel, dim3(grid), dim3(256), 0, s, b1, b2, out, B1, B2, convention);
   return hipGetLastError();
 }
-hipError_t launch_rpn_decode(const float* heads, int h, int w, int k, const float* anchors, float x0, float y0,
+hipError_t launch_rpn_decode(const float* heads, int nimg, int h, int w, int k, const float* anchors, float x0, float y0,
                              float sx, float sy, int img_h, int img_w, float* boxes, float* anchors_out,
                              float* trans, float* x1y1x2y2, float* p, uint8_t* valid, int clip, hipStream_t s) {
-  LAUNCH1D(rpn_decode_kernel, k * h * w, s, heads, h, w, k, anchors, x0, y0, sx, sy, (float)img_h, (float)img_w,
-           boxes, anchors_out, trans, x1y1x2y2, p, valid, clip);
+  if (nimg <= 0 || nimg > 65535) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rpn_decode_kernel, dim3((k * h * w + 255) / 256, nimg), dim3(256), 0, s, heads, h, w, k, anchors, x0, y0,
+                     sx, sy, (float)img_h, (float)img_w, boxes, anchors_out, trans, x1y1x2y2, p, valid, clip);
+  return hipGetLastError();
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -660,6 +695,17 @@ hipError_t launch_nms(NmsWorkspace& ws, const float* boxes, const float* scores,
                        std::max(r1, r0), max_boxes, ws.removed0, picks, ws.pick_pos, st, count);
     if (rows <= 0) break;
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_final_pack(const float* final_boxes, const float* obj, const int32_t* tokens, int tok_gather,
+                             const float* codes, const int32_t* picks, const int32_t* count, int count_stride,
+                             const uint32_t* fault, int nimg, int P, int T, int D, void* pack, size_t stride, hipStream_t s) {
+  if (nimg <= 0 || nimg > 65535 || P <= 0) return hipErrorInvalidValue;
+  const long per = (long)P * (5 + (codes != nullptr ? D : T));
+  const int gx = (int)std::min<long>((per + 255) / 256, 2048);
+  hipLaunchKernelGGL(final_pack_kernel, dim3(gx, nimg), dim3(256), 0, s, final_boxes, obj, tokens, tok_gather, codes, picks,
+                     count, count_stride, fault, P, T, D, static_cast<char*>(pack), stride);
   return hipGetLastError();
 }
 

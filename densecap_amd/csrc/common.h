@@ -19,6 +19,18 @@ __device__ __forceinline__ float th_expf(float x) { return (float)exp((double)x)
 __device__ __forceinline__ float th_sigmoidf(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }
 __device__ __forceinline__ float th_tanhf(float x) { return (float)tanh((double)x); }
 
+// (shared by boxes.hip and the recognition heads: one definition of the conversion every NMS input goes through)
+__device__ __forceinline__ void corners(float xc, float yc, float w, float h, float& x1, float& y1, float& x2,
+                                        float& y2) {
+  // box_utils.xcycwh_to_x1y1x2y2 (box_utils.lua:288-291): x0 = ((w-1)/2)*-1 + xc ; x1 = (w-1)/2 + xc
+  const float hw = __fdiv_rn(__fsub_rn(w, 1.f), 2.f);
+  const float hh = __fdiv_rn(__fsub_rn(h, 1.f), 2.f);
+  x1 = __fadd_rn(-hw, xc);
+  y1 = __fadd_rn(-hh, yc);
+  x2 = __fadd_rn(hw, xc);
+  y2 = __fadd_rn(hh, yc);
+}
+
 // ---- ctx accessors for the other translation units (densecap.hip) ------------------
 int dc_ctx_device(const dc_ctx* ctx);
 void dc_ctx_set_error(dc_ctx* ctx, const char* msg);
@@ -157,9 +169,10 @@ hipError_t launch_lstm_step_tail(const float* pval, const int32_t* pidx, int nti
                                  const float* xg, const float* gates_pre, float* c, float* h, int n,
                                  const int32_t* n_dev, int Hd, int zero_c, int32_t* seq, int T, int t, hipStream_t s);
 // objectness + box regression heads + final ApplyBoxTransform (DenseCapModel.lua:134,139-140)
+// final_xyxy (optional): the final boxes as corners too (box_utils.xcycwh_to_x1y1x2y2), what the final NMS reads
 hipError_t launch_recog_heads(const float* codes, const float* w5 /*(5,D): obj, 4 boxreg*/, const float* b5,
-                              const float* roi_boxes, float* obj, float* trans, float* final_boxes, int n, int D,
-                              hipStream_t s);
+                              const float* roi_boxes, float* obj, float* trans, float* final_boxes, float* final_xyxy,
+                              int n, int D, hipStream_t s);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize per (device, kernel) -- mfma_gemm.hip
 hipError_t ensure_dyn_lds(const void* fn, size_t bytes);
@@ -187,7 +200,8 @@ hipError_t launch_clip_boxes(const float* boxes, float* clipped, uint8_t* valid,
 hipError_t launch_xcycwh_to_x1y1x2y2(const float* boxes, float* out, int n, hipStream_t s);
 hipError_t launch_box_iou(const float* b1, const float* b2, float* out, int B1, int B2, int convention,
                           hipStream_t s);
-hipError_t launch_rpn_decode(const float* heads, int h, int w, int k, const float* anchors, float x0, float y0,
+// (nimg images of a group side by side: every per-image tensor follows the previous image's)
+hipError_t launch_rpn_decode(const float* heads, int nimg, int h, int w, int k, const float* anchors, float x0, float y0,
                              float sx, float sy, int img_h, int img_w, float* boxes, float* anchors_out,
                              float* trans, float* x1y1x2y2, float* p, uint8_t* valid, int clip, hipStream_t s);
 struct NmsWorkspace {
@@ -222,7 +236,18 @@ hipError_t launch_gather_rows(const float* src, const int32_t* idx, const int32_
 hipError_t launch_gather_rows_i32(const int32_t* src, const int32_t* idx, const int32_t* count, int cap, int width,
                                   int32_t* out, hipStream_t s);
 
+// the results of a group of images gathered by their final-NMS picks into packed records (see final_pack_kernel)
+hipError_t launch_final_pack(const float* final_boxes, const float* obj, const int32_t* tokens, int tok_gather,
+                             const float* codes, const int32_t* picks, const int32_t* count, int count_stride,
+                             const uint32_t* fault, int nimg, int P, int T, int D, void* pack, size_t stride, hipStream_t s);
+
 // ---- bilinear RoI pooling (roipool.hip) ---------------------------------------------
+// group form: nimg feature maps feat_stride floats apart, B rows of boxes / output per image, live counts
+// B_dev[image * bdev_stride]; pick != null: box b of an image = src_boxes[image * src_stride + pick[b]], also written to boxes
+hipError_t launch_bilinear_roi_pool_group(const float* feat_hwc, size_t feat_stride, int nimg, int h, int w, int C,
+                                          float* boxes, int B, const int32_t* B_dev, int bdev_stride,
+                                          const int32_t* pick, const float* src_boxes, size_t src_stride, int img_h,
+                                          int img_w, int HH, int WW, float* out, int out_layout, hipStream_t s);
 hipError_t launch_bilinear_roi_pool(const float* feat_hwc, int h, int w, int C, const float* boxes, int B,
                                     const int32_t* B_dev, int img_h, int img_w, int HH, int WW, float* out,
                                     int out_layout, hipStream_t s);

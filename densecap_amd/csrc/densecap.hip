@@ -53,7 +53,8 @@ struct Lane {
   float *obj = nullptr, *final_trans = nullptr, *final_boxes = nullptr, *final_xyxy = nullptr;
   float *enc = nullptr, *gates = nullptr, *hstate = nullptr, *cstate = nullptr, *logits = nullptr;
   int32_t *tok = nullptr, *seq = nullptr;
-  float *out_boxes = nullptr, *out_scores = nullptr, *out_feats = nullptr;
+  float* out_feats = nullptr;
+  char* out_pack = nullptr;     // the group's packed result records (final_pack_kernel), copied to host_stage in one piece
   float* splitk_ws = nullptr;   // split-K partial tiles (<= 256 tiles of 128x128)
   int32_t* out_tokens = nullptr;
   // pinned host staging
@@ -335,6 +336,11 @@ size_t host_stage_stride(const dc_ctx* ctx, int P) {
   return al(256 + (size_t)P * (16 + 4 + (size_t)ctx->T * 4 + (size_t)ctx->D * 4));
 }
 
+// bytes of one image's PACKED record (device and pinned host staging share the layout): {K, fault | boxes | scores | tokens or codes}
+size_t pack_stride(const dc_ctx* ctx, int P, bool feats) {
+  return al(256 + (size_t)P * (16 + 4 + (feats ? (size_t)ctx->D * 4 : (size_t)ctx->T * 4)));
+}
+
 // (Re)build a lane's workspace for G images of size (H,W) side by side and proposal capacity P each.
 int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P, int G) {
   if (L.stream == nullptr) {
@@ -387,8 +393,7 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P, int G) {
       {(void**)&L.logits, GP * (size_t)std::max(V1, ctx->V1pad / 16) * 4},   // full logits (beam) or 2 x V1pad/32 arg-max partials per row
       {(void**)&L.tok, GP * 4},
       {(void**)&L.seq, GP * Tn * 4},
-      {(void**)&L.out_boxes, GP * 16},
-      {(void**)&L.out_scores, GP * 4},
+      {(void**)&L.out_pack, (size_t)G * host_stage_stride(ctx, P)},   // packed result records of the group (either kind)
       {(void**)&L.out_tokens, GP * Tn * 4},
       {(void**)&L.out_feats, GP * Dm * 4},
       {(void**)&L.splitk_ws, kSplitkWsFloats * 4},
@@ -645,24 +650,18 @@ int enqueue_body(dc_ctx* ctx, Lane& L, int g, bool features_only, bool events) {
   // ---- RPN (LocalizationLayer.lua:265, build_rpn :609-690) ----------------------------------
   DCCHK(conv3x3(ctx, s, L.feat, ctx->rpn_w, ctx->rpn_b, L.rpn_hidden, g, h, w, 512, ctx->R, 1, lane_ws(L)));
   DCCHK(linear(ctx, s, L.rpn_hidden, ctx->heads_w, ctx->heads_b, L.heads, g * h * w, 6 * ctx->k, ctx->R, 0, Ws(), h * w));
-  for (int i = 0; i < g; ++i)
-    KCHK(launch_rpn_decode(L.heads + (size_t)i * h * w * 6 * ctx->k, h, w, ctx->k, ctx->anchors, ctx->fc[0], ctx->fc[1],
-                           ctx->fc[2], ctx->fc[3], H, W, L.rpn_boxes + (size_t)i * L.A * 4, nullptr, nullptr,
-                           L.rpn_xyxy + (size_t)i * L.A * 4, L.rpn_p + (size_t)i * L.A, L.rpn_valid + (size_t)i * L.A,
-                           ctx->clip_boxes ? 1 : 0, s));
+  KCHK(launch_rpn_decode(L.heads, g, h, w, ctx->k, ctx->anchors, ctx->fc[0], ctx->fc[1], ctx->fc[2], ctx->fc[3], H, W,
+                         L.rpn_boxes, nullptr, nullptr, L.rpn_xyxy, L.rpn_p, L.rpn_valid, ctx->clip_boxes ? 1 : 0, s));   // the whole group in one launch
   STAGE_EVENT(2);
   // ---- RPN NMS (LocalizationLayer.lua:318-338) ------------------------------------------------
-  for (int i = 0; i < g; ++i) {
+  for (int i = 0; i < g; ++i)
     KCHK(launch_nms(L.nms, L.rpn_xyxy + (size_t)i * L.A * 4, L.rpn_p + (size_t)i * L.A, L.rpn_valid + (size_t)i * L.A, L.A,
                     nullptr, ctx->rpn_nms_thresh, P, L.picks1 + (size_t)i * P, L.count1 + i * 64, s));
-    KCHK(launch_gather_rows(L.rpn_boxes + (size_t)i * L.A * 4, L.picks1 + (size_t)i * P, L.count1 + i * 64, P, 4,
-                            L.roi_boxes + (size_t)i * P * 4, s));
-  }
   STAGE_EVENT(3);
-  // ---- bilinear RoI pooling (LocalizationLayer.lua:346-349) -----------------------------------
-  for (int i = 0; i < g; ++i)
-    KCHK(launch_bilinear_roi_pool(L.feat + i * feat_elems, h, w, 512, L.roi_boxes + (size_t)i * P * 4, P, L.count1 + i * 64,
-                                  H, W, 7, 7, L.roi_feats + (size_t)i * P * 49 * 512, 1, s));
+  // ---- bilinear RoI pooling (LocalizationLayer.lua:338-349) -----------------------------------
+  // one launch for the group; the picked RPN boxes are gathered by the kernel itself (and left in roi_boxes for the heads)
+  KCHK(launch_bilinear_roi_pool_group(L.feat, feat_elems, g, h, w, 512, L.roi_boxes, P, L.count1, 64, L.picks1, L.rpn_boxes,
+                                      (size_t)L.A * 4, H, W, 7, 7, L.roi_feats, 1, s));
   STAGE_EVENT(4);
   // ---- recog_base fc6/fc7 (DenseCapModel.lua:133) ------------------------------------------------
   const int R = g * P;                      // RoI rows of the group
@@ -670,8 +669,8 @@ int enqueue_body(dc_ctx* ctx, Lane& L, int g, bool features_only, bool events) {
   DCCHK(linear(ctx, s, L.fc6_out, ctx->fc7_w, ctx->fc7_b, L.codes, R, ctx->D, ctx->D, 1, lane_ws(L), P));
   STAGE_EVENT(5);
   // ---- objectness / box regression / final boxes (DenseCapModel.lua:134,139-140) -----------------
-  KCHK(launch_recog_heads(L.codes, ctx->head5_w, ctx->head5_b, L.roi_boxes, L.obj, L.final_trans, L.final_boxes, R,
-                          ctx->D, s));
+  KCHK(launch_recog_heads(L.codes, ctx->head5_w, ctx->head5_b, L.roi_boxes, L.obj, L.final_trans, L.final_boxes,
+                          L.final_xyxy, R, ctx->D, s));
   STAGE_EVENT(6);
   const bool survivors_only = ctx->captions_after_final_nms && !features_only;
   // single-image mode, reference order: decode (two row blocks on two streams) and final NMS (a third stream) are
@@ -692,7 +691,6 @@ int enqueue_body(dc_ctx* ctx, Lane& L, int g, bool features_only, bool events) {
   }
   STAGE_EVENT(7);
   // ---- final NMS + gather (DenseCapModel.lua:261-275) ----------------------------------------------
-  KCHK(launch_xcycwh_to_x1y1x2y2(L.final_boxes, L.final_xyxy, R, sn));
   for (int i = 0; i < g; ++i) {
     const size_t r0 = (size_t)i * P;
     // forward_test skips the final NMS when final_nms_thresh <= 0 (DenseCapModel.lua:261); extractFeatures calls
@@ -709,37 +707,23 @@ int enqueue_body(dc_ctx* ctx, Lane& L, int g, bool features_only, bool events) {
     HIPCHK(hipEventRecord(L.ev_join2, L.aux2));
     HIPCHK(hipStreamWaitEvent(s, L.ev_join2, 0));
   }
-  for (int i = 0; i < g; ++i) {
-    const size_t r0 = (size_t)i * P;
-    const int32_t *pk = L.picks2 + r0, *cnt = L.count2 + i * 64;
-    KCHK(launch_gather_rows(L.final_boxes + r0 * 4, pk, cnt, P, 4, L.out_boxes + r0 * 4, s));
-    KCHK(launch_gather_rows(L.obj + r0, pk, cnt, P, 1, L.out_scores + r0, s));
-    if (features_only) {
-      KCHK(launch_gather_rows(L.codes + r0 * ctx->D, pk, cnt, P, ctx->D, L.out_feats + r0 * ctx->D, s));
-    } else if (survivors_only) {
-      // identical outputs, less work: LSTM rows are independent, so decode only the rows the final NMS kept
+  if (survivors_only) {
+    // identical outputs, less work: LSTM rows are independent, so decode only the rows the final NMS kept
+    for (int i = 0; i < g; ++i) {
+      const size_t r0 = (size_t)i * P;
+      const int32_t *pk = L.picks2 + r0, *cnt = L.count2 + i * 64;
       KCHK(launch_gather_rows(L.codes + r0 * ctx->D, pk, cnt, P, ctx->D, L.out_feats + r0 * ctx->D, s));
       if (ctx->beam_size > 0) DCCHK(lm_beamsearch(ctx, L, L.out_feats + r0 * ctx->D, P, L.out_tokens + r0 * ctx->T, s));   // rows past K: zero codes, ignored
       else DCCHK(lm_sample_rows(ctx, L, L.out_feats, (int)r0, P, cnt, L.out_tokens));
-    } else {
-      KCHK(launch_gather_rows_i32(L.seq + r0 * ctx->T, pk, cnt, P, ctx->T, L.out_tokens + r0 * ctx->T, s));
     }
   }
+  // ---- results: ONE gather launch for the group into packed records, ONE copy to the pinned host staging ---------------
+  const size_t stride = pack_stride(ctx, P, features_only);
+  KCHK(launch_final_pack(L.final_boxes, L.obj, survivors_only ? L.out_tokens : L.seq, survivors_only ? 0 : 1,
+                         features_only ? L.codes : nullptr, L.picks2, L.count2, 64, ctx->fault_dev, g, P, ctx->T, ctx->D,
+                         L.out_pack, stride, s));
   STAGE_EVENT(8);
-  // ---- results -> pinned host staging (one slot per image) ------------------------------------------------------
-  const size_t stride = host_stage_stride(ctx, P);
-  for (int i = 0; i < g; ++i) {
-    char* hs = static_cast<char*>(L.host_stage) + i * stride;
-    const size_t r0 = (size_t)i * P;
-    HIPCHK(hipMemcpyAsync(hs, L.count2 + i * 64, 4, hipMemcpyDeviceToHost, s));
-    if (ctx->fault_dev != nullptr) HIPCHK(hipMemcpyAsync(hs + 68, ctx->fault_dev, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hs + 256, L.out_boxes + r0 * 4, (size_t)P * 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hs + 256 + (size_t)P * 16, L.out_scores + r0, (size_t)P * 4, hipMemcpyDeviceToHost, s));
-    if (features_only)
-      HIPCHK(hipMemcpyAsync(hs + 256 + (size_t)P * 20, L.out_feats + r0 * ctx->D, (size_t)P * ctx->D * 4, hipMemcpyDeviceToHost, s));
-    else
-      HIPCHK(hipMemcpyAsync(hs + 256 + (size_t)P * 20, L.out_tokens + r0 * ctx->T, (size_t)P * ctx->T * 4, hipMemcpyDeviceToHost, s));
-  }
+  HIPCHK(hipMemcpyAsync(L.host_stage, L.out_pack, (size_t)g * stride, hipMemcpyDeviceToHost, s));
 #undef STAGE_EVENT
   return DC_OK;
 }
@@ -761,7 +745,7 @@ int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_de
   if (img_on_device) HIPCHK(hipMemcpyAsync(L.img, img, g * img_elems * 4, hipMemcpyDeviceToDevice, s));
   else HIPCHK(hipMemcpyAsync(L.img, img, g * img_elems * 4, hipMemcpyHostToDevice, s));
   L.g = g;
-  const size_t stride = host_stage_stride(ctx, L.P);
+  const size_t stride = pack_stride(ctx, L.P, features_only);
   for (int i = 0; i < g; ++i) *reinterpret_cast<uint32_t*>(static_cast<char*>(L.host_stage) + i * stride + 68) = 0;
   L.ran_graph = false;
   // Graph replay (dc_set_graph_replay): the FIRST forward of a key runs eagerly (lazy allocations, kernel attributes and
@@ -833,7 +817,7 @@ int harvest(dc_ctx* ctx, Lane& L) {
   }
   L.have_times = !L.ran_graph;                            // a replayed graph carries no stage events
   const int P = L.P;
-  const size_t stride = host_stage_stride(ctx, P);
+  const size_t stride = pack_stride(ctx, P, L.pending_feats);
   for (int i = 0; i < L.g; ++i) {
     const char* hs = static_cast<const char*>(L.host_stage) + i * stride;
     if (*reinterpret_cast<const uint32_t*>(hs + 68) != 0u) {
@@ -1565,7 +1549,7 @@ int dc_op_rpn_decode(dc_ctx* ctx, const float* heads, int h, int w, int k, const
                      float y0, float sx, float sy, int img_h, int img_w, float* boxes, float* anchors_out,
                      float* trans, float* x1y1x2y2, float* p, uint8_t* valid) {
   OP_PROLOGUE();
-  KCHK(launch_rpn_decode(heads, h, w, k, anchors_dev, x0, y0, sx, sy, img_h, img_w, boxes, anchors_out, trans,
+  KCHK(launch_rpn_decode(heads, 1, h, w, k, anchors_dev, x0, y0, sx, sy, img_h, img_w, boxes, anchors_out, trans,
                          x1y1x2y2, p, valid, 1, s));
   OP_EPILOGUE();
 }

@@ -386,7 +386,8 @@ __global__ void fill_i32_kernel(int32_t* p, int32_t v, int n) {
 __global__ __launch_bounds__(256) void recog_heads_kernel(const float* __restrict__ codes, const float* __restrict__ w5,
                                                           const float* __restrict__ b5, const float* __restrict__ roi,
                                                           float* __restrict__ obj, float* __restrict__ trans,
-                                                          float* __restrict__ fin, int n, int D) {
+                                                          float* __restrict__ fin, float* __restrict__ fin_xyxy, int n,
+                                                          int D) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
@@ -407,10 +408,17 @@ __global__ __launch_bounds__(256) void recog_heads_kernel(const float* __restric
     const float xa = roi[row * 4 + 0], ya = roi[row * 4 + 1], wa = roi[row * 4 + 2], ha = roi[row * 4 + 3];
     trans[row * 4 + 0] = s[1]; trans[row * 4 + 1] = s[2]; trans[row * 4 + 2] = s[3]; trans[row * 4 + 3] = s[4];
     // nn.ApplyBoxTransform (ApplyBoxTransform.lua:85-88); no FMA contraction to keep op order
-    fin[row * 4 + 0] = __fadd_rn(__fmul_rn(s[1], wa), xa);
-    fin[row * 4 + 1] = __fadd_rn(__fmul_rn(s[2], ha), ya);
-    fin[row * 4 + 2] = __fmul_rn(th_expf(s[3]), wa);
-    fin[row * 4 + 3] = __fmul_rn(th_expf(s[4]), ha);
+    const float fx = __fadd_rn(__fmul_rn(s[1], wa), xa), fy = __fadd_rn(__fmul_rn(s[2], ha), ya);
+    const float fw = __fmul_rn(th_expf(s[3]), wa), fh = __fmul_rn(th_expf(s[4]), ha);
+    fin[row * 4 + 0] = fx;
+    fin[row * 4 + 1] = fy;
+    fin[row * 4 + 2] = fw;
+    fin[row * 4 + 3] = fh;
+    if (fin_xyxy != nullptr) {            // box_utils.xcycwh_to_x1y1x2y2 on the stored values (DenseCapModel.lua:262): one launch less
+      float c0, c1, c2, c3;
+      corners(fx, fy, fw, fh, c0, c1, c2, c3);
+      *reinterpret_cast<f32x4*>(fin_xyxy + (size_t)row * 4) = f32x4{c0, c1, c2, c3};
+    }
   }
 }
 
@@ -501,9 +509,9 @@ hipError_t launch_fill_i32(int32_t* p, int32_t v, int n, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t launch_recog_heads(const float* codes, const float* w5, const float* b5, const float* roi_boxes,
-                              float* obj, float* trans, float* final_boxes, int n, int D, hipStream_t s) {
+                              float* obj, float* trans, float* final_boxes, float* final_xyxy, int n, int D, hipStream_t s) {
   if (D % 256) return hipErrorInvalidValue;
   hipLaunchKernelGGL(recog_heads_kernel, dim3((n + 3) / 4), dim3(256), 0, s, codes, w5, b5, roi_boxes, obj, trans,
-                     final_boxes, n, D);
+                     final_boxes, final_xyxy, n, D);
   return hipGetLastError();
 }

@@ -22,28 +22,46 @@ namespace {
 // from the L2-resident map, blend, one 16-byte store.  A point's C channels are 2 KiB contiguous in the
 // output, so every store instruction of a wave writes 1 KiB linearly.
 constexpr int ROI_MAX_PTS = 256;  // phase 1 uses one thread per point
-__global__ __launch_bounds__(256) void bilinear_roi_pool_kernel(const float* __restrict__ feat, int h, int w, int C,
-                                                                const float* __restrict__ boxes, int B,
-                                                                const int32_t* __restrict__ B_dev, float img_h,
-                                                                float img_w, int HH, int WW, float* __restrict__ out,
-                                                                int out_layout, int split) {
+// Batched over the images of a group (round 5): virtual box v / split runs over nimg * B boxes, image = box / B; every image
+// has its own feature map (feat + image * feat_stride), live count (B_dev[image * bdev_stride]) and B rows of boxes / output.
+// `pick` (optional): the boxes are gathered on the fly -- box b of an image is src_boxes[image * src_stride + pick[b]]
+// (box_utils.nms picks into the RPN boxes, LocalizationLayer.lua:338-343) and is also written to `boxes` (zeros for the rows
+// past the live count), which replaces the separate gather launch.
+__global__ __launch_bounds__(256) void bilinear_roi_pool_kernel(const float* __restrict__ feat_base, int h, int w, int C,
+                                                                float* __restrict__ boxes, int B, int nimg,
+                                                                size_t feat_stride, const int32_t* __restrict__ B_dev,
+                                                                int bdev_stride, const int32_t* __restrict__ pick,
+                                                                const float* __restrict__ src_boxes, size_t src_stride,
+                                                                float img_h, float img_w, int HH, int WW,
+                                                                float* __restrict__ out, int out_layout, int split) {
   __shared__ int s_off[ROI_MAX_PTS][4];     // element offset of each tap (or -1 when outside the map)
   __shared__ float s_w[ROI_MAX_PTS][4];     // w00, w01, w10, w11
   const int C4 = C >> 2;
   const int npts = HH * WW;
-  const int b_live = B_dev ? min(*B_dev, B) : B;
   // `split` workgroups share a box (each takes a contiguous slice of its (point, channel-chunk) items): with few boxes
   // the kernel is a latency chain of ~25 dependent load rounds per thread, not a bandwidth problem
-  for (int v = blockIdx.x; v < B * split; v += gridDim.x) {
-    const int b = v / split, part = v - b * split;
-    const bool live = b < b_live;
+  for (int v = blockIdx.x; v < nimg * B * split; v += gridDim.x) {
+    const int b = v / split, part = v - b * split;         // b: row over all images of the group
+    const int img = b / B, bi = b - img * B;
+    const int b_live = B_dev ? min(B_dev[(size_t)img * bdev_stride], B) : B;
+    const bool live = bi < b_live;
+    const float* feat = feat_base + (size_t)img * feat_stride;
+    __shared__ f32x4 s_box;
+    if (pick != nullptr) {                                  // (the previous box's readers of s_box are behind that box's second barrier)
+      if (threadIdx.x == 0) {
+        f32x4 bx = {0.f, 0.f, 0.f, 0.f};
+        if (live) bx = *reinterpret_cast<const f32x4*>(src_boxes + (size_t)img * src_stride + (size_t)pick[b] * 4);
+        s_box = bx;
+        if (part == 0) *reinterpret_cast<f32x4*>(boxes + (size_t)b * 4) = bx;
+      }
+    }
     // boxes past the RPN NMS count are not sampled but their rows ARE zero-filled: fc6 / fc7, the heads and the decode
     // run over all B rows in the reference caption order (only the NMS and the gathers are bounded by the device-side
     // count), so a dead row must hold defined values -- zeros, as the gathers before it write (advisor finding, round 3)
     __syncthreads();
     if (live && threadIdx.x < npts) {
       const int i = threadIdx.x / WW, j = threadIdx.x - i * WW;
-      const f32x4 bx = *reinterpret_cast<const f32x4*>(boxes + (size_t)b * 4);
+      const f32x4 bx = pick != nullptr ? s_box : *reinterpret_cast<const f32x4*>(boxes + (size_t)b * 4);
       // BoxToAffine.lua:88-91
       const float th23 = __fdiv_rn(__fadd_rn(__fmul_rn(bx[0], 2.f), -1.f - img_w), img_w - 1.f);
       const float th13 = __fdiv_rn(__fadd_rn(__fmul_rn(bx[1], 2.f), -1.f - img_h), img_h - 1.f);
@@ -109,15 +127,25 @@ __global__ __launch_bounds__(256) void bilinear_roi_pool_kernel(const float* __r
 
 }  // namespace
 
+hipError_t launch_bilinear_roi_pool_group(const float* feat_hwc, size_t feat_stride, int nimg, int h, int w, int C,
+                                          float* boxes, int B, const int32_t* B_dev, int bdev_stride,
+                                          const int32_t* pick, const float* src_boxes, size_t src_stride, int img_h,
+                                          int img_w, int HH, int WW, float* out, int out_layout, hipStream_t s) {
+  if (C % 4 || B <= 0 || nimg <= 0 || HH * WW > ROI_MAX_PTS || (pick != nullptr && src_boxes == nullptr)) return hipErrorInvalidValue;
+  const long Bt = (long)B * nimg;
+  long split = (4096 + Bt / 2) / Bt;          // ~4096 workgroups (16 per CU) measured best for 300 .. 2000 boxes
+  split = split < 1 ? 1 : (split > 8 ? 8 : split);
+  const long want = Bt * split;
+  const int grid = want < 256 * 16 ? (int)want : 256 * 16;
+  hipLaunchKernelGGL(bilinear_roi_pool_kernel, dim3((unsigned)grid), dim3(256), 0, s, feat_hwc, h, w, C, boxes, B, nimg,
+                     feat_stride, B_dev, bdev_stride, pick, src_boxes, src_stride, (float)img_h, (float)img_w, HH, WW, out,
+                     out_layout, (int)split);
+  return hipGetLastError();
+}
+
 hipError_t launch_bilinear_roi_pool(const float* feat_hwc, int h, int w, int C, const float* boxes, int B,
                                     const int32_t* B_dev, int img_h, int img_w, int HH, int WW, float* out,
                                     int out_layout, hipStream_t s) {
-  if (C % 4 || B <= 0 || HH * WW > ROI_MAX_PTS) return hipErrorInvalidValue;
-  int split = (4096 + B / 2) / B;             // ~4096 workgroups (16 per CU) measured best for B = 300 .. 2000
-  split = split < 1 ? 1 : (split > 8 ? 8 : split);
-  const long want = (long)B * split;
-  const int grid = want < 256 * 16 ? (int)want : 256 * 16;
-  hipLaunchKernelGGL(bilinear_roi_pool_kernel, dim3((unsigned)grid), dim3(256), 0, s, feat_hwc, h, w, C, boxes, B,
-                     B_dev, (float)img_h, (float)img_w, HH, WW, out, out_layout, split);
-  return hipGetLastError();
+  return launch_bilinear_roi_pool_group(feat_hwc, 0, 1, h, w, C, const_cast<float*>(boxes), B, B_dev, 0, nullptr, nullptr, 0,
+                                        img_h, img_w, HH, WW, out, out_layout, s);
 }
