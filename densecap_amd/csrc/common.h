@@ -140,6 +140,8 @@ void mfma_gemm_plan(const GemmDesc& d, bool serial_mode, int tail_mode, size_t w
 // Launches the fp32 MFMA kernel on `stream`; returns hipSuccess or the launch error.
 hipError_t launch_mfma_gemm(const GemmDesc& d, hipStream_t stream);
 double gemm_flops(const GemmDesc& d);
+// does the split-bf16 mode pay for this contraction (enough tiles for ONE image to fill the chip without K sharing)?
+bool mfma_gemm_bf3_pays(const GemmDesc& d);
 
 // ---- element-wise / layout kernels (elementwise.hip) ---------------------------
 hipError_t launch_chw_to_hwc(const float* in, float* out, int C, int H, int W, hipStream_t s);

@@ -211,7 +211,7 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, const Ws& w = Ws(
   d.stagger = ctx->stagger;
   d.walk = ctx->walk;
   d.epi_wide = ctx->epi_wide;
-  d.bf3 = ctx->math_mode == 1 ? 1 : 0;
+  d.bf3 = ctx->math_mode == 1 && mfma_gemm_bf3_pays(d) ? 1 : 0;
   ProfEvt pe{nullptr, nullptr, gemm_flops(d)};
   if (ctx->prof) {
     pe.a = prof_event(ctx); pe.b = prof_event(ctx);

@@ -1598,6 +1598,16 @@ hipError_t launch_pick(const GemmDesc& d, hipStream_t stream) {
 
 }  // namespace
 
+// Split-bf16 mode is taken contraction by contraction: only where ONE image's problem (plan_M) fills the chip with 128x64
+// tiles (>= 1.5 per CU).  Problems with fewer tiles live on K sharing between workgroups -- split-K, stream-K, tail plans --
+// which this mode's kernels do not have, and lose there (measured: conv5_x 74 vs 82 TF, RPN conv 40 vs 69, LM encoder 51 vs 74,
+// the whole 480x320 / 50-proposal frame 2.62 vs 1.98 ms): they keep the fp32 route.
+bool mfma_gemm_bf3_pays(const GemmDesc& d) {
+  const int pm = d.plan_M > 0 ? d.plan_M : d.M;
+  const long t64 = (long)((pm + 127) / 128) * ((d.N + 63) / 64);
+  return 2 * t64 >= 3 * (long)device_cu_count();
+}
+
 // Few 128x128 tiles and a long K: split K so that ~224-256 workgroups exist (one round on 256 CUs).  Every slice
 // keeps an even number (>= 16) of K-tiles for the K-split kernel.
 int mfma_gemm_splitk(const GemmDesc& d, size_t ws_floats) {

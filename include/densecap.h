@@ -162,8 +162,10 @@ int dc_set_caption_order(dc_ctx* ctx, int after_final_nms);
  *     v_mfma_f32_32x32x16_bf16, which runs at 16x the fp32 MFMA rate -- 2.67x the matrix throughput.  Error against an fp64
  *     result is of the fp32 path's size (tests: <= 1.5x), but the bits differ: NMS / arg-max decisions that hang on the
  *     last ulp may fall the other way, as between any two fp32 summation orders.  Non-finite operands give NaN where fp32
- *     gives inf.  Inputs, outputs and everything between the contractions stay fp32; conv1_1 (3 input channels) and the
- *     objectness / box-regression heads stay on the fp32 path.
+ *     gives inf.  Inputs, outputs and everything between the contractions stay fp32; conv1_1 (3 input channels), the
+ *     objectness / box-regression heads and every contraction too small to fill the chip with whole tiles (one image's
+ *     conv5_x, RPN conv, LM encoder; everything at webcam sizes) stay on the fp32 path -- the mode is taken layer by
+ *     layer, by a rule that depends on ONE image's problem only (results do not depend on lanes or groups).
  * May be changed between forwards; weights need no reloading. */
 #define DC_MATH_FP32 0
 #define DC_MATH_SPLIT_BF16 1
