@@ -48,6 +48,8 @@ _SIGS = {
     "dc_set_localization_test_args": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int]),
     "dc_set_lanes": (C.c_int, [C.c_void_p, C.c_int]),
     "dc_set_caption_order": (C.c_int, [C.c_void_p, C.c_int]),
+    "dc_preprocess_size": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dc_preprocess_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dc_set_math_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "dc_set_graph_replay": (C.c_int, [C.c_void_p, C.c_int]),
     "dc_set_beam_size": (C.c_int, [C.c_void_p, C.c_int]),

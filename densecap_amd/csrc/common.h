@@ -253,3 +253,9 @@ hipError_t launch_bilinear_roi_pool_group(const float* feat_hwc, size_t feat_str
 hipError_t launch_bilinear_roi_pool(const float* feat_hwc, int h, int w, int C, const float* boxes, int B,
                                     const int32_t* B_dev, int img_h, int img_w, int HH, int WW, float* out,
                                     int out_layout, hipStream_t s);
+
+// ---- image preprocessing (preprocess.hip; run_model.lua:67-74) -------------------------------------------------------
+void preprocess_scaled_size(int H0, int W0, int image_size, int* oh, int* ow);
+size_t preprocess_scratch_bytes(int H0, int W0, int oh, int ow);
+hipError_t launch_preprocess_u8(const uint8_t* src_dev, int H0, int W0, int oh, int ow, const float mean_bgr[3],
+                                void* scratch, float* out_chw, uint8_t* rgb_hwc, hipStream_t s);

@@ -131,6 +131,7 @@ struct dc_ctx {
   float* dec_w = nullptr;   // (V1pad + 4Hd, Hd): rows [0,V+1) = lm_out_w, zero rows up to V1pad (multiple of 64), then Wh^T
   int V1pad = 0;
   std::vector<std::unique_ptr<Lane>> lanes;
+  DevBuf pre_src, pre_scratch;      // dc_preprocess_u8: uploaded bytes, width-pass plane + tap tables (grow only)
   // MFMA profile
   bool prof = false;
   std::vector<ProfEvt> prof_pending;
@@ -739,11 +740,15 @@ std::array<int64_t, 28> graph_key(const dc_ctx* ctx, const Lane& L, int g, bool 
           (int64_t)(uintptr_t)L.arena.p, (int64_t)(uintptr_t)L.host_stage, (int64_t)(uintptr_t)L.splitk_ws, ctx->math_mode, 0, 0};
 }
 
-int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_device, bool features_only) {
+// `img`: the g images back to back; `sep` (optional) = g separate images instead (a run of equal-sized images of a mixed list)
+int enqueue_forward(dc_ctx* ctx, Lane& L, const float* img, int g, int img_on_device, bool features_only,
+                    const float* const* sep = nullptr) {
   hipStream_t s = L.stream;
   const size_t img_elems = (size_t)3 * L.H * L.W;
-  if (img_on_device) HIPCHK(hipMemcpyAsync(L.img, img, g * img_elems * 4, hipMemcpyDeviceToDevice, s));
-  else HIPCHK(hipMemcpyAsync(L.img, img, g * img_elems * 4, hipMemcpyHostToDevice, s));
+  const hipMemcpyKind kind = img_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (sep == nullptr) HIPCHK(hipMemcpyAsync(L.img, img, g * img_elems * 4, kind, s));
+  else
+    for (int i = 0; i < g; ++i) HIPCHK(hipMemcpyAsync(L.img + (size_t)i * img_elems, sep[i], img_elems * 4, kind, s));
   L.g = g;
   const size_t stride = pack_stride(ctx, L.P, features_only);
   for (int i = 0; i < g; ++i) *reinterpret_cast<uint32_t*>(static_cast<char*>(L.host_stage) + i * stride + 68) = 0;
@@ -830,9 +835,10 @@ int harvest(dc_ctx* ctx, Lane& L) {
     int K = *reinterpret_cast<const int32_t*>(hs);
     if (L.pending_feats) {
       K = std::min(K, L.pending_capacity);
-      if (L.pending_k_dst) *L.pending_k_dst = K;
-      if (L.pending_box_dst) memcpy(L.pending_box_dst, hs + 256, (size_t)K * 16);
-      if (L.pending_feat_dst) memcpy(L.pending_feat_dst, hs + 256 + (size_t)P * 20, (size_t)K * ctx->D * 4);
+      if (L.pending_k_dst) L.pending_k_dst[i] = K;
+      if (L.pending_box_dst) memcpy(L.pending_box_dst + (size_t)i * L.pending_capacity * 4, hs + 256, (size_t)K * 16);
+      if (L.pending_feat_dst)
+        memcpy(L.pending_feat_dst + (size_t)i * L.pending_capacity * ctx->D, hs + 256 + (size_t)P * 20, (size_t)K * ctx->D * 4);
     } else if (L.pending) {
       dc_result* r = L.pending + i;
       K = std::min(K, (int)r->capacity);
@@ -915,6 +921,8 @@ void dc_destroy(dc_ctx* ctx) {
     if (L.stream) hipStreamDestroy(L.stream);
   }
   for (void* p : ctx->owned) hipFree(p);
+  if (ctx->pre_src.p) hipFree(ctx->pre_src.p);
+  if (ctx->pre_scratch.p) hipFree(ctx->pre_scratch.p);
   for (auto e : ctx->prof_pool) hipEventDestroy(e);
   delete ctx;
 }
@@ -1143,6 +1151,21 @@ static int check_image_size(dc_ctx* ctx, int H, int W, const char* who) {
   return DC_OK;
 }
 
+// images of a group share one 32-bit operand offset space in conv1_x (the pooled conv counts window slots)
+static int clamp_group(const dc_ctx* ctx, int G, int H, int W) {
+  if (ctx->plan_mode < 0 ? ctx->serial_mode : ctx->plan_mode == 1) return 1;       // single-image planning: images travel alone
+  const size_t rows1 = std::max((size_t)H * W, (size_t)4 * ((H + 1) / 2) * ((W + 1) / 2));
+  while (G > 1 && (size_t)G * rows1 * 64 * 4 >= 0xffffe000ull) --G;
+  return std::max(G, 1);
+}
+// length of the run of equal-sized images starting at i that may travel as one group
+static int group_run(const dc_ctx* ctx, const int* H, const int* W, int i, int n) {
+  const int G = clamp_group(ctx, std::max(1, ctx->group), H[i], W[i]);
+  int g = 1;
+  while (g < G && i + g < n && H[i + g] == H[i] && W[i + g] == W[i]) ++g;
+  return g;
+}
+
 static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, int on_dev, dc_result* outs) {
   if (!ctx) return DC_E_INVALID;
   if (!ctx->have_weights) return ctx->fail(DC_E_STATE, "dc_forward_*: weights not loaded");
@@ -1153,14 +1176,11 @@ static int forward_common(dc_ctx* ctx, const float* imgs, int n, int H, int W, i
   for (int i = 0; i < n; ++i)
     if (outs[i].capacity <= 0) return ctx->fail(DC_E_INVALID, "dc_result.capacity must be > 0");
   // images travel in groups of G through a lane (dc_set_group): the group's dense stages share launches
-  int G = std::max(1, std::min(ctx->group > 0 ? ctx->group : 1, n));
   // Single-image planning (dc_set_lanes(1)) shares a layer's partial last round along K -- plans made for ONE image's tile
   // count, which a group does not have: images travel alone there, so that results never depend on the group.
-  if (ctx->plan_mode < 0 ? ctx->serial_mode : ctx->plan_mode == 1) G = 1;
-  // a group's conv1_x activation shares one 32-bit offset space; the pooled conv counts window slots (4 per 2x2 window: a
-  // pixel more per odd side) -- the same count the launch itself checks
-  const size_t rows1 = std::max((size_t)H * W, (size_t)4 * ((H + 1) / 2) * ((W + 1) / 2));
-  while (G > 1 && (size_t)G * rows1 * 64 * 4 >= 0xffffe000ull) --G;
+  // A group's conv1_x activation shares one 32-bit offset space; the pooled conv counts window slots (4 per 2x2 window: a
+  // pixel more per odd side) -- the same count the launch itself checks.
+  const int G = clamp_group(ctx, std::max(1, std::min(ctx->group > 0 ? ctx->group : 1, n)), H, W);
   const int ngroups = (n + G - 1) / G;
   const int nl = std::min(ngroups, ctx->max_lanes);
   while ((int)ctx->lanes.size() < nl) ctx->lanes.emplace_back(new Lane());
@@ -1194,12 +1214,16 @@ int dc_forward_images(dc_ctx* ctx, const float* const* imgs, const int* H, const
   HIPCHK(hipSetDevice(ctx->device));
   const int nl = std::min(n, ctx->max_lanes);
   while ((int)ctx->lanes.size() < nl) ctx->lanes.emplace_back(new Lane());
-  for (int i = 0; i < n; ++i) {
-    Lane& L = *ctx->lanes[i % nl];
-    DCCHK_DRAIN(harvest(ctx, L));                 // the lane's previous image leaves before its workspace is re-carved
-    DCCHK_DRAIN(lane_prepare(ctx, L, H[i], W[i], effective_proposals(ctx, H[i], W[i]), 1));
+  // runs of consecutive images of ONE size travel as groups (dc_set_group), like the images of dc_forward_batch
+  int gi = 0;
+  for (int i = 0; i < n; ++gi) {
+    const int g = group_run(ctx, H, W, i, n);
+    Lane& L = *ctx->lanes[gi % nl];
+    DCCHK_DRAIN(harvest(ctx, L));                 // the lane's previous images leave before its workspace is re-carved
+    DCCHK_DRAIN(lane_prepare(ctx, L, H[i], W[i], effective_proposals(ctx, H[i], W[i]), std::max(g, L.H == H[i] && L.W == W[i] ? L.G : 1)));
     L.pending = &outs[i];
-    DCCHK_DRAIN(enqueue_forward(ctx, L, imgs[i], 1, on_dev, false));
+    DCCHK_DRAIN(enqueue_forward(ctx, L, nullptr, g, on_dev, false, imgs + i));
+    i += g;
   }
   for (int l = 0; l < nl; ++l) DCCHK_DRAIN(harvest(ctx, *ctx->lanes[l]));
   prof_collect(ctx);
@@ -1245,19 +1269,62 @@ int dc_extract_features_images(dc_ctx* ctx, const float* const* imgs, const int*
   HIPCHK(hipSetDevice(ctx->device));
   const int nl = std::min(n, ctx->max_lanes);
   while ((int)ctx->lanes.size() < nl) ctx->lanes.emplace_back(new Lane());
-  for (int i = 0; i < n; ++i) {
-    Lane& L = *ctx->lanes[i % nl];
+  // runs of equal-sized images travel as groups here too (round-4 verdict: extractFeatures always ran groups of one)
+  int gi = 0;
+  for (int i = 0; i < n; ++gi) {
+    const int g = group_run(ctx, H, W, i, n);
+    Lane& L = *ctx->lanes[gi % nl];
     DCCHK_DRAIN(harvest(ctx, L));
-    DCCHK_DRAIN(lane_prepare(ctx, L, H[i], W[i], effective_proposals(ctx, H[i], W[i]), 1));
+    DCCHK_DRAIN(lane_prepare(ctx, L, H[i], W[i], effective_proposals(ctx, H[i], W[i]), std::max(g, L.H == H[i] && L.W == W[i] ? L.G : 1)));
     L.pending = nullptr;
     L.pending_capacity = capacity;
-    L.pending_box_dst = boxes + (size_t)i * capacity * 4;
+    L.pending_box_dst = boxes + (size_t)i * capacity * 4;           // image j of the group: j * capacity rows further on
     L.pending_feat_dst = feats + (size_t)i * capacity * ctx->D;
     L.pending_k_dst = K + i;
-    DCCHK_DRAIN(enqueue_forward(ctx, L, imgs[i], 1, on_dev, true));
+    DCCHK_DRAIN(enqueue_forward(ctx, L, nullptr, g, on_dev, true, imgs + i));
+    i += g;
   }
   for (int l = 0; l < nl; ++l) DCCHK_DRAIN(harvest(ctx, *ctx->lanes[l]));
   prof_collect(ctx);
+  return DC_OK;
+}
+
+// run_model.lua:67-74 on the device.  Synchronous; runs on the ctx's primary stream.
+int dc_preprocess_size(int H0, int W0, int image_size, int* H, int* W) {
+  if (H0 <= 0 || W0 <= 0 || image_size <= 0 || !H || !W) return DC_E_INVALID;
+  preprocess_scaled_size(H0, W0, image_size, H, W);
+  return (*H >= 1 && *W >= 1) ? DC_OK : DC_E_INVALID;
+}
+
+int dc_preprocess_u8(dc_ctx* ctx, const uint8_t* rgb_hwc, int H0, int W0, int on_device, int image_size, float* out_chw_dev,
+                     uint8_t* scaled_rgb_dev) {
+  if (!ctx) return DC_E_INVALID;
+  if (!rgb_hwc || !out_chw_dev || H0 <= 0 || W0 <= 0 || image_size <= 0 || (size_t)H0 * W0 > ((size_t)1 << 28))
+    return ctx->fail(DC_E_INVALID, "dc_preprocess_u8: bad arguments");
+  int oh = 0, ow = 0;
+  preprocess_scaled_size(H0, W0, image_size, &oh, &ow);
+  if (oh < 1 || ow < 1) return ctx->fail(DC_E_INVALID, "dc_preprocess_u8: a %dx%d image scaled to %d leaves no pixels", W0, H0, image_size);
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s;
+  DCCHK(lane0_stream(ctx, &s));
+  auto grow = [&](DevBuf& b, size_t bytes) -> int {
+    if (b.bytes >= bytes) return DC_OK;
+    if (b.p) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(b.p)); b = DevBuf(); }
+    HIPCHK(hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return DC_OK;
+  };
+  const uint8_t* src = rgb_hwc;
+  if (!on_device) {
+    const size_t nb = (size_t)H0 * W0 * 3;
+    DCCHK(grow(ctx->pre_src, nb));
+    HIPCHK(hipMemcpyAsync(ctx->pre_src.p, rgb_hwc, nb, hipMemcpyHostToDevice, s));
+    src = static_cast<const uint8_t*>(ctx->pre_src.p);
+  }
+  DCCHK(grow(ctx->pre_scratch, preprocess_scratch_bytes(H0, W0, oh, ow)));
+  const float mean_bgr[3] = {103.939f, 116.779f, 123.68f};          // run_model.lua:73
+  KCHK(launch_preprocess_u8(src, H0, W0, oh, ow, mean_bgr, ctx->pre_scratch.p, out_chw_dev, scaled_rgb_dev, s));
+  HIPCHK(hipStreamSynchronize(s));
   return DC_OK;
 }
 

@@ -17,7 +17,7 @@ import sys
 
 import numpy as np
 
-from .run_model import load_image_caffe, xcycwh_to_xywh
+from .run_model import ImagePipeline, xcycwh_to_xywh
 
 
 def build_parser():
@@ -34,6 +34,12 @@ def build_parser():
     a("-max_images", type=int, default=0)
     a("-output_h5", default="")
     a("-gpu", type=int, default=0)
+    # ---- not reference flags ----
+    a("-lanes", type=int, default=2, help="images in flight")
+    a("-group", type=int, default=4, help="equal-sized images that share the dense launches (dc_set_group)")
+    a("-io_threads", type=int, default=8, help="threads that decode the input files")
+    a("-host_preprocess", type=int, default=0, help="1: image.scale on the host (NumPy restatement) instead of dc_preprocess_u8")
+    a("-timing", type=int, default=0, help="1: print the images/s of the image loop at the end")
     a("-synthetic_weights", type=int, default=0,
       help="1: random weights in checkpoint shapes (no pretrained .t7 is available offline)")
     return p
@@ -67,29 +73,38 @@ def main(argv=None):
             raise SystemExit("checkpoint %s not found (use -synthetic_weights 1 for random weights)" % opt.checkpoint)
         weights = t7.weights_from_checkpoint(t7.load(opt.checkpoint))
     model = DenseCapModel(weights, device=opt.gpu)
-    model.setLanes(1 if len(paths) == 1 else 2)      # a list of images is pipelined over two streams (same results per image)
+    model.setLanes(1 if len(paths) == 1 else opt.lanes)   # a list of images is pipelined over the lanes (same results per image)
+    model.setGroup(1 if len(paths) == 1 else opt.group)
     model.setTestArgs(rpn_nms_thresh=opt.rpn_nms_thresh, final_nms_thresh=opt.final_nms_thresh,
                       num_proposals=opt.num_proposals)
     model.evaluate()
     N, M = len(paths), opt.boxes_per_image
     all_boxes = np.zeros((N, M, 4), np.float32)
     all_feats = None
-    CHUNK = 16
-    for k0 in range(0, N, CHUNK):
-        chunk = paths[k0:k0 + CHUNK]
-        pre = []
-        for j, path in enumerate(chunk):
-            print("Processing image %d / %d" % (k0 + j + 1, N))
-            pre.append(load_image_caffe(path, opt.image_size)[0])
-        for j, (boxes_xcycwh, feats) in enumerate(model.extractFeatures_images(pre)):
-            i = k0 + j
+    import time
+    t_loop = time.perf_counter()
+    # extract_features.lua:79-91 as a pipeline: files decoded ahead on io threads, image.scale & co on the device
+    pipe = ImagePipeline(paths, opt.image_size, opt.gpu, model.ctx, io_threads=opt.io_threads,
+                         chunk=max(1, opt.lanes) * max(1, opt.group) * 2, host_preprocess=bool(opt.host_preprocess), want_rgb=False)
+    for chunk in pipe:
+        for i, _, _ in chunk:
+            print("Processing image %d / %d" % (i + 1, N))
+        outs = model.extractFeatures_images_device([d for _, d, _ in chunk])
+        for (i, dev, _), (boxes_xcycwh, feats) in zip(chunk, outs):
+            pipe.recycle(dev)
             if len(boxes_xcycwh) < M:     # the reference's boxes[{{1, M}}] raises on a short result as well
                 raise SystemExit("image %s: only %d boxes survive the final NMS, -boxes_per_image is %d"
-                                 % (chunk[j], len(boxes_xcycwh), M))
+                                 % (paths[i], len(boxes_xcycwh), M))
             if all_feats is None:
                 all_feats = np.zeros((N, M, feats.shape[1]), np.float32)
             all_boxes[i] = xcycwh_to_xywh(boxes_xcycwh)[:M]
             all_feats[i] = feats[:M]
+    pipe.close()
+    if opt.timing:
+        dt = time.perf_counter() - t_loop
+        print("TIMING %d images in %.3f s = %.1f images/s (decode + preprocess + extractFeatures; lanes %d, group %d, %d io "
+              "threads, %s preprocessing)" % (N, dt, N / max(dt, 1e-9), opt.lanes, opt.group, opt.io_threads,
+                                              "host" if opt.host_preprocess else "device"))
     if all_feats is None:
         all_feats = np.zeros((0, M, 4096), np.float32)
     write_datasets(opt.output_h5, all_feats, all_boxes)

@@ -362,6 +362,41 @@ class DenseCapModel:
         check(self.ctx.h, self.lib.dc_forward_images(self.ctx.h, ptrs, Hs, Ws, n, 0, res), "dc_forward_images")
         return [(b[:res[i].K].copy(), s[:res[i].K].copy(), t[:res[i].K].copy()) for i, (b, s, t) in enumerate(keep)]
 
+    def forward_images_device(self, dev_imgs):
+        """forward_images on images that are ALREADY on the device: dev_imgs = sequence of ops.DeviceArray (3,H,W) float32
+        (ops.preprocess_u8 makes them).  Runs of equal-sized images travel as groups (setGroup)."""
+        self._push_test_args()
+        n = len(dev_imgs)
+        if n == 0:
+            return []
+        ptrs = (C.c_void_p * n)(*[a.ptr.value for a in dev_imgs])
+        Hs = (C.c_int * n)(*[a.shape[1] for a in dev_imgs])
+        Ws = (C.c_int * n)(*[a.shape[2] for a in dev_imgs])
+        res = (DcResult * n)()
+        keep = []
+        for i, a in enumerate(dev_imgs):
+            r, b, s, t = self._new_result(self._capacity(a.shape[1], a.shape[2]))
+            res[i] = r
+            keep.append((b, s, t))
+        check(self.ctx.h, self.lib.dc_forward_images(self.ctx.h, ptrs, Hs, Ws, n, 1, res), "dc_forward_images")
+        return [(b[:res[i].K].copy(), s[:res[i].K].copy(), t[:res[i].K].copy()) for i, (b, s, t) in enumerate(keep)]
+
+    def extractFeatures_images_device(self, dev_imgs):
+        """extractFeatures_images on device-resident images (ops.preprocess_u8): list of (boxes, feats)."""
+        self._push_test_args()
+        n = len(dev_imgs)
+        if n == 0:
+            return []
+        cap = max(self._capacity(a.shape[1], a.shape[2]) for a in dev_imgs)
+        ptrs = (C.c_void_p * n)(*[a.ptr.value for a in dev_imgs])
+        Hs = (C.c_int * n)(*[a.shape[1] for a in dev_imgs])
+        Ws = (C.c_int * n)(*[a.shape[2] for a in dev_imgs])
+        boxes = np.zeros((n, cap, 4), np.float32); feats = np.zeros((n, cap, self.fc_dim), np.float32)
+        K = (C.c_int32 * n)()
+        check(self.ctx.h, self.lib.dc_extract_features_images(self.ctx.h, ptrs, Hs, Ws, n, 1, cap, boxes.ctypes.data,
+                                                              feats.ctypes.data, K), "dc_extract_features_images")
+        return [(boxes[i, :K[i]].copy(), feats[i, :K[i]].copy()) for i in range(n)]
+
     def extractFeatures(self, img):
         """DenseCapModel:extractFeatures -> (boxes_xcycwh (K,4), feats (K,fc_dim))."""
         self._push_test_args()

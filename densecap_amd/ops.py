@@ -86,6 +86,36 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+# ---- preprocessing (run_model.lua:67-74 on the device) ----------------------------------------
+def preprocess_size(lib, H0, W0, image_size):
+    H, W = C.c_int(0), C.c_int(0)
+    rc = lib.dc_preprocess_size(int(H0), int(W0), int(image_size), C.byref(H), C.byref(W))
+    if rc < 0:
+        raise ValueError("image.scale: %dx%d -> size %d leaves no pixels" % (W0, H0, image_size))
+    return H.value, W.value
+
+
+def preprocess_u8(ctx, rgb_hwc_u8, image_size, want_rgb=True, out=None, rgb=None):
+    """image.load's float conversion + image.scale(img, image_size) + BGR, x255, minus the VGG mean, on the device
+    (dc_preprocess_u8).  rgb_hwc_u8: (H0,W0,3) uint8 as a JPEG decoder delivers it.  Returns (DeviceArray (3,H,W) float32 --
+    what forward_images_device takes --, DeviceArray (H,W,3) uint8 of the scaled image for the visualiser or None).
+    out / rgb: buffers of exactly those shapes to fill instead of new ones."""
+    a = np.ascontiguousarray(rgb_hwc_u8, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("preprocess_u8 wants an (H,W,3) uint8 image")
+    H0, W0 = a.shape[:2]
+    H, W = preprocess_size(ctx.lib, H0, W0, image_size)
+    if out is None:
+        out = ctx.empty((3, H, W), np.float32)
+    if rgb is None and want_rgb:
+        rgb = ctx.empty((H, W, 3), np.uint8)
+    if out.shape != (3, H, W) or (rgb is not None and rgb.shape != (H, W, 3)):
+        raise ValueError("preprocess_u8: output buffers do not have the scaled image's shape")
+    check(ctx.h, ctx.lib.dc_preprocess_u8(ctx.h, a.ctypes.data, H0, W0, 0, int(image_size), out.ptr, rgb.ptr if rgb else None),
+          "dc_preprocess_u8")
+    return out, rgb
+
+
 # ---- layout ----------------------------------------------------------------------------------
 def chw_to_hwc(ctx, x):
     C_, H, W = x.shape

@@ -25,21 +25,40 @@ VGG_MEAN_BGR = np.array([103.939, 116.779, 123.68], np.float32)   # run_model.lu
 
 
 def build_parser():
+    """The reference's flags (run_model.lua:26-61), every one of them, plus the scheduling knobs of this path."""
     p = argparse.ArgumentParser(prefix_chars="-", description=__doc__,
                                 formatter_class=argparse.RawDescriptionHelpFormatter)
     a = p.add_argument
+    # Model options
     a("-checkpoint", default="data/models/densecap/densecap-pretrained-vgg16.t7")
     a("-image_size", type=int, default=720)
     a("-rpn_nms_thresh", type=float, default=0.7)
     a("-final_nms_thresh", type=float, default=0.3)
     a("-num_proposals", type=int, default=1000)
-    a("-input_image", default="")
-    a("-input_dir", default="")
-    a("-max_images", type=int, default=100)
-    a("-output_vis", type=int, default=1)
+    # Input settings
+    a("-input_image", default="", help="A path to a single specific image to caption")
+    a("-input_dir", default="", help="A path to a directory with images to caption")
+    a("-input_split", default="", help="A VisualGenome split identifier to process (train|val|test)")
+    a("-splits_json", default="info/densecap_splits.json")             # only used when input_split is given
+    a("-vg_img_root_dir", default="", help="root directory for vg images")
+    # Output settings
+    a("-max_images", type=int, default=100, help="max number of images to process")
+    a("-output_dir", default="", help="if given: every image with its first num_to_draw boxes and captions drawn on it")
+    a("-num_to_draw", type=int, default=10, help="max number of predictions per image")
+    a("-text_size", type=int, default=2)
+    a("-box_width", type=int, default=2, help="width of rendered box")
+    a("-output_vis", type=int, default=1, help="if 1 then writes files needed for pretty vis into vis/")
     a("-output_vis_dir", default="vis/data")
+    # Misc
     a("-gpu", type=int, default=0)
-    a("-lanes", type=int, default=2, help="images in flight when a directory is processed (not a reference flag)")
+    a("-use_cudnn", type=int, default=1, help="accepted for compatibility; this path has no cuDNN / MIOpen to switch")
+    # ---- not reference flags ----
+    a("-lanes", type=int, default=2, help="images in flight when several images are processed")
+    a("-group", type=int, default=4, help="equal-sized images that share the dense launches (dc_set_group)")
+    a("-io_threads", type=int, default=8, help="threads that decode the input files / write the output images")
+    a("-host_preprocess", type=int, default=0,
+      help="1: image.scale on the host (the NumPy restatement) instead of dc_preprocess_u8; same bits, ~100x slower")
+    a("-timing", type=int, default=0, help="1: print the images/s of the image loop (files in -> results out) at the end")
     a("-synthetic_weights", type=int, default=0,
       help="1: random weights in checkpoint shapes (no pretrained .t7 is available offline)")
     return p
@@ -135,12 +154,17 @@ def xcycwh_to_xywh(boxes):
 
 
 def get_input_images(opt):
+    """run_model.lua:115-143."""
     if opt.input_image:
         return [opt.input_image]
     if opt.input_dir:
         return [os.path.join(opt.input_dir, fn) for fn in sorted(os.listdir(opt.input_dir))
                 if not fn.startswith(".")]
-    raise SystemExit("one of input_image or input_dir must be provided.")
+    if opt.input_split:
+        with open(opt.splits_json) as f:
+            info = json.load(f)
+        return [os.path.join(opt.vg_img_root_dir, "%s.jpg" % i) for i in info[opt.input_split]]
+    raise SystemExit("one of input_image, input_dir, or input_split must be provided.")
 
 
 def result_to_json(boxes_xywh, scores, captions):
@@ -148,9 +172,134 @@ def result_to_json(boxes_xywh, scores, captions):
                 scores=[float(s) for s in np.asarray(scores).reshape(-1)], captions=list(captions))
 
 
+# vis_utils.WAD_COLORS (densecap/vis_utils.lua:5-27 defines the palette; any palette serves the purpose)
+_COLORS = [(173, 35, 35), (42, 75, 215), (29, 105, 20), (129, 74, 25), (129, 38, 192), (160, 160, 160), (129, 197, 122),
+           (157, 175, 255), (41, 208, 208), (255, 146, 51), (255, 238, 51), (233, 222, 187), (255, 205, 243)]
+
+
+def render_result(rgb_hwc, boxes_xywh, captions, opt):
+    """lua_render_result (run_model.lua:96-113) / vis_utils.densecap_draw (vis_utils.lua:44-79): the first num_to_draw boxes
+    as rectangles of box_width pixels with their captions.  The font is PIL's (torch/image's bitmap font is not
+    available): same layout, not the same pixels."""
+    from PIL import Image, ImageDraw
+    im = Image.fromarray(rgb_hwc).copy()
+    dr = ImageDraw.Draw(im)
+    n = min(opt.num_to_draw, len(boxes_xywh))
+    for i in range(n):
+        x, y, w, h = (float(v) for v in boxes_xywh[i])
+        col = _COLORS[(i + 1) % len(_COLORS)]
+        dr.rectangle([x - opt.box_width, y - opt.box_width, x + w + opt.box_width, y + h + opt.box_width], outline=col,
+                     width=max(1, int(opt.box_width)))
+        try:
+            from PIL import ImageFont
+            font = ImageFont.load_default(size=6 * max(1, int(opt.text_size)) + 4)
+        except Exception:
+            font = None
+        dr.text((x + opt.box_width + 1, y + opt.box_width + 1), captions[i], fill=col, font=font)
+    return im
+
+
+def _decode_file(path):
+    """image.load(path, 3)'s decode (run_model.lua:67): RGB bytes.  PIL here, libjpeg through torch/image there."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert("RGB"), dtype=np.uint8)
+
+
+class ImagePipeline:
+    """The image loop of run_model.lua:160-180 / extract_features.lua:79-91 as a pipeline in front of the device:
+
+        io threads : decode the next files (PIL releases the interpreter lock)            \\  all of it overlaps with the
+        prep thread: dc_preprocess_u8 on a context of its own (upload + two launches)      >  device, which is busy with the
+        (caller)   : writes results / images of finished chunks on the same io threads    /   previous chunk
+
+    Iterating yields chunks [(index, device image (3,H,W) float32, scaled RGB bytes (H,W,3) or None), ...] in file order;
+    give every device image back with recycle().  Round-4 verdict: done serially with a Python resize, the loop ran at
+    5-10 images/s in front of a 180 images/s device."""
+
+    def __init__(self, paths, image_size, gpu, model_ctx, io_threads=8, chunk=16, host_preprocess=False, want_rgb=True):
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        from . import ops
+        self.paths, self.num, self.chunk = list(paths), len(paths), max(1, int(chunk))
+        self.pool = ThreadPoolExecutor(max_workers=max(1, int(io_threads)))
+        self._decoded = [None] * self.num
+        self._ahead = 3 * self.chunk
+        self._ready = queue.Queue(maxsize=2 * self.chunk)      # bounds the device memory in flight
+        # device buffers are recycled by shape (a directory is mostly one or two sizes): hipMalloc / hipFree synchronise the device
+        self._spare, self._lock = {}, threading.Lock()
+        self._host = bool(host_preprocess)
+        for i in range(min(self._ahead, self.num)):
+            self._submit(i)
+
+        def worker():
+            pctx = None
+            try:
+                pctx = ops.Context(gpu) if not self._host else None
+                for i in range(self.num):
+                    rgb0 = self._decoded[i].result()
+                    self._decoded[i] = True
+                    self._submit(i + self._ahead)
+                    if self._host:
+                        img_caffe, sc = preprocess_rgb01(rgb0.astype(np.float32).transpose(2, 0, 1) / np.float32(255.0), image_size)
+                        rgb = np.ascontiguousarray((np.clip(sc, 0, 1) * 255.0).astype(np.uint8).transpose(1, 2, 0)) if want_rgb else None
+                        self._ready.put((i, model_ctx.to_device(img_caffe[0]), rgb))
+                    else:
+                        H, W = ops.preprocess_size(pctx.lib, rgb0.shape[0], rgb0.shape[1], image_size)
+                        dev = self._take(pctx, (3, H, W), np.float32)
+                        rgb_dev = self._take(pctx, (H, W, 3), np.uint8) if want_rgb else None
+                        ops.preprocess_u8(pctx, rgb0, image_size, want_rgb=want_rgb, out=dev, rgb=rgb_dev)
+                        self._ready.put((i, dev, rgb_dev.numpy() if want_rgb else None))
+                        if rgb_dev is not None:
+                            self.recycle(rgb_dev)
+            except BaseException as e:                   # noqa: BLE001 -- handed to the consuming thread
+                self._ready.put(e)
+            finally:
+                self._ready.put(None)
+        self._thread = threading.Thread(target=worker, daemon=True)
+        self._thread.start()
+
+    def _submit(self, i):
+        if i < self.num and self._decoded[i] is None:
+            self._decoded[i] = self.pool.submit(_decode_file, self.paths[i])
+
+    def _take(self, ctx, shape, dtype):
+        with self._lock:
+            lst = self._spare.get((tuple(shape), np.dtype(dtype).str))
+            if lst:
+                return lst.pop()
+        return ctx.empty(shape, dtype)
+
+    def recycle(self, buf):
+        if self._host:
+            buf.free()
+            return
+        with self._lock:
+            self._spare.setdefault((buf.shape, buf.dtype.str), []).append(buf)
+
+    def __iter__(self):
+        done, chunk = False, []
+        while not done:
+            item = self._ready.get()
+            if isinstance(item, BaseException):
+                raise item
+            if item is None:
+                done = True
+            else:
+                chunk.append(item)
+            if chunk and (done or len(chunk) >= self.chunk):
+                yield chunk
+                chunk = []
+
+    def close(self):
+        self._thread.join()
+        self.pool.shutdown()
+
+
 def main(argv=None):
     opt = build_parser().parse_args(argv)
-    from . import DenseCapModel
+    from . import DenseCapModel, ops
     if opt.synthetic_weights:
         from .weights import make_synthetic_weights
         weights = make_synthetic_weights()
@@ -169,29 +318,59 @@ def main(argv=None):
     model = DenseCapModel(weights, device=opt.gpu)                      # utils.setup_gpus + model:convert
     paths = get_input_images(opt)
     num = min(len(paths), opt.max_images)
-    # one image: single-image mode (lowest latency, like the reference); a directory: its images -- whatever their
-    # sizes -- are pipelined over the lanes in chunks (dc_forward_images), results identical to one-by-one processing
+    # one image: single-image mode (lowest latency, like the reference); several: pipelined over the lanes, runs of
+    # equal-sized images sharing their dense launches -- results identical to one-by-one processing
     model.setLanes(1 if num == 1 else opt.lanes)
+    model.setGroup(1 if num == 1 else opt.group)
     model.setTestArgs(rpn_nms_thresh=opt.rpn_nms_thresh, final_nms_thresh=opt.final_nms_thresh,
                       num_proposals=opt.num_proposals)
     model.evaluate()
-    results = []
-    CHUNK = 16
-    for k0 in range(0, num, CHUNK):
-        chunk = paths[k0:min(k0 + CHUNK, num)]
-        pre = []
-        for j, path in enumerate(chunk):
-            print("%d/%d processing image %s" % (k0 + j + 1, num, path))
-            pre.append(load_image_caffe(path, opt.image_size))
-        outs = model.forward_images([p[0] for p in pre])
-        for path, (img_caffe, rgb), (boxes, scores, tokens) in zip(chunk, pre, outs):
-            rj = result_to_json(xcycwh_to_xywh(boxes), scores, model.decodeSequence(tokens))
-            if opt.output_vis == 1:
-                os.makedirs(opt.output_vis_dir, exist_ok=True)
-                from PIL import Image
-                Image.fromarray(rgb).save(os.path.join(opt.output_vis_dir, os.path.basename(path)))
-                rj["img_name"] = os.path.basename(path)
-                results.append(rj)
+    if opt.output_vis == 1:
+        os.makedirs(opt.output_vis_dir, exist_ok=True)
+    if opt.output_dir:
+        os.makedirs(opt.output_dir, exist_ok=True)
+
+    # ---- the loop of run_model.lua:160-180 as a pipeline (ImagePipeline below) ------------------------------------------
+    import time
+    t_loop = time.perf_counter()
+    CHUNK = max(1, opt.lanes) * max(1, opt.group) * 2
+    pipe = ImagePipeline(paths[:num], opt.image_size, opt.gpu, model.ctx, io_threads=opt.io_threads, chunk=CHUNK,
+                         host_preprocess=bool(opt.host_preprocess), want_rgb=True)
+    pool = pipe.pool
+    results = [None] * num
+    writes = []
+
+    def finish(i, rgb, out):
+        """run_model.lua:78-95,170-180 for one image (runs on an io thread while the device works on the next chunk)"""
+        boxes, scores, tokens = out
+        xywh = xcycwh_to_xywh(boxes)
+        captions = model.decodeSequence(tokens)
+        name = os.path.basename(paths[i])
+        if opt.output_dir:
+            render_result(rgb, xywh, captions, opt).save(os.path.join(opt.output_dir, name))
+        if opt.output_vis == 1:
+            from PIL import Image
+            Image.fromarray(rgb).save(os.path.join(opt.output_vis_dir, name))
+            rj = result_to_json(xywh, scores, captions)
+            rj["img_name"] = name
+            results[i] = rj
+
+    for chunk in pipe:
+        for i, _, _ in chunk:
+            print("%d/%d processing image %s" % (i + 1, num, paths[i]))
+        outs = model.forward_images_device([d for _, d, _ in chunk])
+        for (i, dev, rgb), out in zip(chunk, outs):
+            pipe.recycle(dev)
+            writes.append(pool.submit(finish, i, rgb, out))
+    for w in writes:
+        w.result()
+    pipe.close()
+    if opt.timing:
+        dt = time.perf_counter() - t_loop
+        print("TIMING %d images in %.3f s = %.1f images/s (decode + preprocess + forward + captions + image files; "
+              "lanes %d, group %d, %d io threads, %s preprocessing)" % (num, dt, num / dt, opt.lanes, opt.group, opt.io_threads,
+                                                                      "host" if opt.host_preprocess else "device"))
+    results = [r for r in results if r is not None]
     if results:
         out = dict(results=results, opt={k: v for k, v in vars(opt).items()})
         with open(os.path.join(opt.output_vis_dir, "results.json"), "w") as f:

@@ -195,6 +195,18 @@ int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img
 int dc_extract_features_images(dc_ctx* ctx, const float* const* imgs, const int* H, const int* W, int n,
                                int imgs_on_device, int capacity, float* boxes, float* feats, int32_t* K);
 
+/* run_model.lua:67-74 (`run_image` before the forward) on the device: image.load's byte -> float conversion (byte / 255),
+ * image.scale(img, image_size) -- torch/image's scaleBilinear: scaleLinear_rowcol along the width, then the height; linear
+ * interpolation where a side grows, area averaging where it shrinks; the longer side becomes image_size --, RGB -> BGR,
+ * x 255, minus the VGG mean (103.939, 116.779, 123.68).  rgb_hwc: (H0, W0, 3) bytes as a JPEG decoder delivers them, host or
+ * device memory (on_device); out_chw_dev: (3, H, W) fp32 on the device with (H, W) from dc_preprocess_size -- the tensor
+ * dc_forward_test / dc_forward_images take with img_on_device = 1; scaled_rgb_dev (optional, device): the scaled image as
+ * (H, W, 3) bytes, what run_model.lua:184 saves for the visualiser.  Every sample is the same chain of fp32 operations as the
+ * library's C loops (bit-equal to the host restatement in densecap_amd/run_model.py).  Synchronous. */
+int dc_preprocess_size(int H0, int W0, int image_size, int* H, int* W);
+int dc_preprocess_u8(dc_ctx* ctx, const uint8_t* rgb_hwc, int H0, int W0, int on_device, int image_size, float* out_chw_dev,
+                     uint8_t* scaled_rgb_dev);
+
 /* Per-stage GPU time of the most recent dc_forward_test on this ctx, measured with
  * HIP events on the ctx's stream (replaces LocalizationLayer:timeit,
  * LocalizationLayer.lua:219-230).  names[i] are static strings.  Returns the

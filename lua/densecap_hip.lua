@@ -49,6 +49,9 @@ int dc_extract_features(dc_ctx* ctx, const float* img_chw, int H, int W, int img
                         int capacity, float* boxes, float* feats, int32_t* K);
 int dc_extract_features_images(dc_ctx* ctx, const float* const* imgs, const int* H, const int* W, int n,
                                int imgs_on_device, int capacity, float* boxes, float* feats, int32_t* K);
+int dc_preprocess_size(int H0, int W0, int image_size, int* H, int* W);
+int dc_preprocess_u8(dc_ctx* ctx, const uint8_t* rgb_hwc, int H0, int W0, int on_device, int image_size, float* out_chw_dev,
+                     uint8_t* scaled_rgb_dev);
 int dc_stage_times(dc_ctx* ctx, const char** names, float* ms, int max_stages);
 typedef struct dc_comm dc_comm;
 int dc_comm_unique_id(void* id_out);
