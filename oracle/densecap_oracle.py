@@ -629,13 +629,17 @@ def preprocess(img_rgb01_chw, image_size):
 
 
 def forward_test(img, Wt, rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=1000,
-                 T=15, stages=None, beam_size=None, clip_boxes=True):
+                 T=15, stages=None, beam_size=None, clip_boxes=True, nms_impl="c"):
     """DenseCapModel:forward_test numerics (DenseCapModel.lua:242-275,319-327 via
     LocalizationLayer.lua:250-363).  img: numpy/torch (3,H,W) BGR mean-subtracted.
     Returns (boxes_xcycwh (K,4), scores (K,), tokens (K,T) int64 1-based).
-    If `stages` is a dict, intermediate tensors are stored in it."""
+    If `stages` is a dict, intermediate tensors are stored in it.
+    nms_impl: "c" = the early-out C restatement (fast; what the parity tests use), "vector" = nms_py, the reference's own
+    algorithmic form -- one full-length vector pass per pick (box_utils.lua:206-249) -- which is what BASELINE.md 3 asks the
+    CPU baseline to time.  Same picks either way (tests/test_oracle_golden.py)."""
     import torch
     torch.set_grad_enabled(False)
+    nms_fn = nms_py if nms_impl == "vector" else nms
     st = stages if stages is not None else {}
     img_t = torch.as_tensor(np.asarray(img, F32))[None]
     H, W = img_t.shape[2:]
@@ -646,7 +650,7 @@ def forward_test(img, Wt, rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposal
     d = rpn_decode(box_head, score_head, H, W, clip_boxes=clip_boxes)
     st["rpn"] = d
     b5 = np.concatenate([d["x1y1x2y2"], d["p"][:, None]], 1)
-    idx = nms(b5, rpn_nms_thresh, None if num_proposals == -1 else num_proposals)
+    idx = nms_fn(b5, rpn_nms_thresh, None if num_proposals == -1 else num_proposals)
     st["rpn_nms_idx"] = idx
     roi_boxes = d["boxes"][idx]
     st["roi_boxes"] = roi_boxes
@@ -667,7 +671,7 @@ def forward_test(img, Wt, rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposal
     st["seq_pre_nms"] = seq
     if final_nms_thresh > 0:
         b5 = np.concatenate([xcycwh_to_x1y1x2y2(final_boxes), obj[:, None]], 1)
-        idx2 = nms(b5, final_nms_thresh, None)
+        idx2 = nms_fn(b5, final_nms_thresh, None)
     else:
         idx2 = np.arange(final_boxes.shape[0])
     st["final_nms_idx"] = idx2

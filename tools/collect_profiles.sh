@@ -10,7 +10,8 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 # one lane = one stream for the profiled images (per-launch events switch the two-stream decode off); the short legs only
-BENCH="python $REPO/bench.py --lanes 1 --group 1 --no-cpu-baseline --no-alt-pass --no-host-input-leg --sustain-seconds 0"
+LEAN="--no-cpu-baseline --no-alt-pass --no-host-input-leg --sustain-seconds 0 --no-settle --no-split-leg --gather torch"
+BENCH="python $REPO/bench.py --lanes 1 --group 1 $LEAN"
 run() {  # name, bench args, rocprof args...
   local name=$1 args=$2; shift 2
   rm -rf /tmp/rp_$name
@@ -24,7 +25,7 @@ run write "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc WRITE_SIZE
 run mfma "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT
 # PROFILE WHAT IS TIMED: one stream (per-kernel counters need non-overlapping kernels) but the MULTI-LANE planning of the
 # headline schedule (--plan-mode 0): conv4_2 / conv4_3 on whole K-split tiles, no stream-K, no tail plans
-BENCH="python $REPO/bench.py --lanes 1 --plan-mode 0 --group 1 --no-cpu-baseline --no-alt-pass --no-host-input-leg --sustain-seconds 0"
+BENCH="python $REPO/bench.py --lanes 1 --plan-mode 0 --group 1 $LEAN"
 run mlplan "--steps 10 --warmup 3 --repeats 1" --kernel-trace --stats
 grep '^{' /tmp/rp_mlplan.json > "$OUT/bench_mlplan.json"
 run mlplan_fetch "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc FETCH_SIZE
@@ -32,9 +33,16 @@ run mlplan_write "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc WRITE_S
 run mlplan_mfma "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT
 # the DEFAULT (multi-lane) schedule -- the one the headline number comes from -- under the kernel trace as well
 # (rocprofv3 serialises dispatches, so the overlap itself is not visible; per-kernel durations and counts are)
-BENCH="python $REPO/bench.py --no-cpu-baseline --no-alt-pass --no-host-input-leg --sustain-seconds 0"
+BENCH="python $REPO/bench.py $LEAN"
 run default "--steps 10 --warmup 3 --repeats 2" --kernel-trace --stats
 grep '^{' /tmp/rp_default.json > "$OUT/bench_default_under_rocprof.json"
+# the opt-in split-bf16 mode (round 5): kernel names + durations, MFMA busy and clock of ITS kernels (one stream, multi-lane planning)
+BENCH="python $REPO/bench.py --lanes 1 --plan-mode 0 --group 1 --math-mode 1 $LEAN"
+run split "--steps 10 --warmup 3 --repeats 1" --kernel-trace --stats
+grep '^{' /tmp/rp_split.json > "$OUT/bench_split_lanes1.json"
+run split_mfma "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT
+run split_fetch "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc FETCH_SIZE
+run split_write "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc WRITE_SIZE
 cd "$REPO"
 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 Q="--no-cpu-baseline --sustain-seconds 2 --repeats 3"
@@ -42,8 +50,13 @@ python bench.py --height 320 --width 480 --proposals 50 --lanes 1 --steps 30 --n
 python bench.py --height 480 --width 720 --proposals 1000 --steps 32 $Q > "$OUT/bench_config0_720x480.json" 2>/dev/null
 python bench.py --proposals 300 --steps 32 $Q > "$OUT/bench_config3_p300.json" 2>/dev/null     # (images per group picked by the untimed trial)
 python bench.py --height 720 --width 1080 --proposals 2000 --steps 12 --warmup 2 $Q > "$OUT/bench_config5.json" 2>/dev/null
+python bench.py --math-mode 1 --steps 32 --no-split-leg $Q > "$OUT/bench_split_bf16_mode.json" 2>/dev/null
 python tools/gemm_bench.py 5 --serial > "$OUT/gemm_bench_serial.txt" 2>/dev/null
 python tools/gemm_bench.py 5 > "$OUT/gemm_bench_multilane.txt" 2>/dev/null
+python tools/gemm_bench.py 5 --math-mode=1 > "$OUT/gemm_bench_split_bf16.txt" 2>/dev/null
+python tools/cli_throughput.py 64 "$OUT/cli_throughput.json" > "$OUT/cli_throughput.log" 2>&1
+./tools/probes/bin/mfma_probe > "$OUT/mfma_bf16_numerics.txt" 2>&1
+python -m pytest tests/test_gpu_bf3.py -m gpu -q -s -k "linear_error or conv3x3_error or zz_print" 2>&1 | grep "split-bf16 error" > "$OUT/split_bf16_error_ratios.txt"
 python tools/decode_bench.py 20 1000 300 50 > "$OUT/decode_bench.txt" 2>/dev/null
 python tools/decode_bench.py 5 1000 50 --beam=5 >> "$OUT/decode_bench.txt" 2>/dev/null
 PARITY_EXTRA=8 python tests/parity_report.py > "$OUT/parity_report.log" 2>&1

@@ -172,6 +172,49 @@ def main():
                 summ[f]["algorithmic_bytes_per_launch"] = tot / n
                 if "avg_hbm_bytes_per_launch" in summ[f]:
                     summ[f]["fabric_over_algorithmic"] = summ[f]["avg_hbm_bytes_per_launch"] / (tot / n)
+    # the opt-in split-bf16 mode (round 5): its own passes (split_*), per kernel family -- names, durations, MFMA busy, clock
+    if os.path.exists(os.path.join(d, "split_kernel_trace.csv")):
+        sp = collections.OrderedDict()
+        for r in csv.DictReader(open(os.path.join(d, "split_kernel_trace.csv"))):
+            e = sp.setdefault(fam(r["Kernel_Name"]), collections.OrderedDict(calls=0, total_us=0.0))
+            e["calls"] += 1
+            e["total_us"] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        for e in sp.values():
+            e["avg_us"] = e["total_us"] / e["calls"]
+        if os.path.exists(os.path.join(d, "split_mfma_counter_collection.csv")):
+            kt2 = trace("split_mfma")
+            acc2 = collections.defaultdict(lambda: collections.defaultdict(float))
+            for r in csv.DictReader(open(os.path.join(d, "split_mfma_counter_collection.csv"))):
+                f = fam(r["Kernel_Name"])
+                acc2[f][r["Counter_Name"]] += float(r["Counter_Value"])
+                if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                    k = kt2[r["Dispatch_Id"]]
+                    acc2[f]["_dur_us"] += (int(k["End_Timestamp"]) - int(k["Start_Timestamp"])) / 1e3
+            for f, c in acc2.items():
+                if f in sp and c.get("GRBM_GUI_ACTIVE", 0) > 0 and c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0:
+                    gui = c["GRBM_GUI_ACTIVE"] / 8.0
+                    sp[f]["mfma_util"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024.0)
+                    sp[f]["clock_ghz"] = gui / c["_dur_us"] / 1e3
+                    sp[f]["valu_insts"] = c.get("SQ_INSTS_VALU", 0.0)
+                    sp[f]["lds_bank_conflict_cycles"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0)
+        for cname, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            fn = os.path.join(d, "split_%s_counter_collection.csv" % cname)
+            if not os.path.exists(fn):
+                continue
+            acc3 = collections.defaultdict(lambda: [0.0, 0])
+            for r in csv.DictReader(open(fn)):
+                if r["Counter_Name"] == key:
+                    a3 = acc3[fam(r["Kernel_Name"])]
+                    a3[0] += float(r["Counter_Value"]); a3[1] += 1
+            for f, (tot, n) in acc3.items():
+                if f in sp:
+                    sp[f]["avg_%s_kb" % cname] = tot / n
+        summ["_split_bf16_mode"] = sp
+        print("_split_bf16_mode (bench.py --lanes 1 --plan-mode 0 --math-mode 1)")
+        for f, e in sp.items():
+            if e["total_us"] > 50:
+                print("  %-52s calls=%4d avg_us=%9.1f %s" % (f[:52], e["calls"], e["avg_us"],
+                      " ".join("%s=%.3g" % (k, v) for k, v in e.items() if k not in ("calls", "total_us", "avg_us"))))
     json.dump(summ, open(prefix + "_pmc_summary.json", "w"), indent=1)
     for key in ("_layers_single_image_plan", "_layers_multi_lane_plan"):
         tab = summ.get(key)
@@ -185,11 +228,13 @@ def main():
             print(key, tab)
     for extra in ("mlplan_kernel_stats.csv", "bench_mlplan.json", "default_kernel_stats.csv", "bench_default_under_rocprof.json", "bench_default.json",
                   "bench_webcam_480_p50.json", "bench_config3_p300.json", "bench_config5.json", "bench_config0_720x480.json",
-                  "gemm_bench_serial.txt", "gemm_bench_multilane.txt", "decode_bench.txt", "parity_report.json"):
+                  "gemm_bench_serial.txt", "gemm_bench_multilane.txt", "decode_bench.txt", "parity_report.json",
+                  "split_kernel_stats.csv", "bench_split_lanes1.json", "bench_split_bf16_mode.json", "gemm_bench_split_bf16.txt",
+                  "cli_throughput.json", "mfma_bf16_numerics.txt", "split_bf16_error_ratios.txt"):
         if os.path.exists(os.path.join(d, extra)):
             shutil.copy(os.path.join(d, extra), prefix + "_" + extra.replace("default_kernel_stats", "kernel_stats_default_lanes"))
     for f, e in summ.items():
-        if isinstance(e, dict) and e["total_us"] > 50:
+        if isinstance(e, dict) and "total_us" in e and e["total_us"] > 50:
             print("%-44s calls=%4d avg_us=%9.1f %s" % (f[:44], e["calls"], e["avg_us"],
                   " ".join("%s=%.3g" % (k, v) for k, v in e.items() if k not in ("calls", "total_us", "avg_us"))))
 
