@@ -40,7 +40,20 @@ __global__ __launch_bounds__(256) void bilinear_roi_pool_kernel(const float* __r
   const int npts = HH * WW;
   // `split` workgroups share a box (each takes a contiguous slice of its (point, channel-chunk) items): with few boxes
   // the kernel is a latency chain of ~25 dependent load rounds per thread, not a bandwidth problem
-  for (int v = blockIdx.x; v < nimg * B * split; v += gridDim.x) {
+  // XCD-aware order for a group: blocks x, x + 8, ... share an XCD and its 4 MiB L2.  With 2, 4 or 8 images every image gets
+  // its own XCDs, so that an L2 holds ONE feature map (3.5 MB at 720x600) instead of streaming all of them (measured with
+  // 4 x 300 boxes: 2.1 TB/s on the interleaved order against 2.9 for a single image's 1000 boxes).
+  const int per_img = B * split;                           // work items of one image
+  int v0 = blockIdx.x, vstride = gridDim.x, v_end = nimg * per_img, img_fixed = -1;
+  if (nimg > 1 && (8 % nimg) == 0 && (gridDim.x & 7) == 0) {
+    const int xpi = 8 / nimg, xcd = blockIdx.x & 7;        // XCDs per image
+    img_fixed = xcd / xpi;
+    v0 = (xcd % xpi) + xpi * (blockIdx.x >> 3);            // index among the blocks that serve this image
+    vstride = xpi * (gridDim.x >> 3);
+    v_end = per_img;
+  }
+  for (int vv = v0; vv < v_end; vv += vstride) {
+    const int v = img_fixed >= 0 ? img_fixed * per_img + vv : vv;
     const int b = v / split, part = v - b * split;         // b: row over all images of the group
     const int img = b / B, bi = b - img * B;
     const int b_live = B_dev ? min(B_dev[(size_t)img * bdev_stride], B) : B;
@@ -135,7 +148,7 @@ hipError_t launch_bilinear_roi_pool_group(const float* feat_hwc, size_t feat_str
   const long Bt = (long)B * nimg;
   long split = (4096 + Bt / 2) / Bt;          // ~4096 workgroups (16 per CU) measured best for 300 .. 2000 boxes
   split = split < 1 ? 1 : (split > 8 ? 8 : split);
-  const long want = Bt * split;
+  const long want = (Bt * split + 7) / 8 * 8;     // a multiple of 8: the XCD-aware order of a group
   const int grid = want < 256 * 16 ? (int)want : 256 * 16;
   hipLaunchKernelGGL(bilinear_roi_pool_kernel, dim3((unsigned)grid), dim3(256), 0, s, feat_hwc, h, w, C, boxes, B, nimg,
                      feat_stride, B_dev, bdev_stride, pick, src_boxes, src_stride, (float)img_h, (float)img_w, HH, WW, out,

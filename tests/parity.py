@@ -16,7 +16,7 @@ rigorous for a pipeline with integer decisions:
       departure of a pick list is accepted only through a FLIP REPLAY (hybrid_nms): the oracle's NMS is run
       again on the oracle's own boxes and scores, and a single decision (an IoU-vs-threshold test, the order
       of two scores) is taken from the HIP path's values only where the oracle's margin for THAT decision is
-      within 10x the discrepancy actually observed between the two paths for the very operands involved.  The
+      within FLIP_K (2) x the discrepancy actually observed between the two paths for the very operands involved.  The
       replay must reproduce the HIP list exactly; the flipped decisions are counted and reported.  A token row
       may differ only where the oracle's own top-2 logit margin at the first differing step is below 2e-5
       relative (10x the fp32 logit noise measured by the GEMM op tests).
@@ -29,7 +29,11 @@ import numpy as np
 
 REL = 1e-4
 TOKEN_TOL = 2e-5        # top-2 logit margin below which a greedy token may legitimately differ (10x the measured logit noise)
-FLIP_K = 10.0           # a decision may flip only if the oracle's margin is within FLIP_K x the observed discrepancy of its operands
+# A decision may flip only if the oracle's margin is within FLIP_K x the discrepancy observed for its operands.  Round 5: the
+# constant follows the data -- every replayed list of profiles/r05_parity_report.json (13 RPN lists and one final list over 15
+# images, up to 2837 flipped decisions in a list) is reproduced at k <= 1.0 (`k_needed`); FLIP_K is twice that.  It was a free
+# constant of 10 before (round-4 verdict).
+FLIP_K = 2.0
 
 
 def oracle_threads():
@@ -146,7 +150,7 @@ def token_divergence_proven(oracle_mod, codes_row, weights, T, hip_row, oracle_r
     return margin < tol, "step %d top-2 margin %.3g" % (t, margin)
 
 
-K_LADDER = (0.0, 0.25, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0, 8.0, 10.0)
+K_LADDER = (0.0, 0.25, 0.5, 1.0, 1.5, 2.0)
 
 
 def k_needed(b5_oracle, b5_hip, thr, max_boxes, want):
