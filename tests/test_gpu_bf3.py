@@ -95,7 +95,12 @@ def test_linear_error_vs_fp64_is_the_fp32_paths(ctx, mnk):
     three = _three_ways(ctx, lambda: ops.linear(ctx, x, w, b))
     f32, bf3 = three[0], three[2]
     _within_the_fp32_paths_error(three, ref, mnk)
-    assert not np.array_equal(f32, bf3) or K <= 32                      # it IS another arithmetic (same bits only by accident)
+    # the mode is taken where ONE problem fills the chip with 128x64 tiles (mfma_gemm_bf3_pays); elsewhere the fp32 route runs
+    pays = 2 * ((M + 127) // 128) * ((N + 63) // 64) >= 3 * 256
+    if pays:
+        assert not np.array_equal(f32, bf3)                             # it IS another arithmetic
+    else:
+        np.testing.assert_array_equal(f32, bf3)                         # few-tile problems keep the fp32 kernels and their bits
     # ReLU and no-bias epilogues
     refr = np.maximum(ref - b, 0)
     _within_the_fp32_paths_error(_three_ways(ctx, lambda: ops.linear(ctx, x, w, None, relu=True)), refr, mnk + ("relu",))
