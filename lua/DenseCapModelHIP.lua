@@ -186,6 +186,24 @@ function Model:setGraphReplay(on)
   hip.check(self.ctx, C.dc_set_graph_replay(self.ctx, on and 1 or 0), 'dc_set_graph_replay')
   return self
 end
+-- arithmetic of the large contractions: 0 = fp32 MFMA (default, the reference's arithmetic), 1 = split-bf16 (opt-in; include/densecap.h)
+function Model:setMathMode(mode)
+  hip.check(self.ctx, C.dc_set_math_mode(self.ctx, mode or 0), 'dc_set_math_mode')
+  return self
+end
+-- run_model.lua:67-74 on the device: `img` = ByteTensor (H0, W0, 3) RGB as a decoder delivers it -> device pointer of the
+-- (3, H, W) float tensor forward_test_device takes, plus H, W.  (image.load + image.scale + BGR, x255, mean; bit-equal to the
+-- library's own C loops.)  The caller frees the pointer with C.dc_free(self.ctx, ptr).
+function Model:preprocess(img_hwc_bytes, image_size)
+  local H0, W0 = img_hwc_bytes:size(1), img_hwc_bytes:size(2)
+  local ph, pw = ffi.new('int[1]'), ffi.new('int[1]')
+  assert(C.dc_preprocess_size(H0, W0, image_size, ph, pw) == 0, 'image.scale leaves no pixels')
+  local pp = ffi.new('void*[1]')
+  hip.check(self.ctx, C.dc_malloc(self.ctx, pp, 3 * ph[0] * pw[0] * 4), 'dc_malloc')
+  hip.check(self.ctx, C.dc_preprocess_u8(self.ctx, img_hwc_bytes:contiguous():data(), H0, W0, 0, image_size,
+                                         ffi.cast('float*', pp[0]), nil), 'dc_preprocess_u8')
+  return pp[0], ph[0], pw[0]
+end
 function Model:convert(dtype, use_cudnn) return self end
 function Model:evaluate() return self end
 function Model:type() return self end
@@ -247,9 +265,11 @@ function Model.commUniqueId()
   hip.check(nil, C.dc_comm_unique_id(id), 'dc_comm_unique_id')
   return ffi.string(id, 128)
 end
-function Model:commInit(id, rank, world)
+-- self_transport (world == 1 only): build the RCCL carrier for the single rank too, so that gatherResults travels through
+-- ncclSend / ncclRecv to itself (DC_COMM_SELF_TRANSPORT) -- the multi-GPU code path on one GPU
+function Model:commInit(id, rank, world, self_transport)
   local pc = ffi.new('dc_comm*[1]')
-  hip.check(self.ctx, C.dc_comm_create(pc, self.ctx, id, rank, world), 'dc_comm_create')
+  hip.check(self.ctx, C.dc_comm_create_ex(pc, self.ctx, id, rank, world, self_transport and 1 or 0), 'dc_comm_create')
   self.comm, self.rank, self.world = ffi.gc(pc[0], C.dc_comm_destroy), rank, world
 end
 -- forward_test without string decoding: returns a dc_result (and the tensors that own its buffers)
