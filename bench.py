@@ -319,6 +319,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # stdout carries ONE line, rank 0's JSON, and it is the LAST line: RCCL prints a version banner through C stdio when a
+    # communicator is made (buffered, so it would surface after the JSON at exit).  Ranks other than 0 send their C-level
+    # stdout to stderr from the start; rank 0 flushes C stdio before the line and closes stdout to C code after it.
+    import ctypes
+    _libc = ctypes.CDLL(None)
+    if rank != 0:
+        sys.stdout.flush(); _libc.fflush(None)
+        os.dup2(2, 1)
     on_gpu = not args.stub
     # ranks may outnumber the visible GPUs only in the gloo configuration (two ranks on GPU 0 in the tests)
     ndev = torch.cuda.device_count() if on_gpu else 0
@@ -471,7 +479,9 @@ def main():
     sched_trials = None
     if args.lanes <= 0 and args.group < 0 and on_gpu:
         # both scheduling knobs together (results are bit-identical for every pair): the best lane count depends on the group size
-        sched_trials = model.autotuneSchedule(imgs, min(n_img, 16), H, W)
+        # (the trial runs regions of exactly K images, the size of a timed region: with few images per region the best pair
+        # depends on how the groups fall on the lanes -- 20 images are five groups of four on two lanes, three against two)
+        sched_trials = model.autotuneSchedule(imgs, min(n_img, K), H, W)
         args.lanes, args.group = max(sched_trials, key=sched_trials.get)
         if dist is not None:
             lt = torch.tensor([args.lanes, args.group], dtype=torch.int32, device=coll_device)
@@ -988,7 +998,9 @@ def main():
                     ident3 += 1 if ok3 else 0
                 out["parity"]["in_run_split_bf16"] = {"images": min(nb, len(split["results"])), "identical_to_oracle": ident3,
                                                       "rule": "same as in_run (a near-tie may legitimately flip: tests/parity.py replays those)"}
+        _libc.fflush(None)                       # whatever C code buffered so far (the RCCL banner) goes out BEFORE the line
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)                            # nothing after it reaches stdout (teardown messages of native libraries)
     if comm is not None:
         comm.close()
     if dist is not None:

@@ -188,15 +188,20 @@ def test_bench_line_has_roofline_and_cpu_baseline():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
+    # the JSON line is the LAST line of stdout: the banner RCCL prints through C stdio (the gather runs over a one-rank RCCL
+    # communicator now) is flushed before it, nothing native reaches stdout after it
+    assert p.stdout.strip().splitlines()[-1] == lines[0], p.stdout[-600:]
     d = json.loads(lines[0])
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "trunk_frac", "fc_frac", "decode_frac",
-              "serial_ms_per_image", "measured_on", "traffic_from_profile"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "frac_serial", "achieved_serial", "traffic", "kernel", "trunk_frac",
+              "fc_frac", "decode_frac", "serial_ms_per_image", "measured_on", "traffic_from_profile"):
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "images/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert d["n_gpus"] == 1 and len(d["repeats"]["images_per_s"]) == 2 and d["value"] > c["value"]
+    assert d["value_split_bf16"] > 0 and d["roofline_split_bf16"]["peak"] > 400 and 0 < d["roofline_split_bf16"]["frac"] < 1
+    assert abs(r["frac"] - r["frac_timed_region"]) < 1e-12 and len(d["warm_up_regions_images_per_s"]) >= 2
     # one GPU, no launcher: the end-of-region gather ran over the one-rank RCCL communicator
     assert d["config"]["gather"] == "dc_gather_results (rccl, self)", d["config"]["gather"]
 
