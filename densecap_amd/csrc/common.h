@@ -57,6 +57,8 @@ struct GemmDesc {
   // arithmetic: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, the default and the only mode results are bit-compared in);
   // 1 = split-bf16 (dc_set_math_mode(1)): both operands split into three bf16 planes in registers, six of the nine partial
   // products accumulated in fp32 on v_mfma_f32_32x32x16_bf16 -- fp32-class accuracy at 2.67x the matrix rate
+  // 2 = the same with the B operand (weights) split ONCE into planes in HBM (launch_split_planes): `sk_slots` then carries the
+  // planes pointer and `sk_np` the rows of the plane matrix (stream-K, whose fields these are, does not exist in this mode)
   int bf3 = 0;                // (sits in what was the alignment hole in front of `rowterm`: no other field moved)
   // optional gathered row term (LSTM input gates): C[m][n] += rowterm[rowidx[m]*rowterm_ld + n]
   const float* rowterm = nullptr;
@@ -170,6 +172,8 @@ hipError_t launch_iota_count(int32_t* idx, int32_t* count_out, const int32_t* co
 hipError_t launch_lstm_step_tail(const float* pval, const int32_t* pidx, int ntiles, int ld, int fixed_tok,
                                  const float* xg, const float* gates_pre, float* c, float* h, int n,
                                  const int32_t* n_dev, int Hd, int zero_c, int32_t* seq, int T, int t, hipStream_t s);
+// split-bf16 mode: W (N, K) fp32 -> 3 x N x K bf16 planes, k permuted per 32-tile as the kernels read them (elementwise.hip)
+hipError_t launch_split_planes(const float* W, uint16_t* planes, size_t N, int K, hipStream_t s);
 // objectness + box regression heads + final ApplyBoxTransform (DenseCapModel.lua:134,139-140)
 // final_xyxy (optional): the final boxes as corners too (box_utils.xcycwh_to_x1y1x2y2), what the final NMS reads
 hipError_t launch_recog_heads(const float* codes, const float* w5 /*(5,D): obj, 4 boxreg*/, const float* b5,

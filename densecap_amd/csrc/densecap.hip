@@ -131,6 +131,10 @@ struct dc_ctx {
   float* dec_w = nullptr;   // (V1pad + 4Hd, Hd): rows [0,V+1) = lm_out_w, zero rows up to V1pad (multiple of 64), then Wh^T
   int V1pad = 0;
   std::vector<std::unique_ptr<Lane>> lanes;
+  // split-bf16 mode: weight matrices that can take it, and their bf16 planes (made when the mode is first switched on)
+  struct PlaneEnt { const float* W; size_t rows; int K; uint16_t* planes; };
+  std::vector<PlaneEnt> planes;
+  int bf3_presplit = 1;             // dc_debug_set "bf3_presplit": 0 = split the weights in registers too (mode 1 of the kernels)
   DevBuf pre_src, pre_scratch;      // dc_preprocess_u8: uploaded bytes, width-pass plane + tap tables (grow only)
   // MFMA profile
   bool prof = false;
@@ -213,6 +217,15 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, const Ws& w = Ws(
   d.walk = ctx->walk;
   d.epi_wide = ctx->epi_wide;
   d.bf3 = ctx->math_mode == 1 && mfma_gemm_bf3_pays(d) ? 1 : 0;
+  if (d.bf3 && ctx->bf3_presplit) {
+    const uint16_t* pp = d_in.sk_slots != nullptr ? reinterpret_cast<const uint16_t*>(d_in.sk_slots) : nullptr;    // a caller's own planes (per-op entry points)
+    int prow = d_in.sk_np;
+    if (pp == nullptr)
+      for (const auto& e : ctx->planes)
+        if (e.W == d.W && e.K == d.K && e.planes != nullptr) { pp = e.planes; prow = (int)e.rows; break; }
+    if (pp != nullptr) { d.bf3 = 2; d.sk_slots = reinterpret_cast<float*>(const_cast<uint16_t*>(pp)); d.sk_np = prow; }
+  }
+  if (d.bf3 != 2) { d.sk_slots = nullptr; d.sk_np = 0; }            // (a caller's planes mean nothing to the other routes)
   ProfEvt pe{nullptr, nullptr, gemm_flops(d)};
   if (ctx->prof) {
     pe.a = prof_event(ctx); pe.b = prof_event(ctx);
@@ -290,15 +303,19 @@ void prof_collect(dc_ctx* ctx) {
   ctx->prof_pending.clear();
 }
 
+// `planes` (optional): the caller's own bf16 planes of W for the split-bf16 mode (per-op entry points; the model's weights
+// are looked up in ctx->planes)
 int linear(dc_ctx* ctx, hipStream_t s, const float* A, const float* W, const float* bias, float* C, int M, int N,
-           int K, int relu, const Ws& ws = Ws(), int plan_M = 0) {
+           int K, int relu, const Ws& ws = Ws(), int plan_M = 0, const uint16_t* planes = nullptr) {
   GemmDesc d;
   d.A = A; d.W = W; d.bias = bias; d.C = C; d.M = M; d.N = N; d.K = K; d.ldc = N; d.relu = relu; d.plan_M = plan_M;
+  d.sk_slots = reinterpret_cast<float*>(const_cast<uint16_t*>(planes)); d.sk_np = planes ? N : 0;
   return run_gemm(ctx, d, s, ws);
 }
 int conv3x3(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, const float* b, float* out, int nimg, int H,
-            int W, int Cin, int Cout, int relu, const Ws& ws = Ws()) {
+            int W, int Cin, int Cout, int relu, const Ws& ws = Ws(), const uint16_t* planes = nullptr) {
   GemmDesc d;
+  d.sk_slots = reinterpret_cast<float*>(const_cast<uint16_t*>(planes)); d.sk_np = planes ? Cout : 0;
   d.A = in; d.W = w; d.bias = b; d.C = out; d.M = nimg * H * W; d.N = Cout; d.K = 9 * Cin; d.ldc = Cout;
   d.relu = relu; d.conv = 1; d.H = H; d.Wd = W; d.Cin = Cin; d.plan_M = H * W;
   return run_gemm(ctx, d, s, ws);
@@ -307,8 +324,9 @@ int conv3x3(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, const f
 // DenseCapModel.lua:61-76): the pool rides in the conv's epilogue -- the full-resolution activation never reaches HBM
 // (conv1_2: 110 MB store -> 28 MB) and four launches disappear.  out: (ceil(H/2), ceil(W/2), Cout).
 int conv3x3_pool(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, const float* b, float* out, int nimg, int H,
-                 int W, int Cin, int Cout, int relu, const Ws& ws) {
+                 int W, int Cin, int Cout, int relu, const Ws& ws, const uint16_t* planes = nullptr) {
   GemmDesc d;
+  d.sk_slots = reinterpret_cast<float*>(const_cast<uint16_t*>(planes)); d.sk_np = planes ? Cout : 0;
   const int slots = 4 * ((H + 1) / 2) * ((W + 1) / 2);          // window slots of one image
   d.A = in; d.W = w; d.bias = b; d.C = out; d.M = nimg * slots; d.N = Cout; d.K = 9 * Cin; d.plan_M = slots;
   d.ldc = Cout; d.relu = relu; d.conv = 1; d.H = H; d.Wd = W; d.Cin = Cin; d.pool = 1;
@@ -737,7 +755,7 @@ std::array<int64_t, 28> graph_key(const dc_ctx* ctx, const Lane& L, int g, bool 
           f2i(ctx->rpn_nms_thresh), f2i(ctx->final_nms_thresh), ctx->num_proposals, ctx->clip_boxes ? 1 : 0,
           ctx->captions_after_final_nms ? 1 : 0, ctx->serial_mode ? 1 : 0, ctx->plan_mode, ctx->tail_mode, ctx->force_cfg,
           ctx->v2_stages, ctx->stagger, ctx->walk + 2 * ctx->epi_wide, ctx->beam_size, (int64_t)(uintptr_t)ctx->fault_dev,
-          (int64_t)(uintptr_t)L.arena.p, (int64_t)(uintptr_t)L.host_stage, (int64_t)(uintptr_t)L.splitk_ws, ctx->math_mode, 0, 0};
+          (int64_t)(uintptr_t)L.arena.p, (int64_t)(uintptr_t)L.host_stage, (int64_t)(uintptr_t)L.splitk_ws, ctx->math_mode + 2 * ctx->bf3_presplit, 0, 0};
 }
 
 // `img`: the g images back to back; `sep` (optional) = g separate images instead (a run of equal-sized images of a mixed list)
@@ -986,10 +1004,25 @@ int dc_set_beam_size(dc_ctx* ctx, int beam_size) {
   return DC_OK;
 }
 
+// the bf16 planes of every registered weight matrix (once; ~0.85 GB next to the 0.7 GB of fp32 weights)
+static int make_weight_planes(dc_ctx* ctx) {
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s;
+  DCCHK(lane0_stream(ctx, &s));
+  for (auto& e : ctx->planes) {
+    if (e.planes != nullptr) continue;
+    DCCHK(dev_alloc(ctx, reinterpret_cast<void**>(&e.planes), (size_t)3 * e.rows * e.K * 2));
+    KCHK(launch_split_planes(e.W, e.planes, e.rows, e.K, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  return DC_OK;
+}
+
 int dc_set_math_mode(dc_ctx* ctx, int mode) {
   if (!ctx) return DC_E_INVALID;
   if (mode != DC_MATH_FP32 && mode != DC_MATH_SPLIT_BF16)
     return ctx->fail(DC_E_INVALID, "dc_set_math_mode: 0 (fp32 MFMA) or 1 (split-bf16), got %d", mode);
+  if (mode == DC_MATH_SPLIT_BF16 && ctx->have_weights) DCCHK(make_weight_planes(ctx));
   ctx->math_mode = mode;
   return DC_OK;
 }
@@ -1112,6 +1145,13 @@ int dc_load_weights(dc_ctx* ctx, const dc_weights* w) {
   DCCHK(upload(ctx, &ctx->anchors, w->anchors, (size_t)2 * k));
   HIPCHK(hipStreamSynchronize(s));
   prof_collect(ctx);
+  // the matrices the split-bf16 mode can take (one image's problem fills the chip): their planes are made when the mode is on
+  for (int i = 1; i < DC_NUM_VGG_CONVS; ++i)
+    ctx->planes.push_back({ctx->conv_w[i], (size_t)kVgg[i].cout, 9 * kVgg[i].cin, nullptr});
+  ctx->planes.push_back({ctx->fc6_w, (size_t)D, 49 * 512, nullptr});
+  ctx->planes.push_back({ctx->fc7_w, (size_t)D, D, nullptr});
+  ctx->planes.push_back({ctx->dec_w, (size_t)ctx->V1pad + 4 * Hd, Hd, nullptr});
+  if (ctx->math_mode == DC_MATH_SPLIT_BF16) DCCHK(make_weight_planes(ctx));
   ctx->have_weights = true;
   ctx->weights_epoch += 1;                 // captured graphs hold the old weight pointers
   if (int rc = check_beam_fits(ctx, ctx->beam_size); rc != DC_OK) {   // dc_set_beam_size came first: validate it now
@@ -1472,6 +1512,11 @@ int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value) {
     ctx->walk = (int)value;
     return DC_OK;
   }
+  if (strcmp(name, "bf3_presplit") == 0) {
+    if (value < 0 || value > 1) return ctx->fail(DC_E_INVALID, "dc_debug_set: bf3_presplit must be 0 or 1");
+    ctx->bf3_presplit = (int)value;
+    return DC_OK;
+  }
   if (strcmp(name, "tail_mode") == 0) {
     if (value < 0 || value > 2) return ctx->fail(DC_E_INVALID, "dc_debug_set: tail_mode must be 0, 1 or 2");
     ctx->tail_mode = (int)value;
@@ -1521,6 +1566,15 @@ static int check_sk_fault(dc_ctx* ctx, const char* who) {
   return ctx->fail(DC_E_HIP, "%s: stream-K partner never published its partial tile within the spin bound", who);
 }
 
+// split-bf16 mode on a per-op call: the caller's weight matrix gets temporary planes (the model's own are made once)
+static int op_planes(dc_ctx* ctx, hipStream_t s, const float* W, int N, int K, uint16_t** out) {
+  *out = nullptr;
+  if (ctx->math_mode != DC_MATH_SPLIT_BF16 || !ctx->bf3_presplit || K % 32) return DC_OK;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(out), (size_t)3 * N * K * 2));
+  KCHK(launch_split_planes(W, *out, (size_t)N, K, s));
+  return DC_OK;
+}
+
 // ---- per-op entry points --------------------------------------------------------------------
 #define OP_PROLOGUE()                         \
   if (!ctx) return DC_E_INVALID;              \
@@ -1548,9 +1602,12 @@ int dc_op_conv3x3(dc_ctx* ctx, const float* in, const float* w, const float* b, 
     return ctx->fail(DC_E_INVALID, "dc_op_conv3x3: need Cin %% 32 == 0 and positive sizes");
   float* ws = nullptr;
   HIPCHK(hipMalloc((void**)&ws, kSplitkWsFloats * 4));
-  int rc = conv3x3(ctx, s, in, w, b, out, n_img, H, W, Cin, Cout, relu, Ws{ws, kSplitkWsFloats});
+  uint16_t* pl = nullptr;
+  if (int rc0 = op_planes(ctx, s, w, Cout, 9 * Cin, &pl); rc0 != DC_OK) { (void)hipFree(ws); return rc0; }
+  int rc = conv3x3(ctx, s, in, w, b, out, n_img, H, W, Cin, Cout, relu, Ws{ws, kSplitkWsFloats}, pl);
   hipError_t e2 = hipStreamSynchronize(s);
   (void)hipFree(ws);
+  if (pl) (void)hipFree(pl);
   prof_collect(ctx);
   if (rc != DC_OK) return rc;
   if (e2 != hipSuccess) return ctx->fail(DC_E_HIP, "dc_op_conv3x3 sync: %s", hipGetErrorString(e2));
@@ -1563,9 +1620,12 @@ int dc_op_conv3x3_relu_pool(dc_ctx* ctx, const float* in, const float* w, const 
     return ctx->fail(DC_E_INVALID, "dc_op_conv3x3_relu_pool: need Cin %% 32 == 0, Cout %% 4 == 0 and positive sizes");
   float* ws = nullptr;
   HIPCHK(hipMalloc((void**)&ws, kSplitkWsFloats * 4));
-  int rc = conv3x3_pool(ctx, s, in, w, b, out, 1, H, W, Cin, Cout, 1, Ws{ws, kSplitkWsFloats});
+  uint16_t* pl = nullptr;
+  if (int rc0 = op_planes(ctx, s, w, Cout, 9 * Cin, &pl); rc0 != DC_OK) { (void)hipFree(ws); return rc0; }
+  int rc = conv3x3_pool(ctx, s, in, w, b, out, 1, H, W, Cin, Cout, 1, Ws{ws, kSplitkWsFloats}, pl);
   hipError_t e2 = hipStreamSynchronize(s);
   (void)hipFree(ws);
+  if (pl) (void)hipFree(pl);
   prof_collect(ctx);
   if (rc != DC_OK) return rc;
   if (e2 != hipSuccess) return ctx->fail(DC_E_HIP, "dc_op_conv3x3_relu_pool sync: %s", hipGetErrorString(e2));
@@ -1587,9 +1647,12 @@ int dc_op_linear(dc_ctx* ctx, const float* A, const float* W, const float* bias,
   if (K % 32 || M <= 0 || N <= 0) return ctx->fail(DC_E_INVALID, "dc_op_linear: need K %% 32 == 0");
   float* ws = nullptr;
   HIPCHK(hipMalloc((void**)&ws, kSplitkWsFloats * 4));
-  int rc = linear(ctx, s, A, W, bias, C, M, N, K, relu, Ws{ws, kSplitkWsFloats});
+  uint16_t* pl = nullptr;
+  if (int rc0 = op_planes(ctx, s, W, N, K, &pl); rc0 != DC_OK) { (void)hipFree(ws); return rc0; }
+  int rc = linear(ctx, s, A, W, bias, C, M, N, K, relu, Ws{ws, kSplitkWsFloats}, 0, pl);
   hipError_t e2 = hipStreamSynchronize(s);
   (void)hipFree(ws);
+  if (pl) (void)hipFree(pl);
   prof_collect(ctx);
   if (rc != DC_OK) return rc;
   if (e2 != hipSuccess) return ctx->fail(DC_E_HIP, "dc_op_linear sync: %s", hipGetErrorString(e2));

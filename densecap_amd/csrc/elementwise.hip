@@ -1,6 +1,8 @@
 // Layout, pooling, conv1_1, LSTM point-wise, arg-max and recognition-head kernels (gfx950).
 // All of these are HBM- or latency-bound byte movers: coalesced 16-byte accesses along the
 // channels-last axis, wavefront (64-lane) reductions, no MFMA.
+#include <algorithm>
+
 #include "common.h"
 
 // every fp32 op rounds once, in source order (integer decisions depend on it)
@@ -508,6 +510,34 @@ hipError_t launch_fill_i32(int32_t* p, int32_t v, int n, hipStream_t s) {
   hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n);
   return hipGetLastError();
 }
+// Weight planes of the split-bf16 mode (mfma_gemm.hip, v2_tile<.., BF3 = 2>): W (N, K) fp32 -> three planes of N x K bf16,
+// x = p0 + p1 + p2 exactly (round to nearest at every level, the same chain as the in-register split), the k of every
+// 32-tile permuted so that 16-byte chunk c = 2s + h holds k = 16s + 4h + {0..3}, 16s + 8 + 4h + {0..3}.
+__global__ void split_planes_kernel(const float* __restrict__ W, uint16_t* __restrict__ P, size_t N, int K) {
+  const size_t total = N * (size_t)K;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = t / K;
+    const int kk = (int)(t - n * K), kt = kk >> 5, o = kk & 31;      // o: position inside the plane's 32-tile
+    const int c = o >> 3, e = o & 7, s_ = c >> 1, h = c & 1;
+    const int kl = 16 * s_ + 4 * h + (e < 4 ? e : 8 + (e - 4));
+    const float x = W[n * K + kt * 32 + kl];
+    const __bf16 p0 = (__bf16)x;
+    const float r1 = x - (float)p0;
+    const __bf16 p1 = (__bf16)r1;
+    const float r2 = r1 - (float)p1;
+    const __bf16 p2 = (__bf16)r2;
+    P[t] = __builtin_bit_cast(uint16_t, p0);
+    P[total + t] = __builtin_bit_cast(uint16_t, p1);
+    P[2 * total + t] = __builtin_bit_cast(uint16_t, p2);
+  }
+}
+hipError_t launch_split_planes(const float* W, uint16_t* planes, size_t N, int K, hipStream_t s) {
+  if (K % 32) return hipErrorInvalidValue;
+  const size_t total = N * (size_t)K;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, s, W, planes, N, K);
+  return hipGetLastError();
+}
+
 hipError_t launch_recog_heads(const float* codes, const float* w5, const float* b5, const float* roi_boxes,
                               float* obj, float* trans, float* final_boxes, float* final_xyxy, int n, int D, hipStream_t s) {
   if (D % 256) return hipErrorInvalidValue;

@@ -170,13 +170,18 @@ __device__ __forceinline__ float pool_window(const GemmDesc& d, int win, float v
 // walk 16 of the block's 32 columns n.  The row arg-max is then a compare chain inside the lane -- no LDS transpose.
 // Each element is the same fp32 fmaf chain over k either way.
 // One output tile [m0, m0+BM) x [n0, n0+BN) (tile_n = n0 / BN indexes the arg-max partials); Meff = rows of the problem.
-template <int TM, int TN, bool CONV, int NS, bool AMAX, bool BF3 = false>
+// BF3: 0 = fp32 MFMA; 1 = split-bf16, both operands split in registers; 2 = split-bf16 with the B operand (weights) split ONCE
+// at load: three bf16 planes in HBM (GemmDesc::sk_slots carries the pointer in this mode), fetched by LDS-DMA as they are
+template <int TM, int TN, bool CONV, int NS, bool AMAX, int BF3 = 0>
 __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const int n0, const int tile_n, const int Meff,
                                         float* const smem) {
   static_assert(!(AMAX && CONV), "arg-max epilogue is for dense GEMMs");
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int PA = BM / 32, PB = BN / 32;
-  constexpr int STAGE = (BM + BN) * BK;  // floats per ring stage
+  // floats per ring stage; BF3 == 2: the B tile is three bf16 planes of BN rows x 32 k (64 bytes a row) instead of fp32 rows
+  constexpr int STAGE = BF3 == 2 ? BM * BK + 3 * BN * (BK / 2) : (BM + BN) * BK;
+  constexpr int PB3 = BF3 == 2 ? (BN / 64 > 0 ? BN / 64 : 1) : 1;     // 64-row passes of a plane: 4 waves x 16 rows x 64 B = one LDS-DMA piece each
+  constexpr int NPIECE = BF3 == 2 ? PA + 3 * PB3 : PA + PB;            // LDS-DMA pieces of a K-tile per wave
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -255,7 +260,28 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
     }
   }
   unsigned b_off[PB];
-  {
+  unsigned b3_off[PB3];
+  unsigned b3_plane = 0;                 // bytes of one plane
+  if constexpr (BF3 == 2) {
+    // Weight planes (split once at load, densecap.hip::weight_planes): plane p = N rows of K bf16, the k of every 32-tile
+    // permuted so that 16-byte chunk 2s+h holds k = 16s + 4h + {0..3}, 16s + 8 + 4h + {0..3} -- the k a lane half h meets
+    // in step s on the A side.  LDS rows are 64 bytes; chunk c of row r sits at slot c ^ ((r >> 2) & 3) (conflict-free
+    // ds_read_b128 over the instruction's 16-lane groups), the swizzle applied here on the SOURCE chunk a lane fetches.
+    const size_t prow = d.sk_np > 0 ? d.sk_np : d.N;          // rows of the plane matrix (>= N: the decode's last step uses a row prefix)
+    const size_t bytes = (size_t)3 * prow * d.K * 2;
+    rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)d.sk_slots, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : bytes), 0x00020000);
+    b3_plane = (unsigned)(prow * d.K * 2);
+#pragma unroll
+    for (int j = 0; j < PB3; ++j) {
+      const int row = 64 * j + 16 * wid + (lane >> 2);
+      int grow = n0 + row;
+      if (grow >= d.N) grow = d.N - 1;
+      const int c = (lane & 3) ^ ((row >> 2) & 3);
+      b3_off[j] = (unsigned)grow * (unsigned)d.K * 2u + (unsigned)c * 16u;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) b_off[i] = 0;
+  } else {
     const float* baseB = d.W + (size_t)n0 * d.K;
     const size_t bytes = (size_t)(d.N - n0) * d.K * 4;
     rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)baseB, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : bytes), 0x00020000);
@@ -265,6 +291,8 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
       if (n0 + rr >= d.N) rr = d.N - 1 - n0;
       b_off[i] = (unsigned)rr * (unsigned)d.K * 4u + (unsigned)lchunk * 16u;
     }
+#pragma unroll
+    for (int j = 0; j < PB3; ++j) b3_off[j] = 0;
   }
 
   int tap = 0, c0 = 0;  // conv K-walk
@@ -307,6 +335,10 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
       } else {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, sa + p * 32 * BK, 16, (int)a_off[p], kt * (BK * 4), 0, 0);
       }
+    } else if constexpr (BF3 == 2) {
+      const int q = p - PA, plane = q / PB3, j = q - plane * PB3;     // this wave's 16 rows of pass j of one plane
+      float* dst = smem + st * STAGE + BM * BK + plane * (BN * (BK / 2)) + (64 * j + 16 * wid) * (BK / 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, dst, 16, (int)b3_off[j], kt * (BK * 2) + plane * (int)b3_plane, 0, 0);
     } else {
       const int i = p - PA;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, sb + i * 32 * BK, 16, (int)b_off[i], kt * (BK * 4), 0, 0);
@@ -315,7 +347,7 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
   auto issue = [&](int kt, int st) {
     issue_begin();
 #pragma unroll
-    for (int p = 0; p < PA + PB; ++p) issue_piece(kt, st, p);
+    for (int p = 0; p < NPIECE; ++p) issue_piece(kt, st, p);
   };
 
   // ---- fragment addressing --------------------------------------------------------------------
@@ -498,9 +530,11 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
     // tile on: at the rendezvous of tile kt (middle of its step 0) tile kt+1 must have landed and tile kt+NS is requested
     // into stage kt % NS -- NS - 1 tiles of lead.
     constexpr int NMF = 6 * TM * TN;        // MFMAs of a step
-    constexpr int NCV = 4 * (TM + TN);      // pair conversions of a step (4 per 32-row block)
-    constexpr int NRD = 2 * (TM + TN);      // fragment reads of a step (2 chunks per block)
-    constexpr int NDM = PA + PB;            // LDS-DMA pieces of a K-tile
+    constexpr int NSPL = BF3 == 2 ? TM : TM + TN;   // blocks split in the loop (BF3 == 2: the weights arrive split)
+    constexpr int NCV = 4 * NSPL;           // pair conversions of a step (4 per 32-row block)
+    constexpr int NRD = 2 * NSPL;           // fp32 fragment reads of a step (2 chunks per block)
+    constexpr int NBR = BF3 == 2 ? 3 * TN : 0;      // plane reads of a step (BF3 == 2: three 16-byte operands per B block)
+    constexpr int NDM = NPIECE;             // LDS-DMA pieces of a K-tile
     // TWO accumulators per 32x32 block: `acc` takes the leading products a0.b0 only, `lo` the five lower-order ones, and the
     // two meet once, after the K loop.  The bf16 MFMA aligns its sixteen products to the largest exponent among them and C and
     // keeps three guard bits (tools/probes/mfma_bf16_numerics.hip: sixteen products of 1/16 ulp(C) vanish, of 1/8 ulp add up):
@@ -535,6 +569,12 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
 #endif
       split3_pair(raw[p][i >> 1][2 * (i & 1)], raw[p][i >> 1][2 * (i & 1) + 1], pl[set][p], i);
     };
+    auto read_b3 = [&](int st, int s, int set, int k) {   // BF3 == 2; k in [0, NBR): B block k / 3, plane k % 3 -> straight into the operand
+      const int j = k / 3, pp = k - 3 * j;
+      const float* src = smem + st * STAGE + BM * BK + pp * (BN * (BK / 2)) + (wn * 32 * TN + j * 32 + r) * (BK / 2) +
+                         (((2 * s + hsel) ^ ((r >> 2) & 3)) << 2);
+      pl[set][TM + j].p[pp] = *reinterpret_cast<const u32x4*>(src);
+    };
     auto mfma3 = [&](int set, int q) {                    // q in [0, NMF): product q / (TM TN) of block q % (TM TN)
       constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};      // a2b0 a0b2 a1b1 a1b0 a0b1 -> lo;  a0b0 -> acc
       const int e = q / (TM * TN), rem = q % (TM * TN), i = rem / TN, j = rem % TN;
@@ -547,13 +587,18 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
     // LDS-DMA piece behind each.  The order is the program's: memory operations and the pinned splits keep it.
     constexpr int QA = (2 * NMF) / 3;                     // MFMAs that cover the conversions
     static_assert(NMF - QA >= 2, "part 2 needs MFMAs");
-    auto region1 = [&](int set, int cset) {
+    // (BF3 == 2: the plane reads of the NEXT step's B operands -- ring stage st_b, step s_b -- go first, the splits of its A
+    // fragments behind them)
+    auto region1 = [&](int set, int cset, int st_b, int s_b) {
 #pragma unroll
       for (int q = 0; q < QA; ++q) {
         mfma3(set, q);
 #pragma unroll
-        for (int k = 0; k < NCV; ++k)
-          if ((k * QA) / NCV == q) convert(cset, k);
+        for (int k = 0; k < NBR + NCV; ++k)
+          if ((k * QA) / (NBR + NCV) == q) {
+            if (k < NBR) read_b3(st_b, s_b, cset, k);
+            else convert(cset, k - NBR);
+          }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -579,6 +624,8 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
 #pragma unroll
     for (int k = 0; k < NCV; ++k) convert(0, k);
 #pragma unroll
+    for (int k = 0; k < NBR; ++k) read_b3(0, 0, 0, k);
+#pragma unroll
     for (int k = 0; k < NRD; ++k) read_raw(0, 1, k);
     __builtin_amdgcn_sched_barrier(0);
     auto body3 = [&](int kt, auto ST) __attribute__((always_inline)) {
@@ -589,7 +636,8 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
       // compiler merges such same-condition blocks across the MFMAs between them -- the interleave is gone.)
       const bool more = kt + NS < nkt;                  // tile kt+NS exists (requested into this tile's stage)
       // step 0: planes[0]; raw holds (kt, step 1) -> planes[1]; rendezvous; raw <- (kt+1, step 0); first half of the LDS-DMA pieces
-      region1(0, 1);
+      region1(0, 1, st, 1);
+      if constexpr (BF3 == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the plane reads just issued still target this ring
 #ifndef BF3_ABL_NO_BARRIER
       if (kt + NS - 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NDM) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -599,7 +647,7 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
       if (more) issue_begin();
       region2(0, st1, 0, more, kt + NS, st, 0, NDM / 2);
       // step 1: planes[1]; raw holds (kt+1, step 0) -> planes[0]; raw <- (kt+1, step 1); the other LDS-DMA pieces
-      region1(1, 0);
+      region1(1, 0, st1, 0);
       region2(1, st1, 1, more, kt + NS, st, NDM / 2, NDM - NDM / 2);
     };
     auto ring3 = [&](int kt, bool guarded) __attribute__((always_inline)) {
@@ -870,7 +918,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
 }
 
-template <int TM, int TN, bool CONV, int NS, bool AMAX = false, bool BF3 = false>
+template <int TM, int TN, bool CONV, int NS, bool AMAX = false, int BF3 = 0>
 __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   start_stagger(d);
@@ -895,7 +943,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
 // are 128x64 and each leftover tile is cut into two 64x64 tiles on the SAME launch -- twice the workgroups at half the
 // duration in the ragged round.  An element's K order does not depend on the tile it falls in (same fragment/lane walk
 // for every v2 shape), so results are bit-identical to the plain launch.
-template <bool CONV, int NS, bool AMAX, bool BF3 = false>
+template <bool CONV, int NS, bool AMAX, int BF3 = 0>
 __global__ __launch_bounds__(256) void mfma_gemm_v2_mixed_kernel(GemmDesc d, int ntm, int ntn, int m_fastest, int nbig,
                                                                  int nwalk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -935,7 +983,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_mixed_kernel(GemmDesc d, int
 // The two accumulator sets of that mode (128 registers) put the wave at ~264 registers; two waves per SIMD need 256, which the
 // compiler reaches by parking the im2col bookkeeping that is touched once per tap (a handful of spills outside the K-tile
 // body).  Worth it: one wave's split (vector unit) runs under the other wave's MFMAs.
-template <bool CONV>
+template <bool CONV, int BF3>
 __global__ __launch_bounds__(256, 2) void mfma_gemm_bf3_128_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = xcd_remap(blockIdx.x, ntm * ntn);
@@ -949,7 +997,7 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_bf3_128_kernel(GemmDesc d, i
     if (me < Meff) Meff = me;
     if (m0 >= Meff) return;
   }
-  v2_tile<2, 2, CONV, 2, false, true>(d, m0, tile_n * 128, tile_n, Meff, smem);
+  v2_tile<2, 2, CONV, 2, false, BF3>(d, m0, tile_n * 128, tile_n, Meff, smem);
 }
 
 // =========================================================================================
@@ -1404,32 +1452,77 @@ inline int v2_pick_stages(int total, int cus) {
   return 2 * total >= 5 * cus && v2_cost_units(total, 2, cus) < v2_cost_units(total, 3, cus) ? 2 : 3;
 }
 
-template <bool CONV, bool AMAX, bool BF3 = false>
+template <bool CONV, bool AMAX, int BF3 = 0>
 hipError_t launch_mixed(const GemmDesc& d, hipStream_t stream, int ntm, int ntn, int m_fastest, size_t lds) {
   // Ring depth: two stages (48 KiB) put three workgroups on a CU instead of two (72 KiB), which hides more of each tile's
   // prologue / epilogue behind its neighbours' K loops -- measured +5% on conv1_2, conv2_1 and the vocabulary projection --
   // but only once there are (nearly) three tiles for every CU: at equal co-residency the deeper ring wins (300-row
   // decode: 495 tiles, 0.87 vs 0.78 ms), so the three-stage ring keeps those launches.
+  // (BF3 == 2: a stage holds the weight tile as three bf16 planes, 28 KiB for 128x64 -- three stages would leave ONE workgroup
+  // per CU: always two stages there; `lds` is then the two-stage size.)
   const int total = ntm * ntn, cus = device_cu_count();
-  const int stages = d.stages == 2 || d.stages == 3 ? d.stages : v2_pick_stages(total, cus);
-  const int wg_per_cu = stages == 2 ? 3 : 2;
+  const int stages = BF3 == 2 ? 2 : (d.stages == 2 || d.stages == 3 ? d.stages : v2_pick_stages(total, cus));
+  const int wg_per_cu = BF3 == 2 ? 2 : (stages == 2 ? 3 : 2);
   const int slots = wg_per_cu * cus;
   int nbig = total / slots * slots, tail = total - nbig;
   if (!v2_split_tail(nbig / slots, tail, slots)) { nbig = total; tail = 0; }     // no ragged round worth splitting
   const int nwalk = d.walk > 0 && nbig > slots ? slots : nbig;     // measurement hook: one workgroup per slot walks its tiles
   if (stages == 2) {
-    const size_t lds2 = lds / 3 * 2;
+    const size_t lds2 = BF3 == 2 ? lds : lds / 3 * 2;
     const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_mixed_kernel<CONV, 2, AMAX, BF3>);
     if (hipError_t e = ensure_dyn_lds(fn, lds2); e != hipSuccess) return e;
     hipLaunchKernelGGL((mfma_gemm_v2_mixed_kernel<CONV, 2, AMAX, BF3>), dim3(nwalk + 2 * tail), dim3(256), lds2, stream, d, ntm, ntn,
                        m_fastest, nbig, nwalk);
     return hipGetLastError();
   }
-  const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX, BF3>);
-  if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL((mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX, BF3>), dim3(nwalk + 2 * tail), dim3(256), lds, stream, d, ntm, ntn,
-                     m_fastest, nbig, nwalk);
-  return hipGetLastError();
+  if constexpr (BF3 != 2) {
+    const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX, BF3>);
+    if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL((mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX, BF3>), dim3(nwalk + 2 * tail), dim3(256), lds, stream, d, ntm, ntn,
+                       m_fastest, nbig, nwalk);
+    return hipGetLastError();
+  }
+  return hipErrorInvalidValue;
+}
+
+// Split-bf16 launches (GemmDesc::bf3): BF3V = 1 both operands split in registers, 2 = weight planes from HBM
+template <int TM, int TN, bool CONV, int BF3V>
+hipError_t launch_bf3(const GemmDesc& d, hipStream_t stream, int ntm, int ntn, int m_fastest) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr size_t stage = BF3V == 2 ? ((size_t)BM * BK + 3 * (size_t)BN * (BK / 2)) * sizeof(float) : (size_t)(BM + BN) * BK * sizeof(float);
+  if constexpr (TM == 2 && TN == 2) {
+    // 128x128 tiles on a two-stage ring (64 / 80 KiB of LDS): two workgroups per CU -- the split's vector work of one wave runs
+    // under the MFMAs of the other
+    if (d.amax_val != nullptr) return hipErrorInvalidValue;
+    const void* fn = reinterpret_cast<const void*>(&mfma_gemm_bf3_128_kernel<CONV, BF3V>);
+    if (hipError_t e = ensure_dyn_lds(fn, 2 * stage); e != hipSuccess) return e;
+    hipLaunchKernelGGL((mfma_gemm_bf3_128_kernel<CONV, BF3V>), dim3(ntm * ntn), dim3(256), 2 * stage, stream, d, ntm, ntn, m_fastest);
+    return hipGetLastError();
+  } else {
+    const size_t lds = (BF3V == 2 && TM == 2 ? 2 : 3) * stage;
+    if (d.amax_val != nullptr) {
+      if constexpr (!CONV) {
+        if (d.amax_cols % BN != 0 || (d.amax_cols > 0 && (d.C == nullptr || d.amax_n > d.amax_cols || d.amax_cols > d.N)))
+          return hipErrorInvalidValue;
+        if constexpr (TM == 2) return launch_mixed<false, true, BF3V>(d, stream, ntm, ntn, m_fastest, lds);
+        else {
+          const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<1, 1, false, 3, true, BF3V>);
+          if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
+          hipLaunchKernelGGL((mfma_gemm_v2_kernel<1, 1, false, 3, true, BF3V>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn, m_fastest);
+          return hipGetLastError();
+        }
+      } else {
+        return hipErrorInvalidValue;
+      }
+    }
+    if constexpr (TM == 2) return launch_mixed<CONV, false, BF3V>(d, stream, ntm, ntn, m_fastest, lds);
+    else {
+      const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<1, 1, CONV, 3, false, BF3V>);
+      if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
+      hipLaunchKernelGGL((mfma_gemm_v2_kernel<1, 1, CONV, 3, false, BF3V>), dim3(ntm * ntn), dim3(256), lds, stream, d, ntm, ntn, m_fastest);
+      return hipGetLastError();
+    }
+  }
 }
 
 bool cfg128_uses_ks(const GemmDesc& d);
@@ -1445,40 +1538,9 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t stream) {
   if (d.bf3) {
     // ---- split-bf16 arithmetic (opt-in): the 2x2-wave kernels only, plain launches only (no K sharing between workgroups)
     if (d.splitk > 1 || d.m_begin != 0 || d.a_rows != 0) return hipErrorInvalidValue;
-    if constexpr (TM == 2 && TN == 2) {
-      // 128x128 tiles on a two-stage ring: 64 KiB of LDS, two workgroups per CU -- the split's vector work of one wave runs
-      // under the MFMAs of the other
-      if (d.amax_val != nullptr) return hipErrorInvalidValue;
-      const size_t lds2 = (size_t)2 * (BM + BN) * BK * sizeof(float);
-      const void* fn = reinterpret_cast<const void*>(&mfma_gemm_bf3_128_kernel<CONV>);
-      if (hipError_t e = ensure_dyn_lds(fn, lds2); e != hipSuccess) return e;
-      hipLaunchKernelGGL((mfma_gemm_bf3_128_kernel<CONV>), dim3(ntm * ntn), dim3(256), lds2, stream, d, ntm, ntn, m_fastest);
-      return hipGetLastError();
-    } else {
-      const size_t lds3 = (size_t)3 * (BM + BN) * BK * sizeof(float);
-      if (d.amax_val != nullptr) {
-        if constexpr (!CONV) {
-          if (d.amax_cols % BN != 0 || (d.amax_cols > 0 && (d.C == nullptr || d.amax_n > d.amax_cols || d.amax_cols > d.N)))
-            return hipErrorInvalidValue;
-          if constexpr (TM == 2) return launch_mixed<false, true, true>(d, stream, ntm, ntn, m_fastest, lds3);
-          else {
-            const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<1, 1, false, 3, true, true>);
-            if (hipError_t e = ensure_dyn_lds(fn, lds3); e != hipSuccess) return e;
-            hipLaunchKernelGGL((mfma_gemm_v2_kernel<1, 1, false, 3, true, true>), dim3(ntm * ntn), dim3(256), lds3, stream, d, ntm, ntn, m_fastest);
-            return hipGetLastError();
-          }
-        } else {
-          return hipErrorInvalidValue;
-        }
-      }
-      if constexpr (TM == 2) return launch_mixed<CONV, false, true>(d, stream, ntm, ntn, m_fastest, lds3);
-      else {
-        const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_kernel<1, 1, CONV, 3, false, true>);
-        if (hipError_t e = ensure_dyn_lds(fn, lds3); e != hipSuccess) return e;
-        hipLaunchKernelGGL((mfma_gemm_v2_kernel<1, 1, CONV, 3, false, true>), dim3(ntm * ntn), dim3(256), lds3, stream, d, ntm, ntn, m_fastest);
-        return hipGetLastError();
-      }
-    }
+    // mode 2 (weights split once at load) needs the planes and 32-bit offsets over all three of them
+    const bool planes = d.bf3 == 2 && d.sk_slots != nullptr && (size_t)3 * (d.sk_np > 0 ? d.sk_np : d.N) * d.K * 2 < 0xfffffff0ull;
+    return planes ? launch_bf3<TM, TN, CONV, 2>(d, stream, ntm, ntn, m_fastest) : launch_bf3<TM, TN, CONV, 1>(d, stream, ntm, ntn, m_fastest);
   }
   if constexpr (TM == 2 && TN == 2) {
     if (d.amax_val != nullptr) return hipErrorInvalidValue;    // the arg-max epilogue lives in the 64-column v2 variant

@@ -120,6 +120,42 @@ def test_conv3x3_error_vs_fp64_is_the_fp32_paths(ctx, shape):
     _within_the_fp32_paths_error(_three_ways(ctx, lambda: ops.conv3x3(ctx, x.numpy(), w.numpy(), b.numpy(), relu=True)), ref, shape)
 
 
+def test_weights_split_at_load_equal_the_in_register_split_bit_for_bit(ctx):
+    """Two kernels of the mode: the weights' three bf16 planes made ONCE (launch_split_planes; the default) and fetched by
+    LDS-DMA as they are, or split in registers like the activations (dc_debug_set bf3_presplit = 0).  Same split values, same
+    products, same accumulation order: identical bits -- which also pins the planes' k permutation and LDS swizzle against the
+    fragment order of the A side.  Shapes cover the 128x128, 128x64 (incl. its 64x64 tail) and 64x64 tiles, ragged N, convs."""
+    import torch
+    from densecap_amd import ops
+    from densecap_amd._lib import check
+    rng = np.random.default_rng(8)
+
+    def both(fn):
+        ctx.set_math_mode(1)
+        try:
+            check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"bf3_presplit", 1), "dc_debug_set")
+            a = fn()
+            check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"bf3_presplit", 0), "dc_debug_set")
+            b = fn()
+        finally:
+            check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"bf3_presplit", 1), "dc_debug_set")
+            ctx.set_math_mode(0)
+        return a, b
+    for M, N, K in ((4096, 4096, 512), (1000, 4096, 1024), (3000, 1000, 96), (1000, 10498, 512), (20000, 64, 64), (700, 4100, 160)):
+        x = rng.standard_normal((M, K)).astype(np.float32)
+        w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        a, b = both(lambda: ops.linear(ctx, x, w, bias, relu=True))
+        np.testing.assert_array_equal(a, b, err_msg=str((M, N, K)))
+    g = torch.Generator().manual_seed(4)
+    for N_, Cin, H, W, Cout in ((1, 64, 150, 180, 128), (1, 128, 75, 90, 256), (2, 256, 75, 90, 512), (1, 64, 300, 360, 64)):
+        x = torch.randn(N_, Cin, H, W, generator=g).numpy()
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).numpy()
+        bias = torch.randn(Cout, generator=g).numpy()
+        a, b = both(lambda: ops.conv3x3(ctx, x, w, bias, relu=True))
+        np.testing.assert_array_equal(a, b, err_msg=str((N_, Cin, H, W, Cout)))
+
+
 def test_operands_that_need_all_three_planes(ctx):
     """Values whose 24 significand bits are all set (x = 1 - 2^-24 scaled by random powers of two and signs): dropping the
     third plane of either operand would leave an error of 2^-17 relative -- 100x the bound asserted here."""

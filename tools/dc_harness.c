@@ -127,6 +127,51 @@ int main(int argc, char** argv) {
   }
   printf("image %dx%d  num_proposals %d  ->  K=%d T=%d  first box (%.2f, %.2f, %.2f, %.2f) score %.4f  %.3f ms/image\n",
          W, H, P, K, T, res[0].boxes[0], res[0].boxes[1], res[0].boxes[2], res[0].boxes[3], res[0].scores[0], ms);
+
+  /* ---- round 5 entry points, from plain C -------------------------------------------------------------------------- */
+  /* (a) run_model.lua:67-74 on the device: decoder bytes in, the device tensor forward_test takes out */
+  {
+    const int H0 = 2 * H + 3, W0 = 2 * W + 1;                       /* a "photograph" that has to shrink */
+    uint8_t* rgb = (uint8_t*)malloc((size_t)H0 * W0 * 3);
+    for (size_t i = 0; i < (size_t)H0 * W0 * 3; ++i) rgb[i] = (uint8_t)(urand() * 256.0f);
+    int Hs = 0, Ws = 0;
+    const int size = W0 > H0 ? W : H;                               /* longer side -> the network size used above */
+    CHECK(dc_preprocess_size(H0, W0, size, &Hs, &Ws));
+    void* dev = NULL;
+    CHECK(dc_malloc(ctx, &dev, (size_t)3 * Hs * Ws * sizeof(float)));
+    CHECK(dc_preprocess_u8(ctx, rgb, H0, W0, 0, size, (float*)dev, NULL));
+    CHECK(dc_forward_test(ctx, (const float*)dev, Hs, Ws, 1, &res[1]));
+    printf("dc_preprocess_u8: %dx%d bytes -> %dx%d device tensor -> K=%d\n", W0, H0, Ws, Hs, res[1].K);
+    CHECK(dc_free(ctx, dev));
+    free(rgb);
+  }
+  /* (b) the opt-in split-bf16 arithmetic: another arithmetic (bits may differ), the same protocol; mode 0 restores the bits */
+  {
+    CHECK(dc_set_math_mode(ctx, DC_MATH_SPLIT_BF16));
+    CHECK(dc_forward_test(ctx, img, H, W, 0, &res[1]));
+    const int Ks = res[1].K;
+    CHECK(dc_set_math_mode(ctx, DC_MATH_FP32));
+    CHECK(dc_forward_test(ctx, img, H, W, 0, &res[1]));
+    if (res[1].K != K || memcmp(res[0].boxes, res[1].boxes, (size_t)K * 16)) { fprintf(stderr, "fp32 bits did not come back\n"); return 1; }
+    if (dc_set_math_mode(ctx, 7) == DC_OK) { fprintf(stderr, "a bad math mode was accepted\n"); return 1; }
+    printf("dc_set_math_mode(1): K=%d (fp32: %d)\n", Ks, K);
+  }
+  /* (c) the multi-GPU gather on one GPU: a one-rank RCCL communicator, the block travels through ncclSend / ncclRecv to self */
+  {
+    dc_comm* comm = NULL;
+    if (dc_comm_create_ex(&comm, ctx, NULL, 0, 1, DC_COMM_SELF_TRANSPORT) != DC_OK) {
+      fprintf(stderr, "dc_comm_create_ex: %s\n", dc_comm_last_error(NULL));
+      return 1;
+    }
+    dc_result g = res[1];
+    g.boxes = (float*)malloc((size_t)P * 16); g.scores = (float*)malloc((size_t)P * 4); g.tokens = (int32_t*)malloc((size_t)P * T * 4);
+    g.K = -1;
+    if (dc_gather_results(comm, &res[0], 1, &g) != DC_OK) { fprintf(stderr, "dc_gather_results: %s\n", dc_comm_last_error(comm)); return 1; }
+    if (g.K != K || memcmp(g.boxes, res[0].boxes, (size_t)K * 16) || memcmp(g.scores, res[0].scores, (size_t)K * 4) ||
+        memcmp(g.tokens, res[0].tokens, (size_t)K * T * 4)) { fprintf(stderr, "gathered record differs\n"); return 1; }
+    printf("dc_gather_results over \"%s\": record intact\n", dc_comm_transport(comm));
+    dc_comm_destroy(comm);
+  }
   dc_destroy(ctx);
   printf("HARNESS OK\n");
   return 0;
