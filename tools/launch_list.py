@@ -42,10 +42,10 @@ def family(p, conv, amax):
     if p["route"] == "ks":
         return ["mfma_gemm_ks_kernel<%s>" % c]
     if p["route"] == "v2_128x64":
-        return ["mfma_gemm_v2_mixed_kernel<%s, %d, %s, false>" % (c, p["stages"], a)]      # (last argument: BF3 = false, the fp32 arithmetic)
+        return ["mfma_gemm_v2_mixed_kernel<%s, %d, %s, 0>" % (c, p["stages"], a)]      # (last argument: BF3 = 0, the fp32 arithmetic)
     if p["route"] == "v2_128x128":
-        return ["mfma_gemm_v2_kernel<2, 2, %s, 3, false, false>" % c]
-    return ["mfma_gemm_v2_kernel<1, 1, %s, 3, %s, false>" % (c, a)]
+        return ["mfma_gemm_v2_kernel<2, 2, %s, 3, false, 0>" % c]
+    return ["mfma_gemm_v2_kernel<1, 1, %s, 3, %s, 0>" % (c, a)]
 
 
 def launches(H=600, W=720, P=1000, T=15, V=10497, serial=0, k=12, R=256, D=4096, E=512, Hd=512):
