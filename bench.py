@@ -477,6 +477,7 @@ def main():
     # ---- setup (not a step): lane workspaces, lane-count trial, warm-up incl. the collective ------------------
     lane_trials = None
     sched_trials = None
+    group_fixed = args.group >= 0                            # --group given: the split-bf16 leg keeps it too
     if args.lanes <= 0 and args.group < 0 and on_gpu:
         # both scheduling knobs together (results are bit-identical for every pair): the best lane count depends on the group size
         # (the trial runs regions of exactly K images, the size of a timed region: with few images per region the best pair
@@ -679,6 +680,20 @@ def main():
         model.setMathMode(1)
         model.forward_batch_device(imgs, K, H, W)            # warm (and clocks settle to this mode's power draw)
         sync()
+        # images per group re-picked for this mode (its dense launches are shorter: the fp32 pick is not its best), untimed
+        split_group, split_group_trial = args.group, None
+        if args.lanes != 1 and not group_fixed:
+            split_group_trial = {}
+            for g in (1, 2, 4):
+                model.setGroup(g)
+                model.forward_batch_device(imgs, K, H, W)
+                sync()
+                g0 = time.perf_counter()
+                model.forward_batch_device(imgs, K, H, W)
+                sync()
+                split_group_trial[g] = K / (time.perf_counter() - g0)
+            split_group = max(split_group_trial, key=split_group_trial.get)
+            model.setGroup(split_group)
         rates, split_results = [], None
         for _ in range(3):
             sync()
@@ -687,7 +702,9 @@ def main():
             sync()
             rates.append(K / (time.perf_counter() - s0))
         model.setMathMode(0)
-        split = {"images_per_s": sorted(rates)[1], "regions": rates, "results": split_results}
+        model.setGroup(args.group)
+        split = {"images_per_s": sorted(rates)[1], "regions": rates, "results": split_results, "group": split_group,
+                 "group_trial": split_group_trial}
     serial_pass = False
     stage_live, single_image_latency_ms, stage_group = None, None, None
     nprof = K * nrep
@@ -888,13 +905,15 @@ def main():
                 out["roofline_split_bf16"] = {
                     "bound": "mfma", "unit": "TFLOP/s (fp32-equivalent)", "achieved": sp_tf, "peak": BF16_MFMA_PEAK_TFLOPS / 6.0,
                     "frac": sp_tf / (BF16_MFMA_PEAK_TFLOPS / 6.0), "vs_value": split["images_per_s"] / burst,
-                    "regions_images_per_s": split["regions"],
+                    "regions_images_per_s": split["regions"], "group": split["group"],
+                    "group_trial_images_per_s": split["group_trial"],
                     "kernel": "mfma_gemm_bf3_128_kernel / mfma_gemm_v2[_mixed]_kernel<.., BF3>: v_mfma_f32_32x32x16_bf16, six bf16 "
-                              "products per fp32 multiply-add (operands split into three bf16 planes in registers)",
+                              "products per fp32 multiply-add (weights as three bf16 planes made at load, activations split "
+                              "into three planes in registers)",
                     "note": "OPT-IN mode (dc_set_math_mode(1)), not the headline: `value`, `dtype` and `roofline` above are pure "
                             "fp32 MFMA.  fp32-equivalent = the same algorithmic FLOPs as `roofline`; peak = dense bf16 MFMA peak / 6. "
                             "Few-tile contractions stay on the fp32 route in this mode (counted at the same FLOPs).  Under this "
-                            "load the board sustains ~1.55-1.75 GHz, not 2.4 (profiles/r05_split_bf16.md)"}
+                            "load the board sustains ~1.55-1.8 GHz, not 2.4, and boxes differ by ~5 % (profiles/r05_split_bf16.md)"}
             out["stage_ms_serial_image"] = stage
         if on_gpu and world == 1 and not args.no_cpu_baseline:
             # the restated reference CPU path (oracle) on a bounded sample of the same workload
