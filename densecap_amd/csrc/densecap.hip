@@ -135,6 +135,8 @@ struct dc_ctx {
   struct PlaneEnt { const float* W; size_t rows; int K; uint16_t* planes; };
   std::vector<PlaneEnt> planes;
   int bf3_presplit = 1;             // dc_debug_set "bf3_presplit": 0 = split the weights in registers too (mode 1 of the kernels)
+  int bf3_all = 0;                  // dc_debug_set "bf3_all": 1 = math mode 1 takes EVERY contraction, not only those mfma_gemm_bf3_pays
+                                    // names (test hook: small and ragged problems then exercise the split-bf16 kernels)
   DevBuf pre_src, pre_scratch;      // dc_preprocess_u8: uploaded bytes, width-pass plane + tap tables (grow only)
   // MFMA profile
   bool prof = false;
@@ -216,7 +218,7 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, const Ws& w = Ws(
   d.stagger = ctx->stagger;
   d.walk = ctx->walk;
   d.epi_wide = ctx->epi_wide;
-  d.bf3 = ctx->math_mode == 1 && mfma_gemm_bf3_pays(d) ? 1 : 0;
+  d.bf3 = ctx->math_mode == 1 && (ctx->bf3_all || mfma_gemm_bf3_pays(d)) ? 1 : 0;
   if (d.bf3 && ctx->bf3_presplit) {
     const uint16_t* pp = d_in.sk_slots != nullptr ? reinterpret_cast<const uint16_t*>(d_in.sk_slots) : nullptr;    // a caller's own planes (per-op entry points)
     int prow = d_in.sk_np;
@@ -755,7 +757,7 @@ std::array<int64_t, 28> graph_key(const dc_ctx* ctx, const Lane& L, int g, bool 
           f2i(ctx->rpn_nms_thresh), f2i(ctx->final_nms_thresh), ctx->num_proposals, ctx->clip_boxes ? 1 : 0,
           ctx->captions_after_final_nms ? 1 : 0, ctx->serial_mode ? 1 : 0, ctx->plan_mode, ctx->tail_mode, ctx->force_cfg,
           ctx->v2_stages, ctx->stagger, ctx->walk + 2 * ctx->epi_wide, ctx->beam_size, (int64_t)(uintptr_t)ctx->fault_dev,
-          (int64_t)(uintptr_t)L.arena.p, (int64_t)(uintptr_t)L.host_stage, (int64_t)(uintptr_t)L.splitk_ws, ctx->math_mode + 2 * ctx->bf3_presplit, 0, 0};
+          (int64_t)(uintptr_t)L.arena.p, (int64_t)(uintptr_t)L.host_stage, (int64_t)(uintptr_t)L.splitk_ws, ctx->math_mode + 2 * ctx->bf3_presplit + 4 * ctx->bf3_all, 0, 0};
 }
 
 // `img`: the g images back to back; `sep` (optional) = g separate images instead (a run of equal-sized images of a mixed list)
@@ -1510,6 +1512,11 @@ int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value) {
   if (strcmp(name, "walk") == 0) {
     if (value < 0 || value > 1) return ctx->fail(DC_E_INVALID, "dc_debug_set: walk must be 0 or 1");
     ctx->walk = (int)value;
+    return DC_OK;
+  }
+  if (strcmp(name, "bf3_all") == 0) {
+    if (value < 0 || value > 1) return ctx->fail(DC_E_INVALID, "dc_debug_set: bf3_all must be 0 or 1");
+    ctx->bf3_all = (int)value;
     return DC_OK;
   }
   if (strcmp(name, "bf3_presplit") == 0) {

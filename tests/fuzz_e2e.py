@@ -1,6 +1,8 @@
 """Randomised end-to-end comparison HIP vs CPU oracle over image sizes, proposal counts and thresholds
 (small vocabulary so the oracle is quick); every case goes through tests/parity.py's strict comparison of the final
-outputs (identical lists, or an oracle near-tie proof).  usage: python tests/fuzz_e2e.py [n_cases] [seed]"""
+outputs (identical lists, or an oracle near-tie proof).  usage: python tests/fuzz_e2e.py [n_cases] [seed]
+FUZZ_MATH_MODE=1: the opt-in split-bf16 arithmetic (dc_set_math_mode(1)) where its own rule takes it; FUZZ_MATH_MODE=2: on
+EVERY contraction (dc_debug_set bf3_all: the images here are small, the rule alone would leave most layers on fp32)."""
 import json
 import os
 import sys
@@ -19,6 +21,10 @@ def main(n_cases, seed):
     rng = np.random.default_rng(seed)
     W = make_synthetic_weights(seed=99, vocab_size=333, seq_length=7)
     m = DenseCapModel(W, device=0)
+    mm = int(os.environ.get("FUZZ_MATH_MODE", "0"))
+    if mm:
+        m.setMathMode(1)
+        check(m.ctx.h, m.ctx.lib.dc_debug_set(m.ctx.h, b"bf3_all", 1 if mm == 2 else 0), "dc_debug_set")
     bad = 0
     for case in range(n_cases):
         H = int(rng.integers(33, 420)); Wd = int(rng.integers(33, 520))
@@ -38,7 +44,7 @@ def main(n_cases, seed):
         check(m.ctx.h, m.ctx.lib.dc_debug_set(m.ctx.h, b"v2_stages", stages_knob), "dc_debug_set")
         check(m.ctx.h, m.ctx.lib.dc_debug_set(m.ctx.h, b"walk", walk), "dc_debug_set")
         rec = dict(case=case, H=H, W=Wd, P=P, rpn_thr=rthr, final_thr=fthr, lanes=lanes, caption_after_nms=order,
-                   tail_mode=tail, v2_stages=stages_knob, walk=walk)
+                   tail_mode=tail, v2_stages=stages_knob, walk=walk, math_mode=mm)
         try:
             # stage tensors are only inspected in the reference caption order (the device "seq" buffer is filled there)
             rec.update(parity.strict_check(m, W, img, P, rpn_thr=rthr, final_thr=fthr, stages=not order))

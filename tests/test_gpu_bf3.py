@@ -11,6 +11,8 @@ What is asserted here:
   * lanes and image groups stay pure scheduling in this mode too (bit-identical results);
   * switching the mode back restores the fp32 bits.
 """
+import contextlib
+
 import numpy as np
 import pytest
 
@@ -33,9 +35,11 @@ def _err(a, ref64):
     return float(np.abs(d).max()) / scale, float(np.sqrt((d * d).mean())) / scale
 
 
-def _three_ways(ctx, fn):
+def _three_ways(ctx, fn, everywhere=False):
     """fn() under (a) the planned fp32 route, (b) the fp32 MFMA kernels with ONE sequential chain over K per output (64x64
-    tiles, no K sharing: dc_debug_set force_cfg = 3), (c) split-bf16."""
+    tiles, no K sharing: dc_debug_set force_cfg = 3), (c) split-bf16 -- where the mode's own rule takes it (mfma_gemm_bf3_pays:
+    one problem fills the chip), or, with `everywhere`, on whatever the problem's size (dc_debug_set bf3_all = 1: the test
+    hook that puts small, ragged and few-tile problems through the split-bf16 kernels)."""
     from densecap_amd._lib import check
     ctx.set_math_mode(0)
     planned = fn()
@@ -45,15 +49,30 @@ def _three_ways(ctx, fn):
     finally:
         check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"force_cfg", 0), "dc_debug_set")
     ctx.set_math_mode(1)
+    check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"bf3_all", 1 if everywhere else 0), "dc_debug_set")
     try:
         split = fn()
     finally:
+        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"bf3_all", 0), "dc_debug_set")
         ctx.set_math_mode(0)
     return planned, chain, split
 
 
+@contextlib.contextmanager
+def _split_mode(ctx, everywhere=True):
+    """dc_set_math_mode(1) for the block; `everywhere`: on every contraction (bf3_all), not only those that fill the chip."""
+    from densecap_amd._lib import check
+    ctx.set_math_mode(1)
+    check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"bf3_all", 1 if everywhere else 0), "dc_debug_set")
+    try:
+        yield
+    finally:
+        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"bf3_all", 0), "dc_debug_set")
+        ctx.set_math_mode(0)
+
+
 def _both_modes(ctx, fn):
-    planned, _, split = _three_ways(ctx, fn)
+    planned, _, split = _three_ways(ctx, fn, everywhere=True)
     return planned, split
 
 
@@ -104,6 +123,13 @@ def test_linear_error_vs_fp64_is_the_fp32_paths(ctx, mnk):
     # ReLU and no-bias epilogues
     refr = np.maximum(ref - b, 0)
     _within_the_fp32_paths_error(_three_ways(ctx, lambda: ops.linear(ctx, x, w, None, relu=True)), refr, mnk + ("relu",))
+    # the kernels themselves on THIS shape, whatever the rule says (ragged rows / columns, single tiles, K = 32)
+    forced = _three_ways(ctx, lambda: ops.linear(ctx, x, w, b), everywhere=True)
+    _within_the_fp32_paths_error(forced, ref, mnk + ("everywhere",))
+    if M * N >= 1000:
+        assert not np.array_equal(forced[0], forced[2])
+    if pays:
+        np.testing.assert_array_equal(forced[2], bf3)                   # the hook changes WHERE the mode runs, not what it computes
 
 
 @pytest.mark.parametrize("shape", [(1, 32, 9, 11, 64), (1, 64, 38, 45, 72), (2, 64, 20, 17, 128), (1, 128, 75, 90, 256),
@@ -118,6 +144,10 @@ def test_conv3x3_error_vs_fp64_is_the_fp32_paths(ctx, shape):
     b = torch.randn(Cout, generator=g)
     ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)).numpy()
     _within_the_fp32_paths_error(_three_ways(ctx, lambda: ops.conv3x3(ctx, x.numpy(), w.numpy(), b.numpy(), relu=True)), ref, shape)
+    # none of these shapes fills the chip on its own (the rule leaves them to the fp32 route): the split-bf16 conv kernels on them
+    forced = _three_ways(ctx, lambda: ops.conv3x3(ctx, x.numpy(), w.numpy(), b.numpy(), relu=True), everywhere=True)
+    _within_the_fp32_paths_error(forced, ref, shape + ("everywhere",))
+    assert not np.array_equal(forced[0], forced[2])
 
 
 def test_weights_split_at_load_equal_the_in_register_split_bit_for_bit(ctx):
@@ -131,24 +161,25 @@ def test_weights_split_at_load_equal_the_in_register_split_bit_for_bit(ctx):
     rng = np.random.default_rng(8)
 
     def both(fn):
-        ctx.set_math_mode(1)
-        try:
-            check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"bf3_presplit", 1), "dc_debug_set")
-            a = fn()
-            check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"bf3_presplit", 0), "dc_debug_set")
-            b = fn()
-        finally:
-            check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"bf3_presplit", 1), "dc_debug_set")
-            ctx.set_math_mode(0)
+        with _split_mode(ctx, everywhere=True):
+            try:
+                check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"bf3_presplit", 1), "dc_debug_set")
+                a = fn()
+                check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"bf3_presplit", 0), "dc_debug_set")
+                b = fn()
+            finally:
+                check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"bf3_presplit", 1), "dc_debug_set")
         return a, b
-    for M, N, K in ((4096, 4096, 512), (1000, 4096, 1024), (3000, 1000, 96), (1000, 10498, 512), (20000, 64, 64), (700, 4100, 160)):
+    for M, N, K in ((4096, 4096, 512), (1000, 4096, 1024), (3000, 1000, 96), (1000, 10498, 512), (20000, 64, 64), (700, 4100, 160),
+                    (37, 5, 4096), (129, 257, 96), (1, 1, 32), (300, 72, 256)):
         x = rng.standard_normal((M, K)).astype(np.float32)
         w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
         bias = rng.standard_normal(N).astype(np.float32)
         a, b = both(lambda: ops.linear(ctx, x, w, bias, relu=True))
         np.testing.assert_array_equal(a, b, err_msg=str((M, N, K)))
     g = torch.Generator().manual_seed(4)
-    for N_, Cin, H, W, Cout in ((1, 64, 150, 180, 128), (1, 128, 75, 90, 256), (2, 256, 75, 90, 512), (1, 64, 300, 360, 64)):
+    for N_, Cin, H, W, Cout in ((1, 64, 150, 180, 128), (1, 128, 75, 90, 256), (2, 256, 75, 90, 512), (1, 64, 300, 360, 64),
+                                 (1, 32, 9, 11, 64), (1, 64, 38, 45, 72), (1, 512, 38, 45, 256)):
         x = torch.randn(N_, Cin, H, W, generator=g).numpy()
         w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).numpy()
         bias = torch.randn(Cout, generator=g).numpy()
@@ -176,16 +207,20 @@ def test_identity_times_asymmetric_matrix_is_exact(ctx):
     """A = I, B asymmetric: every output is ONE nonzero product plus zeros -- the three planes must reassemble each fp32
     value of B exactly and land it in the right row / column (catches a transposed or permuted operand map)."""
     from densecap_amd import ops
+    from densecap_amd._lib import check
     rng = np.random.default_rng(5)
     K = 160
     eye = np.eye(K, dtype=np.float32)
     w = rng.standard_normal((200, K)).astype(np.float32)
-    ctx.set_math_mode(1)
-    try:
+    with _split_mode(ctx):
         out = ops.linear(ctx, eye, w, None)                   # (K, 200) = w^T
-    finally:
-        ctx.set_math_mode(0)
+        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"bf3_presplit", 0), "dc_debug_set")
+        try:
+            out_reg = ops.linear(ctx, eye, w, None)           # the in-register split of the weights
+        finally:
+            check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"bf3_presplit", 1), "dc_debug_set")
     np.testing.assert_array_equal(out, w.T)
+    np.testing.assert_array_equal(out_reg, w.T)
 
 
 def test_fused_pool_and_plain_conv_agree_bit_for_bit_in_split_mode(ctx):
@@ -198,13 +233,12 @@ def test_fused_pool_and_plain_conv_agree_bit_for_bit_in_split_mode(ctx):
         x = torch.randn(Cin, H, W, generator=g).numpy()
         w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).numpy()
         b = torch.randn(Cout, generator=g).numpy()
-        ctx.set_math_mode(1)
-        try:
+        with _split_mode(ctx):
             fused = ops.conv3x3_relu_pool(ctx, x, w, b)
-            plain = ops.maxpool2x2_ceil(ctx, ops.conv3x3(ctx, x[None], w, b, relu=True))[0]
-        finally:
-            ctx.set_math_mode(0)
+            plain_map = ops.conv3x3(ctx, x[None], w, b, relu=True)
+            plain = ops.maxpool2x2_ceil(ctx, plain_map)[0]
         np.testing.assert_array_equal(fused, plain)
+        assert not np.array_equal(plain_map, ops.conv3x3(ctx, x[None], w, b, relu=True))      # (it WAS the other arithmetic)
 
 
 @pytest.fixture(scope="module")
@@ -229,12 +263,9 @@ def test_lm_sample_split_mode_matches_oracle_tokens(small):
     from densecap_amd._lib import check
     T = int(W["seq_length"])
     cd = m.ctx.to_device(codes); td = m.ctx.empty((len(codes), T), np.int32)
-    m.setMathMode(1)
-    try:
+    with _split_mode(m.ctx):                    # (333 rows x 320 + 2048 columns do not fill the chip: the hook puts them on the mode)
         check(m.ctx.h, m.ctx.lib.dc_op_lm_sample(m.ctx.h, cd.ptr, len(codes), td.ptr), "dc_op_lm_sample")
         tok = td.numpy()
-    finally:
-        m.setMathMode(0)
     parity.oracle_threads()
     ref = O.lm_sample(torch.from_numpy(codes), W, int(W["seq_length"]))
     bad = np.nonzero((tok != ref).any(axis=1))[0]
@@ -244,16 +275,16 @@ def test_lm_sample_split_mode_matches_oracle_tokens(small):
     assert len(bad) <= 3
 
 
-@pytest.mark.parametrize("H,Wd,P,seed", [(224, 288, 100, 3), (320, 480, 50, 8)])
-def test_forward_split_mode_passes_the_strict_check_small(small, H, Wd, P, seed):
+@pytest.mark.parametrize("everywhere", [False, True])
+@pytest.mark.parametrize("H,Wd,P,seed", [(224, 288, 100, 3), (320, 480, 50, 8), (97, 131, 300, 4)])
+def test_forward_split_mode_passes_the_strict_check_small(small, H, Wd, P, seed, everywhere):
+    """Small images: under the mode's own rule only conv1_2 .. conv2_2 take it; with the hook EVERY contraction of the forward
+    does (RPN conv and heads, conv5_x, LM encoder, image-step gates, decode steps on a handful of tiles)."""
     from densecap_amd.weights import make_synthetic_image
     from tests import parity
     m, W = small
-    m.setMathMode(1)
-    try:
+    with _split_mode(m.ctx, everywhere=everywhere):
         r = parity.strict_check(m, W, make_synthetic_image(H, Wd, seed), P)
-    finally:
-        m.setMathMode(0)
     assert r["K"] > 0 and r["matched"] > 0 and r["trunk_rel_err"] < 1e-5
 
 
@@ -313,6 +344,22 @@ def test_bad_mode_is_refused(ctx):
     from densecap_amd._lib import DenseCapError
     with pytest.raises(DenseCapError):
         ctx.set_math_mode(2)
+
+
+def test_randomised_shapes_in_split_mode_on_every_contraction():
+    """tests/fuzz_e2e.py with FUZZ_MATH_MODE=2: random sizes / proposal counts / thresholds / lanes / tile knobs, the split-bf16
+    kernels on EVERY contraction (single 64x64 tiles, ragged rows and columns, the arg-max epilogue on a 333-word vocabulary);
+    each case through the strict comparison with the oracle.  (200 cases: profiles/r05_lab/fuzz_split_bf16_everywhere.txt)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FUZZ_MATH_MODE="2")
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_e2e.py"), "8", "5"], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "FUZZ OK: 8/8" in p.stdout and '"math_mode": 2' in p.stdout
+
 
 
 def test_zz_print_error_ratios():
