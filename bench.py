@@ -258,6 +258,57 @@ def git_head():
         return None
 
 
+
+def measure_traffic_live(args, timeout_s=170):
+    """HBM bytes per MFMA launch, measured by THIS run: two child passes of this command on one lane (per-kernel counters need
+    kernels that do not overlap) under `rocprofv3 --kernel-trace --pmc <counter>` -- FETCH_SIZE and WRITE_SIZE in SEPARATE passes,
+    nothing else traced, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- summed over the dispatches of the mfma_gemm_*
+    family exactly as tools/pmc_summary.py sums the committed passes: (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / launches
+    (FETCH_SIZE counts 32-byte requests as if they were 64 on gfx950: the guide's x2 for wide coalesced reads).
+    Returns a dict or raises; never called under a profiler or from a child pass."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        raise RuntimeError("rocprofv3 not found")
+    env = dict(os.environ, TMPDIR="/tmp", DC_BENCH_CHILD="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    per = {}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="dc_traffic_", dir="/tmp")
+        try:
+            cmd = [rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "t", "--", sys.executable,
+                   os.path.abspath(__file__), "--lanes", "1", "--group", "1", "--steps", "3", "--warmup", "1", "--repeats", "1",
+                   "--height", str(args.height), "--width", str(args.width), "--proposals", str(args.proposals),
+                   "--math-mode", str(args.math_mode), "--no-cpu-baseline", "--no-alt-pass", "--no-host-input-leg",
+                   "--sustain-seconds", "0", "--no-settle", "--no-split-leg", "--no-traffic-leg", "--gather", "torch"]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                raise RuntimeError("no counter file from the %s pass" % counter)
+            tot, disp = 0.0, set()
+            for r in csv.DictReader(open(files[0])):
+                name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+                if r["Counter_Name"] == counter and name.startswith("mfma_gemm"):
+                    tot += float(r["Counter_Value"])
+                    disp.add(r["Dispatch_Id"])
+            if not disp:
+                raise RuntimeError("no mfma_gemm dispatch in the %s pass" % counter)
+            per[counter] = (tot, len(disp))
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    (f, nf), (w, nw) = per["FETCH_SIZE"], per["WRITE_SIZE"]
+    return {"hbm_bytes_per_launch": (2.0 * f / nf + w / nw) * 1024.0, "fetch_kb_per_launch": f / nf, "write_kb_per_launch": w / nw,
+            "launches_counted": nf, "seconds": time.perf_counter() - t0,
+            "how": "live: two child passes of this command (--lanes 1 --group 1 --steps 3) under rocprofv3 --kernel-trace --pmc "
+                   "FETCH_SIZE | WRITE_SIZE, mfma_gemm_* dispatches, (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / launches"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -292,6 +343,9 @@ def main():
     ap.add_argument("--no-host-input-leg", action="store_true", help="skip the H2D-inclusive legs (images in host memory)")
     ap.add_argument("--no-settle", action="store_true", help="skip the warm-up-until-stable regions (profiler passes)")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the secondary split-bf16 measurement (value_split_bf16)")
+    ap.add_argument("--no-traffic-leg", action="store_true",
+                    help="skip the live HBM-traffic measurement (two rocprofv3 --pmc child passes of this command on one lane); "
+                         "`roofline.traffic` is then quoted from the committed profile")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--stub-comm-fail", default="never:-1", help=argparse.SUPPRESS)   # "create:R": StubComm cannot be created on rank R
     args = ap.parse_args()
@@ -863,6 +917,21 @@ def main():
                     roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
             except Exception:
                 roof["traffic_from_profile"] = None
+            # ... and measured by this run itself when it can be: not under a profiler already, not a child pass, one GPU
+            under_profiler = any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH", "ROCPROFILER_LIBRARY_CTOR"))
+            if on_gpu and world == 1 and dist is None and not args.no_traffic_leg and not under_profiler and "DC_BENCH_CHILD" not in os.environ:
+                try:
+                    live = measure_traffic_live(args)
+                    roof["traffic_live"] = live
+                    roof["traffic"] = live["hbm_bytes_per_launch"]
+                    roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
+                    roof["traffic_source"] = "traffic_live (this run); traffic_from_profile = the committed passes, for comparison"
+                except Exception as e:                           # the committed figure above stays
+                    roof["traffic_live"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+                    roof["traffic_source"] = "traffic_from_profile (the live passes failed)"
+            elif "traffic" in roof and roof["traffic"] is not None:
+                roof["traffic_source"] = "traffic_from_profile (live passes skipped: %s)" % (
+                    "--no-traffic-leg" if args.no_traffic_leg else "under a profiler" if under_profiler else "child pass / multi-GPU")
             out["roofline"] = roof
             # HBM-side stages named by BASELINE.json (bilinear sampler, NMS): algorithmic bytes / stage time
             fh, fw = (H + 15) // 16, (W + 15) // 16

@@ -197,6 +197,11 @@ def test_bench_line_has_roofline_and_cpu_baseline():
               "fc_frac", "decode_frac", "serial_ms_per_image", "measured_on", "traffic_from_profile"):
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # HBM traffic per MFMA launch measured by the run itself (two rocprofv3 --pmc child passes), not only quoted from profiles/
+    live = r["traffic_live"]
+    assert "error" not in live, live
+    assert live["launches_counted"] > 30 and live["hbm_bytes_per_launch"] > 0 and r["traffic"] == live["hbm_bytes_per_launch"]
+    assert 0.5 < r["traffic_over_algorithmic"] < 20, r["traffic_over_algorithmic"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "images/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert d["n_gpus"] == 1 and len(d["repeats"]["images_per_s"]) == 2 and d["value"] > c["value"]

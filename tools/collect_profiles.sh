@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 # one lane = one stream for the profiled images (per-launch events switch the two-stream decode off); the short legs only
-LEAN="--no-cpu-baseline --no-alt-pass --no-host-input-leg --sustain-seconds 0 --no-settle --no-split-leg --gather torch"
+LEAN="--no-cpu-baseline --no-alt-pass --no-host-input-leg --sustain-seconds 0 --no-settle --no-split-leg --no-traffic-leg --gather torch"
 BENCH="python $REPO/bench.py --lanes 1 --group 1 $LEAN"
 run() {  # name, bench args, rocprof args...
   local name=$1 args=$2; shift 2
@@ -45,7 +45,7 @@ run split_fetch "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc FETCH_SI
 run split_write "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc WRITE_SIZE
 cd "$REPO"
 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-Q="--no-cpu-baseline --sustain-seconds 2 --repeats 3"
+Q="--no-cpu-baseline --sustain-seconds 2 --repeats 3 --no-traffic-leg"
 python bench.py --height 320 --width 480 --proposals 50 --lanes 1 --steps 30 --no-alt-pass $Q > "$OUT/bench_webcam_480_p50.json" 2>/dev/null
 python bench.py --height 480 --width 720 --proposals 1000 --steps 32 $Q > "$OUT/bench_config0_720x480.json" 2>/dev/null
 python bench.py --proposals 300 --steps 32 $Q > "$OUT/bench_config3_p300.json" 2>/dev/null     # (images per group picked by the untimed trial)
