@@ -260,11 +260,13 @@ def git_head():
 
 
 def measure_traffic_live(args, timeout_s=170):
-    """HBM bytes per MFMA launch, measured by THIS run: two child passes of this command on one lane (per-kernel counters need
-    kernels that do not overlap) under `rocprofv3 --kernel-trace --pmc <counter>` -- FETCH_SIZE and WRITE_SIZE in SEPARATE passes,
-    nothing else traced, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- summed over the dispatches of the mfma_gemm_*
-    family exactly as tools/pmc_summary.py sums the committed passes: (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / launches
-    (FETCH_SIZE counts 32-byte requests as if they were 64 on gfx950: the guide's x2 for wide coalesced reads).
+    """HBM bytes per MFMA launch and MFMA-pipe utilisation, measured by THIS run: child passes of this command on one lane
+    (per-kernel counters need kernels that do not overlap) under `rocprofv3 --kernel-trace --pmc <counters>` -- FETCH_SIZE,
+    WRITE_SIZE and the MFMA-busy pair in SEPARATE passes, nothing else traced, as /opt/skills/guides/MI355X_MICROARCH.md
+    prescribes -- summed over the dispatches of the mfma_gemm_* family exactly as tools/pmc_summary.py sums the committed passes:
+    traffic = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / launches (FETCH_SIZE counts 32-byte requests as if they were 64 on
+    gfx950: the guide's x2 for wide coalesced reads); utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024
+    SIMDs), for the family and for its convolution kernels alone (the VGG-16 trunk + the RPN conv: CONV = true instantiations).
     Returns a dict or raises; never called under a profiler or from a child pass."""
     import csv
     import glob
@@ -277,12 +279,17 @@ def measure_traffic_live(args, timeout_s=170):
     env = dict(os.environ, TMPDIR="/tmp", DC_BENCH_CHILD="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+
+    def is_conv(name):                 # mfma_gemm_ks/sk_kernel<true>, mfma_gemm_v2_mixed_kernel<true, ..>, mfma_gemm_v2_kernel<TM, TN, true, ..>, mfma_gemm_bf3_128_kernel<true, ..>
+        a = name.split("<", 1)[1].split(",") if "<" in name else []
+        a = [x.strip(" >") for x in a]
+        return bool(a) and (a[0] == "true" or (name.startswith("mfma_gemm_v2_kernel") and len(a) > 2 and a[2] == "true"))
     per = {}
     t0 = time.perf_counter()
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        out = tempfile.mkdtemp(prefix="dc_traffic_", dir="/tmp")
+    for tag, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("mfma", ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"])):
+        out = tempfile.mkdtemp(prefix="dc_pmc_", dir="/tmp")
         try:
-            cmd = [rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "t", "--", sys.executable,
+            cmd = [rp, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", out, "-o", "t", "--", sys.executable,
                    os.path.abspath(__file__), "--lanes", "1", "--group", "1", "--steps", "3", "--warmup", "1", "--repeats", "1",
                    "--height", str(args.height), "--width", str(args.width), "--proposals", str(args.proposals),
                    "--math-mode", str(args.math_mode), "--no-cpu-baseline", "--no-alt-pass", "--no-host-input-leg",
@@ -290,23 +297,33 @@ def measure_traffic_live(args, timeout_s=170):
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if not files:
-                raise RuntimeError("no counter file from the %s pass" % counter)
-            tot, disp = 0.0, set()
+                raise RuntimeError("no counter file from the %s pass" % tag)
+            acc = {c: [0.0, 0.0] for c in counters}        # [family, conv kernels]
+            disp = set()
             for r in csv.DictReader(open(files[0])):
-                name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-                if r["Counter_Name"] == counter and name.startswith("mfma_gemm"):
-                    tot += float(r["Counter_Value"])
+                name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                if r["Counter_Name"] in acc and name.startswith("mfma_gemm"):
+                    v = float(r["Counter_Value"])
+                    acc[r["Counter_Name"]][0] += v
+                    if is_conv(name):
+                        acc[r["Counter_Name"]][1] += v
                     disp.add(r["Dispatch_Id"])
             if not disp:
-                raise RuntimeError("no mfma_gemm dispatch in the %s pass" % counter)
-            per[counter] = (tot, len(disp))
+                raise RuntimeError("no mfma_gemm dispatch in the %s pass" % tag)
+            per[tag] = (acc, len(disp))
         finally:
             shutil.rmtree(out, ignore_errors=True)
-    (f, nf), (w, nw) = per["FETCH_SIZE"], per["WRITE_SIZE"]
+    (fa, nf), (wa, nw), (ma, nm) = per["fetch"], per["write"], per["mfma"]
+    f, w = fa["FETCH_SIZE"][0], wa["WRITE_SIZE"][0]
+    busy, gui = ma["SQ_VALU_MFMA_BUSY_CYCLES"], ma["GRBM_GUI_ACTIVE"]
+    util = lambda i: busy[i] / (gui[i] / 8.0 * 1024.0) if gui[i] > 0 else None
     return {"hbm_bytes_per_launch": (2.0 * f / nf + w / nw) * 1024.0, "fetch_kb_per_launch": f / nf, "write_kb_per_launch": w / nw,
-            "launches_counted": nf, "seconds": time.perf_counter() - t0,
-            "how": "live: two child passes of this command (--lanes 1 --group 1 --steps 3) under rocprofv3 --kernel-trace --pmc "
-                   "FETCH_SIZE | WRITE_SIZE, mfma_gemm_* dispatches, (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / launches"}
+            "launches_counted": nf, "mfma_util_family": util(0), "mfma_util_conv_kernels": util(1),
+            "seconds": time.perf_counter() - t0,
+            "how": "live: three child passes of this command (--lanes 1 --group 1 --steps 3) under rocprofv3 --kernel-trace --pmc "
+                   "FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, mfma_gemm_* dispatches: (2 x FETCH_SIZE + "
+                   "WRITE_SIZE) KB x 1024 / launches; MFMA busy cycles / (GUI-active cycles / 8 XCDs x 1024 SIMDs), at the "
+                   "profiler's clocks (2.0-2.3 GHz), for the family and for its convolution kernels (VGG-16 trunk + RPN conv)"}
 
 
 def main():

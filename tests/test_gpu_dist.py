@@ -202,6 +202,7 @@ def test_bench_line_has_roofline_and_cpu_baseline():
     assert "error" not in live, live
     assert live["launches_counted"] > 30 and live["hbm_bytes_per_launch"] > 0 and r["traffic"] == live["hbm_bytes_per_launch"]
     assert 0.5 < r["traffic_over_algorithmic"] < 20, r["traffic_over_algorithmic"]
+    assert 0.05 < live["mfma_util_family"] < 1.0 and 0.05 < live["mfma_util_conv_kernels"] < 1.0, live
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "images/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert d["n_gpus"] == 1 and len(d["repeats"]["images_per_s"]) == 2 and d["value"] > c["value"]
