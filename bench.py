@@ -298,27 +298,45 @@ def measure_traffic_live(args, timeout_s=170):
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if not files:
                 raise RuntimeError("no counter file from the %s pass" % tag)
-            acc = {c: [0.0, 0.0] for c in counters}        # [family, conv kernels]
-            disp = set()
+            acc = {c: [0.0, 0.0, 0.0, 0.0] for c in counters}        # [family, conv kernels, RoI pooling, NMS kernels]
+            disp, disp_roi, disp_nms = set(), set(), set()
             for r in csv.DictReader(open(files[0])):
                 name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-                if r["Counter_Name"] in acc and name.startswith("mfma_gemm"):
-                    v = float(r["Counter_Value"])
+                if r["Counter_Name"] not in acc:
+                    continue
+                v = float(r["Counter_Value"])
+                if name.startswith("mfma_gemm"):
                     acc[r["Counter_Name"]][0] += v
                     if is_conv(name):
                         acc[r["Counter_Name"]][1] += v
                     disp.add(r["Dispatch_Id"])
+                elif name.startswith("bilinear_roi_pool"):
+                    acc[r["Counter_Name"]][2] += v
+                    disp_roi.add(r["Dispatch_Id"])
+                elif name.startswith("nms_"):
+                    acc[r["Counter_Name"]][3] += v
+                    disp_nms.add(r["Dispatch_Id"])
             if not disp:
                 raise RuntimeError("no mfma_gemm dispatch in the %s pass" % tag)
             per[tag] = (acc, len(disp))
+            per[tag + "_n"] = (len(disp_roi), len(disp_nms))
         finally:
             shutil.rmtree(out, ignore_errors=True)
     (fa, nf), (wa, nw), (ma, nm) = per["fetch"], per["write"], per["mfma"]
     f, w = fa["FETCH_SIZE"][0], wa["WRITE_SIZE"][0]
     busy, gui = ma["SQ_VALU_MFMA_BUSY_CYCLES"], ma["GRBM_GUI_ACTIVE"]
     util = lambda i: busy[i] / (gui[i] / 8.0 * 1024.0) if gui[i] > 0 else None
+    nroi, nnms = per["fetch_n"]
+    nimg = max(nroi, 1)                                        # one RoI-pooling launch per image on this schedule
+    hbm_stage = {}
+    if nroi:
+        hbm_stage["bilinear_roi_pool_kernel"] = {"fetch_kb_per_launch": fa["FETCH_SIZE"][2] / nroi, "write_kb_per_launch": wa["WRITE_SIZE"][2] / max(per["write_n"][0], 1),
+                                                 "hbm_bytes_per_launch": (2.0 * fa["FETCH_SIZE"][2] / nroi + wa["WRITE_SIZE"][2] / max(per["write_n"][0], 1)) * 1024.0}
+    if nnms:
+        hbm_stage["nms_kernels"] = {"launches_per_image": nnms / nimg,
+                                    "hbm_bytes_per_image": (2.0 * fa["FETCH_SIZE"][3] + wa["WRITE_SIZE"][3]) * 1024.0 / nimg}
     return {"hbm_bytes_per_launch": (2.0 * f / nf + w / nw) * 1024.0, "fetch_kb_per_launch": f / nf, "write_kb_per_launch": w / nw,
-            "launches_counted": nf, "mfma_util_family": util(0), "mfma_util_conv_kernels": util(1),
+            "launches_counted": nf, "mfma_util_family": util(0), "mfma_util_conv_kernels": util(1), "hbm_stage_kernels": hbm_stage,
             "seconds": time.perf_counter() - t0,
             "how": "live: three child passes of this command (--lanes 1 --group 1 --steps 3) under rocprofv3 --kernel-trace --pmc "
                    "FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, mfma_gemm_* dispatches: (2 x FETCH_SIZE + "
@@ -972,6 +990,16 @@ def main():
                                                    "peak_GBps": HBM_PEAK_GBPS,
                                                    "note": "one stream, multi-lane planning, the timed schedule's group size: "
                                                            "the stage as the timed regions run it"}
+            # the same stages' HBM bytes as COUNTED by this run's PMC child passes (traffic_live), beside the algorithmic bytes
+            lk = (roof.get("traffic_live") or {}).get("hbm_stage_kernels") or {}
+            if "bilinear_roi_pool" in hb and "bilinear_roi_pool_kernel" in lk:
+                c = lk["bilinear_roi_pool_kernel"]
+                hb["bilinear_roi_pool"]["hbm_bytes_counted"] = c["hbm_bytes_per_launch"]
+                hb["bilinear_roi_pool"]["write_bytes_counted"] = c["write_kb_per_launch"] * 1024.0
+                hb["bilinear_roi_pool"]["GBps_counted"] = c["hbm_bytes_per_launch"] / (stage["bilinear_roi_pool"] * 1e-3) / 1e9
+            if "rpn_nms" in hb and "nms_kernels" in lk:
+                hb["rpn_nms"]["hbm_bytes_counted_rpn_and_final_nms"] = lk["nms_kernels"]["hbm_bytes_per_image"]
+                hb["rpn_nms"]["nms_launches_per_image"] = lk["nms_kernels"]["launches_per_image"]
             out["hbm_stages"] = hb
             out["warm_up_regions_images_per_s"] = warm_regions
             out["lanes"] = args.lanes
