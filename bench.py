@@ -379,7 +379,7 @@ def main():
     ap.add_argument("--no-settle", action="store_true", help="skip the warm-up-until-stable regions (profiler passes)")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the secondary split-bf16 measurement (value_split_bf16)")
     ap.add_argument("--no-traffic-leg", action="store_true",
-                    help="skip the live HBM-traffic measurement (two rocprofv3 --pmc child passes of this command on one lane); "
+                    help="skip the live HBM-traffic / MFMA-utilisation measurement (three rocprofv3 --pmc child passes of this command on one lane); "
                          "`roofline.traffic` is then quoted from the committed profile")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--stub-comm-fail", default="never:-1", help=argparse.SUPPRESS)   # "create:R": StubComm cannot be created on rank R
