@@ -36,6 +36,10 @@ def build_parser():
     a("-beam_size", type=int, default=0,
       help="language_model.beam_size (LanguageModel.lua:129-131): 0 = greedy sampling, n = beam search")
     a("-max_polls", type=int, default=-1, help="stop after this many directory polls (-1 = forever)")
+    a("-host_preprocess", type=int, default=0, help="1 = image.scale & co on the host (the Python restatement) instead of dc_preprocess_u8")
+    a("-graph_replay", type=int, default=0,
+      help="dc_set_graph_replay: frames of one size are captured once and relaunched as a hipGraph (bit-identical).  Off by default: "
+           "measured at the webcam settings it changes nothing (4.32 against 4.30 ms per frame, profiles/r05_daemon_latency.json)")
     return p
 
 
@@ -48,17 +52,37 @@ def scale_boxes_xywh(boxes, frac):
     return b
 
 
-def process_file(model, in_path, out_path, max_image_size):
-    """One iteration of daemon.lua:57-100.  Returns True if an output was written."""
-    from PIL import Image
+def process_file(model, in_path, out_path, max_image_size, host_preprocess=False):
+    """One iteration of daemon.lua:57-100.  Returns True if an output was written.
+
+    The frame is decoded on the host and scaled / BGR-ed / mean-subtracted ON THE DEVICE (dc_preprocess_u8, bit-equal to the host
+    restatement of image.scale: tests/test_gpu_preprocess.py) -- the Python resize took 30-190 ms per frame in front of a forward
+    of 2 ms (round-4 verdict, item 4).  host_preprocess (or a model without the device entry points) keeps the host route."""
+    device = not host_preprocess and hasattr(model, "forward_images_device")
     try:
-        with Image.open(in_path) as im:
-            ori_w, ori_h = im.size
-        img_caffe, _ = load_image_caffe(in_path, max_image_size)
+        if device:
+            from . import ops
+            from .run_model import _decode_file
+            rgb0 = _decode_file(in_path)              # image.load(path, 3): RGB bytes
+            ori_h, ori_w = int(rgb0.shape[0]), int(rgb0.shape[1])
+        else:
+            from PIL import Image
+            with Image.open(in_path) as im:
+                ori_w, ori_h = im.size
+            img_caffe, _ = load_image_caffe(in_path, max_image_size)
     except Exception:                                 # pcall(image.load) failed: leave the file, try again later
         return False
-    H = img_caffe.shape[2]
-    boxes, _scores, captions = model.forward_test(img_caffe)
+    if device:
+        dev, _ = ops.preprocess_u8(model.ctx, rgb0, max_image_size, want_rgb=False)
+        try:
+            H = dev.shape[1]
+            boxes, scores, tokens = model.forward_images_device([dev])[0]
+            captions = model.decodeSequence(tokens)
+        finally:
+            dev.free()
+    else:
+        H = img_caffe.shape[2]
+        boxes, _scores, captions = model.forward_test(img_caffe)
     boxes_xywh = scale_boxes_xywh(xcycwh_to_xywh(boxes), float(ori_h) / H)
     out = dict(boxes=[[float(v) for v in r] for r in boxes_xywh], captions=list(captions), height=ori_h, width=ori_w)
     os.remove(in_path)
@@ -79,7 +103,7 @@ def serve(model, opt):
             in_path = os.path.join(opt.input_dir, fn)
             out_path = os.path.join(opt.output_dir, fn[:-len(opt.input_ext)] + ".json")
             print("Running model on image " + in_path)
-            process_file(model, in_path, out_path, opt.max_image_size)
+            process_file(model, in_path, out_path, opt.max_image_size, bool(getattr(opt, "host_preprocess", 0)))
         polls += 1
         time.sleep(0.05)
 
@@ -99,6 +123,7 @@ def main(argv=None):
     model.setTestArgs(num_proposals=opt.num_proposals, rpn_nms_thresh=opt.rpn_nms_thresh,
                       final_nms_thresh=opt.final_nms_thresh)
     model.setBeamSize(opt.beam_size)
+    model.setGraphReplay(bool(opt.graph_replay))
     serve(model, opt)
     return 0
 

@@ -623,6 +623,20 @@ def test_webcam_daemon_with_the_hip_model(tmp_path):
         assert not (ind / "frame3.jpg").exists()
         assert out["height"] == 960 and out["width"] == 1280 and out["captions"] == ecaps and len(ecaps) > 0
         np.testing.assert_allclose(out["boxes"], D.scale_boxes_xywh(xcycwh_to_xywh(eb), 960.0 / 360.0), rtol=1e-6)
+        # (the daemon preprocessed the frame ON THE DEVICE -- dc_preprocess_u8 -- and `eb` came from the host restatement: the
+        # equality above is end to end.)  The host route behind -host_preprocess 1 writes the same file:
+        Image.fromarray(frame).save(ind / "frame3.jpg", quality=95)
+        opt_h = D.build_parser().parse_args(["-input_dir", str(ind), "-output_dir", str(tmp_path / "out_host"), "-max_polls", "1",
+                                             "-max_image_size", "480", "-num_proposals", "50", "-host_preprocess", "1"])
+        D.serve(m, opt_h)
+        assert json.load(open(tmp_path / "out_host" / "frame3.json")) == out
+        # graph replay (the daemon's default): the second frame of a size is a hipGraph launch, same results
+        m.setGraphReplay(True)
+        for _ in range(2):
+            Image.fromarray(frame).save(ind / "frame3.jpg", quality=95)
+            D.serve(m, opt)
+            assert json.load(open(outd / "frame3.json")) == out
+        m.setGraphReplay(False)
     finally:
         m.ctx.close()
 
