@@ -35,6 +35,8 @@ def build_parser():
     a("-synthetic_weights", type=int, default=0)
     a("-beam_size", type=int, default=0,
       help="language_model.beam_size (LanguageModel.lua:129-131): 0 = greedy sampling, n = beam search")
+    a("-timing", type=int, default=0, help="1: print the wall time of every frame (decode + preprocess + forward + JSON)")
+    a("-use_cudnn", type=int, default=1, help="accepted for compatibility (webcam/daemon.lua:26); this path has no cuDNN / MIOpen to switch")
     a("-max_polls", type=int, default=-1, help="stop after this many directory polls (-1 = forever)")
     a("-host_preprocess", type=int, default=0, help="1 = image.scale & co on the host (the Python restatement) instead of dc_preprocess_u8")
     a("-graph_replay", type=int, default=0,
@@ -103,7 +105,10 @@ def serve(model, opt):
             in_path = os.path.join(opt.input_dir, fn)
             out_path = os.path.join(opt.output_dir, fn[:-len(opt.input_ext)] + ".json")
             print("Running model on image " + in_path)
-            process_file(model, in_path, out_path, opt.max_image_size, bool(getattr(opt, "host_preprocess", 0)))
+            t0 = time.perf_counter()
+            ok = process_file(model, in_path, out_path, opt.max_image_size, bool(getattr(opt, "host_preprocess", 0)))
+            if ok and getattr(opt, "timing", 0):
+                print("  %.2f ms" % ((time.perf_counter() - t0) * 1e3))
         polls += 1
         time.sleep(0.05)
 

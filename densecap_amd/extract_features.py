@@ -39,6 +39,7 @@ def build_parser():
     a("-group", type=int, default=4, help="equal-sized images that share the dense launches (dc_set_group)")
     a("-io_threads", type=int, default=8, help="threads that decode the input files")
     a("-host_preprocess", type=int, default=0, help="1: image.scale on the host (NumPy restatement) instead of dc_preprocess_u8")
+    a("-use_cudnn", type=int, default=1, help="accepted for compatibility (extract_features.lua:27); this path has no cuDNN / MIOpen to switch")
     a("-timing", type=int, default=0, help="1: print the images/s of the image loop at the end")
     a("-synthetic_weights", type=int, default=0,
       help="1: random weights in checkpoint shapes (no pretrained .t7 is available offline)")

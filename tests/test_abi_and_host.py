@@ -206,6 +206,34 @@ def test_run_model_cli_accepts_every_reference_flag(tmp_path):
         R.get_input_images(R.build_parser().parse_args([]))
 
 
+def test_extract_features_and_daemon_clis_accept_every_reference_flag():
+    """The other two scripts on the boundary (extract_features.lua:14-27, webcam/daemon.lua:14-26): every `cmd:option` parses,
+    with the reference's default."""
+    from densecap_amd import daemon as D, extract_features as E
+    cases = (
+        (E, "/root/reference/extract_features.lua",
+         {"-checkpoint": "data/models/densecap/densecap-pretrained-vgg16.t7", "-image_size": 720, "-rpn_nms_thresh": 0.7,
+          "-final_nms_thresh": 0.4, "-num_proposals": 1000, "-boxes_per_image": 100, "-input_txt": "", "-max_images": 0,
+          "-output_h5": "", "-gpu": 0, "-use_cudnn": 1}),
+        (D, "/root/reference/webcam/daemon.lua",
+         {"-checkpoint": "data/models/densecap/densecap-pretrained-vgg16.t7", "-max_image_size": 720, "-input_dir": "webcam/inputs",
+          "-input_ext": ".jpg", "-output_dir": "webcam/outputs", "-timing": 0, "-rpn_nms_thresh": 0.7, "-final_nms_thresh": 0.3,
+          "-num_proposals": 1000, "-gpu": 0, "-use_cudnn": 1}))
+    for mod, ref, flags in cases:
+        if os.path.exists(ref):        # the lists above ARE the reference's (checked where the reference tree is present)
+            found = dict(re.findall(r"cmd:option\('(-\w+)',\s*\n?\s*('[^']*'|[\d.]+)", open(ref).read()))
+            assert set(found) == set(flags), (ref, set(found) ^ set(flags))
+            for k, v in found.items():
+                assert str(flags[k]) == v.strip("'"), (ref, k, v, flags[k])
+        opt = mod.build_parser().parse_args([])
+        for k, v in flags.items():
+            assert getattr(opt, k[1:]) == v, (mod.__name__, k, getattr(opt, k[1:]), v)
+        argv = []
+        for k, v in flags.items():
+            argv += [k, str(v if v != "" else "x")]
+        mod.build_parser().parse_args(argv)
+
+
 def test_oracle_transcendentals_are_double_then_cast():
     """docs/SEMANTICS.md (round 5): exp / sigmoid / tanh of a FloatTensor as TH computes them -- the C double function, result
     cast to float.  The float result is the correctly rounded one wherever the double is not within 2^-29 of a boundary; overflow
