@@ -38,6 +38,8 @@ def build_parser():
     a("-timing", type=int, default=0, help="1: print the wall time of every frame (decode + preprocess + forward + JSON)")
     a("-use_cudnn", type=int, default=1, help="accepted for compatibility (webcam/daemon.lua:26); this path has no cuDNN / MIOpen to switch")
     a("-max_polls", type=int, default=-1, help="stop after this many directory polls (-1 = forever)")
+    a("-math_mode", type=int, default=0, choices=[0, 1],
+      help="dc_set_math_mode: 0 = fp32 MFMA (default; the reference's arithmetic), 1 = split-bf16 (opt-in: six bf16 partial products per fp32 multiply-add on the bf16 matrix cores, fp32-class accuracy, ~1.2-1.3x images/s)")
     a("-host_preprocess", type=int, default=0, help="1 = image.scale & co on the host (the Python restatement) instead of dc_preprocess_u8")
     a("-graph_replay", type=int, default=0,
       help="dc_set_graph_replay: frames of one size are captured once and relaunched as a hipGraph (bit-identical).  Off by default: "
@@ -128,6 +130,7 @@ def main(argv=None):
     model.setTestArgs(num_proposals=opt.num_proposals, rpn_nms_thresh=opt.rpn_nms_thresh,
                       final_nms_thresh=opt.final_nms_thresh)
     model.setBeamSize(opt.beam_size)
+    model.setMathMode(opt.math_mode)
     model.setGraphReplay(bool(opt.graph_replay))
     serve(model, opt)
     return 0

@@ -41,6 +41,8 @@ def build_parser():
     a("-host_preprocess", type=int, default=0, help="1: image.scale on the host (NumPy restatement) instead of dc_preprocess_u8")
     a("-use_cudnn", type=int, default=1, help="accepted for compatibility (extract_features.lua:27); this path has no cuDNN / MIOpen to switch")
     a("-timing", type=int, default=0, help="1: print the images/s of the image loop at the end")
+    a("-math_mode", type=int, default=0, choices=[0, 1],
+      help="dc_set_math_mode: 0 = fp32 MFMA (default; the reference's arithmetic), 1 = split-bf16 (opt-in: six bf16 partial products per fp32 multiply-add on the bf16 matrix cores, fp32-class accuracy, ~1.2-1.3x images/s)")
     a("-synthetic_weights", type=int, default=0,
       help="1: random weights in checkpoint shapes (no pretrained .t7 is available offline)")
     return p
@@ -74,6 +76,7 @@ def main(argv=None):
             raise SystemExit("checkpoint %s not found (use -synthetic_weights 1 for random weights)" % opt.checkpoint)
         weights = t7.weights_from_checkpoint(t7.load(opt.checkpoint))
     model = DenseCapModel(weights, device=opt.gpu)
+    model.setMathMode(opt.math_mode)
     model.setLanes(1 if len(paths) == 1 else opt.lanes)   # a list of images is pipelined over the lanes (same results per image)
     model.setGroup(1 if len(paths) == 1 else opt.group)
     model.setTestArgs(rpn_nms_thresh=opt.rpn_nms_thresh, final_nms_thresh=opt.final_nms_thresh,

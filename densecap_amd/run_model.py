@@ -59,6 +59,8 @@ def build_parser():
     a("-host_preprocess", type=int, default=0,
       help="1: image.scale on the host (the NumPy restatement) instead of dc_preprocess_u8; same bits, ~100x slower")
     a("-timing", type=int, default=0, help="1: print the images/s of the image loop (files in -> results out) at the end")
+    a("-math_mode", type=int, default=0, choices=[0, 1],
+      help="dc_set_math_mode: 0 = fp32 MFMA (default; the reference's arithmetic), 1 = split-bf16 (opt-in: six bf16 partial products per fp32 multiply-add on the bf16 matrix cores, fp32-class accuracy, ~1.2-1.3x images/s)")
     a("-synthetic_weights", type=int, default=0,
       help="1: random weights in checkpoint shapes (no pretrained .t7 is available offline)")
     return p
@@ -321,6 +323,7 @@ def main(argv=None):
     # one image: single-image mode (lowest latency, like the reference); several: pipelined over the lanes, runs of
     # equal-sized images sharing their dense launches -- results identical to one-by-one processing
     model.setLanes(1 if num == 1 else opt.lanes)
+    model.setMathMode(opt.math_mode)
     model.setGroup(1 if num == 1 else opt.group)
     model.setTestArgs(rpn_nms_thresh=opt.rpn_nms_thresh, final_nms_thresh=opt.final_nms_thresh,
                       num_proposals=opt.num_proposals)

@@ -77,6 +77,11 @@ def test_cli_pipeline_equals_the_host_path_image_by_image(tmp_path):
         res = json.load(open(vis / "results.json"))["results"]
         assert [r["img_name"] for r in res] == sorted(os.listdir(d))
         assert sorted(os.listdir(tmp_path / "drawn")) == sorted(os.listdir(d))
+        # -math_mode 1: the opt-in split-bf16 arithmetic from the command line (dc_set_math_mode)
+        vis1 = tmp_path / "vis_mm1"
+        assert R.main(["-input_dir", str(d), "-synthetic_weights", "1", "-num_proposals", "100", "-output_vis_dir", str(vis1),
+                       "-output_vis", "1", "-lanes", "2", "-group", "2", "-math_mode", "1"]) == 0
+        res1 = json.load(open(vis1 / "results.json"))["results"]
         W = Wm.make_synthetic_weights()
     finally:
         Wm.make_synthetic_weights = orig
@@ -91,6 +96,16 @@ def test_cli_pipeline_equals_the_host_path_image_by_image(tmp_path):
             np.testing.assert_array_equal(np.asarray(r["scores"], np.float32), np.asarray(scores).reshape(-1))
             assert r["captions"] == m.decodeSequence(tokens)
             assert os.path.exists(vis / r["img_name"])
+        m.setMathMode(1)
+        differs = False
+        for r, r0 in zip(res1, res):
+            x, _ = R.load_image_caffe(str(d / r["img_name"]), 720)
+            boxes, scores, tokens = m.forward_raw(x[0])
+            np.testing.assert_array_equal(np.asarray(r["boxes"], np.float32), R.xcycwh_to_xywh(boxes))
+            np.testing.assert_array_equal(np.asarray(r["scores"], np.float32), np.asarray(scores).reshape(-1))
+            assert r["captions"] == m.decodeSequence(tokens)
+            differs = differs or r["scores"] != r0["scores"]
+        assert differs                                        # (it was the other arithmetic)
     finally:
         m.ctx.close()
 
