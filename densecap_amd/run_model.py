@@ -224,6 +224,7 @@ class ImagePipeline:
         import threading
         from concurrent.futures import ThreadPoolExecutor
         from . import ops
+        from ._lib import check
         self.paths, self.num, self.chunk = list(paths), len(paths), max(1, int(chunk))
         self.pool = ThreadPoolExecutor(max_workers=max(1, int(io_threads)))
         self._decoded = [None] * self.num
@@ -238,7 +239,7 @@ class ImagePipeline:
         def worker():
             pctx = None
             try:
-                pctx = ops.Context(gpu) if not self._host else None
+                pctx = ops.Context(gpu)                  # a dc_ctx is not thread-safe: this thread never touches the model's
                 for i in range(self.num):
                     rgb0 = self._decoded[i].result()
                     self._decoded[i] = True
@@ -246,7 +247,10 @@ class ImagePipeline:
                     if self._host:
                         img_caffe, sc = preprocess_rgb01(rgb0.astype(np.float32).transpose(2, 0, 1) / np.float32(255.0), image_size)
                         rgb = np.ascontiguousarray((np.clip(sc, 0, 1) * 255.0).astype(np.uint8).transpose(1, 2, 0)) if want_rgb else None
-                        self._ready.put((i, model_ctx.to_device(img_caffe[0]), rgb))
+                        x = np.ascontiguousarray(img_caffe[0], dtype=np.float32)
+                        dev = self._take(pctx, x.shape, np.float32)
+                        check(pctx.h, pctx.lib.dc_memcpy_h2d(pctx.h, dev.ptr, x.ctypes.data, x.nbytes), "dc_memcpy_h2d")
+                        self._ready.put((i, dev, rgb))
                     else:
                         H, W = ops.preprocess_size(pctx.lib, rgb0.shape[0], rgb0.shape[1], image_size)
                         dev = self._take(pctx, (3, H, W), np.float32)
@@ -274,9 +278,7 @@ class ImagePipeline:
         return ctx.empty(shape, dtype)
 
     def recycle(self, buf):
-        if self._host:
-            buf.free()
-            return
+        # (never freed from the consuming thread: the buffer belongs to the preparation thread's context)
         with self._lock:
             self._spare.setdefault((buf.shape, buf.dtype.str), []).append(buf)
 
