@@ -43,7 +43,7 @@ def build_parser():
     a("-host_preprocess", type=int, default=0, help="1 = image.scale & co on the host (the Python restatement) instead of dc_preprocess_u8")
     a("-graph_replay", type=int, default=0,
       help="dc_set_graph_replay: frames of one size are captured once and relaunched as a hipGraph (bit-identical).  Off by default: "
-           "measured at the webcam settings it changes nothing (4.32 against 4.30 ms per frame, profiles/r05_daemon_latency.json)")
+           "measured at the webcam settings it changes nothing (4.23 against 4.21 ms per frame, profiles/r05_daemon_latency.json)")
     return p
 
 
@@ -77,13 +77,21 @@ def process_file(model, in_path, out_path, max_image_size, host_preprocess=False
     except Exception:                                 # pcall(image.load) failed: leave the file, try again later
         return False
     if device:
-        dev, _ = ops.preprocess_u8(model.ctx, rgb0, max_image_size, want_rgb=False)
-        try:
-            H = dev.shape[1]
-            boxes, scores, tokens = model.forward_images_device([dev])[0]
-            captions = model.decodeSequence(tokens)
-        finally:
-            dev.free()
+        # the preprocessed frame's device buffer is kept per size (a webcam delivers one size: hipMalloc / hipFree would
+        # synchronise the device once per frame)
+        bufs = model.__dict__.setdefault("_daemon_frame_bufs", {})
+        Hs, Ws = ops.preprocess_size(model.ctx.lib, ori_h, ori_w, max_image_size)
+        dev = bufs.get((Hs, Ws))
+        if dev is None:
+            if len(bufs) >= 4:                        # sizes keep changing: do not hoard device memory
+                for b in bufs.values():
+                    b.free()
+                bufs.clear()
+            dev = bufs[(Hs, Ws)] = model.ctx.empty((3, Hs, Ws), np.float32)
+        ops.preprocess_u8(model.ctx, rgb0, max_image_size, want_rgb=False, out=dev)
+        H = Hs
+        boxes, scores, tokens = model.forward_images_device([dev])[0]
+        captions = model.decodeSequence(tokens)
     else:
         H = img_caffe.shape[2]
         boxes, _scores, captions = model.forward_test(img_caffe)
