@@ -542,11 +542,41 @@ __global__ void gather_rows_i32_kernel(const int32_t* __restrict__ src, const in
   out[t] = i < *count ? src[(size_t)idx[i] * width + c] : 0;
 }
 
+// Captions after the final NMS, once per GROUP (round 6; DenseCapModel.lua:261-275 keeps K of the P rows -- LSTM rows are
+// independent, so only those need a caption): the fc7 rows the final NMS kept, of all `nimg` images of a group, packed
+// into ONE row block -- image i's K_i rows at [off_i, off_i + K_i), off_i = sum of min(count_j, P) over j < i, in pick
+// order -- so that a single decode of `*total` rows serves the whole group.  Rows past *total are left as they are: the
+// decode's launches carry the device-side row count (GemmDesc::m_dev) and never store them.  image = blockIdx.y.
+__global__ __launch_bounds__(256) void survivor_compact_kernel(const float* __restrict__ codes,
+                                                               const int32_t* __restrict__ picks,
+                                                               const int32_t* __restrict__ count, int count_stride,
+                                                               int nimg, int P, int D, float* __restrict__ out,
+                                                               int32_t* __restrict__ total) {
+  const int img = blockIdx.y;
+  int off = 0, all = 0;
+  for (int j = 0; j < nimg; ++j) {
+    const int k = min(count[(size_t)j * count_stride], P);
+    if (j < img) off += k;
+    all += k;
+  }
+  if (blockIdx.x == 0 && img == 0 && threadIdx.x == 0) *total = all;
+  const int K = min(count[(size_t)img * count_stride], P);
+  const int D4 = D >> 2;
+  const size_t r0 = (size_t)img * P;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < (long)K * D4; t += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(t / D4), c = (int)(t - (long)r * D4);
+    const size_t src = r0 + (size_t)picks[r0 + r];
+    reinterpret_cast<f32x4*>(out)[((size_t)off + r) * D4 + c] = reinterpret_cast<const f32x4*>(codes)[src * D4 + c];
+  }
+}
+
 // The results of a group in ONE launch (round 5; three gathers per image before): image = blockIdx.y.  A record is laid out
 // exactly as the pinned host staging expects it -- {int32 K at byte 0, uint32 fault word at byte 68 | 256: boxes (P,4) |
 // scores (P) | int32 tokens (P,T) or fc7 codes (P,D)} -- so that the whole group leaves in one device-to-host copy.
 // Row r < K of image i is row picks[i*P + r] of the per-RoI tensors (box_utils.nms order, DenseCapModel.lua:261-275);
-// tok_gather = 0: the token rows are already in final order (captions decoded after the final NMS).
+// tok_gather = 0: the token rows are already in final order, image by image (captions decoded after the final NMS, rows
+// [img*P, img*P + K)); tok_gather = 2: in final order and PACKED over the group (survivor_compact_kernel's row block: image
+// img's rows start at the sum of the earlier images' counts).
 __global__ void final_pack_kernel(const float* __restrict__ final_boxes, const float* __restrict__ obj,
                                   const int32_t* __restrict__ tokens, int tok_gather, const float* __restrict__ codes,
                                   const int32_t* __restrict__ picks, const int32_t* __restrict__ count, int count_stride,
@@ -564,13 +594,18 @@ __global__ void final_pack_kernel(const float* __restrict__ final_boxes, const f
   float* os = ob + (size_t)P * 4;
   uint32_t* ot = reinterpret_cast<uint32_t*>(os + P);
   const size_t r0 = (size_t)img * P;
+  size_t tok0 = r0;
+  if (tok_gather == 2) {
+    tok0 = 0;
+    for (int j = 0; j < img; ++j) tok0 += (size_t)min(count[(size_t)j * count_stride], P);
+  }
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < (long)K * W; t += (long)gridDim.x * blockDim.x) {
     const int r = (int)(t / W), c = (int)(t - (long)r * W);
     const size_t src = r0 + (size_t)picks[r0 + r];
     if (c < 4) ob[(size_t)r * 4 + c] = final_boxes[src * 4 + c];
     else if (c == 4) os[r] = obj[src];
     else if (codes != nullptr) ot[(size_t)r * D + (c - 5)] = __float_as_uint(codes[src * D + (c - 5)]);
-    else ot[(size_t)r * T + (c - 5)] = (uint32_t)tokens[(tok_gather ? src : r0 + r) * T + (c - 5)];
+    else ot[(size_t)r * T + (c - 5)] = (uint32_t)tokens[(tok_gather == 1 ? src : tok0 + r) * T + (c - 5)];
   }
 }
 
@@ -706,6 +741,17 @@ hipError_t launch_final_pack(const float* final_boxes, const float* obj, const i
   const int gx = (int)std::min<long>((per + 255) / 256, 2048);
   hipLaunchKernelGGL(final_pack_kernel, dim3(gx, nimg), dim3(256), 0, s, final_boxes, obj, tokens, tok_gather, codes, picks,
                      count, count_stride, fault, P, T, D, static_cast<char*>(pack), stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_survivor_compact(const float* codes, const int32_t* picks, const int32_t* count, int count_stride, int nimg,
+                                   int P, int D, float* out, int32_t* total, hipStream_t s) {
+  if (nimg <= 0 || nimg > 65535 || P <= 0 || D <= 0 || D % 4) return hipErrorInvalidValue;
+  // a final NMS at 0.3 keeps about a quarter of the rows: blocks for P/2 rows, grid-stride beyond
+  const long work = (long)std::max(P / 2, 1) * (D / 4);
+  const int gx = (int)std::min<long>((work + 255) / 256, 2048);
+  hipLaunchKernelGGL(survivor_compact_kernel, dim3(gx, nimg), dim3(256), 0, s, codes, picks, count, count_stride, nimg, P, D, out,
+                     total);
   return hipGetLastError();
 }
 

@@ -102,8 +102,9 @@ struct GemmDesc {
   int a_rows = 0;
 };
 // C = act(sum_s ws[s] + bias): fixed summation order s = 0..S-1
+// m_dev (optional): device-side row count, rows >= *m_dev are left alone (their partials were never written)
 hipError_t launch_splitk_reduce(const float* ws, int S, const float* bias, float* C, int M, int N, int ldc, int relu,
-                                hipStream_t s);
+                                hipStream_t s, const int32_t* m_dev = nullptr);
 // same for a pooled conv (GemmDesc::pool): ws rows are window-ordered slots [m_begin, m_begin+M); C_pooled is the base
 // of the whole pooled map
 hipError_t launch_splitk_reduce_pool(const float* ws, int S, const float* bias, float* C_pooled, int m_begin, int M, int N,
@@ -242,7 +243,12 @@ hipError_t launch_gather_rows(const float* src, const int32_t* idx, const int32_
 hipError_t launch_gather_rows_i32(const int32_t* src, const int32_t* idx, const int32_t* count, int cap, int width,
                                   int32_t* out, hipStream_t s);
 
-// the results of a group of images gathered by their final-NMS picks into packed records (see final_pack_kernel)
+// the fc7 rows the final NMS kept, of all images of a group, packed into one row block in pick order; *total = their number
+hipError_t launch_survivor_compact(const float* codes, const int32_t* picks, const int32_t* count, int count_stride, int nimg,
+                                   int P, int D, float* out, int32_t* total, hipStream_t s);
+
+// the results of a group of images gathered by their final-NMS picks into packed records (see final_pack_kernel);
+// tok_gather: 1 = token rows are per RoI (gathered by pick), 0 = already in final order per image, 2 = final order, packed over the group
 hipError_t launch_final_pack(const float* final_boxes, const float* obj, const int32_t* tokens, int tok_gather,
                              const float* codes, const int32_t* picks, const int32_t* count, int count_stride,
                              const uint32_t* fault, int nimg, int P, int T, int D, void* pack, size_t stride, hipStream_t s);

@@ -53,6 +53,7 @@ struct Lane {
   float *obj = nullptr, *final_trans = nullptr, *final_boxes = nullptr, *final_xyxy = nullptr;
   float *enc = nullptr, *gates = nullptr, *hstate = nullptr, *cstate = nullptr, *logits = nullptr;
   int32_t *tok = nullptr, *seq = nullptr;
+  int32_t* surv_total = nullptr;   // captions after the final NMS: rows the group's final NMS runs kept, all images together
   float* out_feats = nullptr;
   char* out_pack = nullptr;     // the group's packed result records (final_pack_kernel), copied to host_stage in one piece
   float* splitk_ws = nullptr;   // split-K partial tiles (<= 256 tiles of 128x128)
@@ -83,6 +84,7 @@ struct Lane {
   std::array<int64_t, 28> gkey{}, last_key{};
   bool last_key_valid = false;          // last_key = the key of the previous (eager) forward on this lane
   bool ran_graph = false;               // the group in flight was a graph launch (no stage events)
+  bool nms_before_decode = false;       // the group in flight ran the final NMS before the decode (dc_set_caption_order(1))
 };
 
 struct ProfEvt { hipEvent_t a, b; double flops; };
@@ -244,7 +246,7 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, const Ws& w = Ws(
     e = launch_mfma_gemm(d, s);
     if (e == hipSuccess)
       e = d.pool ? launch_splitk_reduce_pool(ws, pl.splitk, d.bias, d.C, 0, d.M, d.N, d.ldc, d.H, d.Wd, d.relu, s)
-                 : launch_splitk_reduce(ws, pl.splitk, d.bias, d.C, d.M, d.N, d.ldc, d.relu, s);
+                 : launch_splitk_reduce(ws, pl.splitk, d.bias, d.C, d.M, d.N, d.ldc, d.relu, s, d.m_dev);
   } else if (pl.kind == GEMM_PLAN_STREAMK) {
     // tile count not a multiple of the CU count: whole tiles for the full rounds, the last partial round shared evenly
     // along K by all CUs (stream-K with in-kernel fix-up: no reduce launch, one partial tile per cut)
@@ -399,6 +401,7 @@ int lane_prepare(dc_ctx* ctx, Lane& L, int H, int W, int P, int G) {
       {(void**)&L.count1, (size_t)G * 256},
       {(void**)&L.picks2, GP * 4},
       {(void**)&L.count2, (size_t)G * 256},
+      {(void**)&L.surv_total, 256},
       {(void**)&L.roi_boxes, GP * 16},
       {(void**)&L.roi_feats, GP * 49 * 512 * 4},
       {(void**)&L.fc6_out, GP * Dm * 4},
@@ -531,12 +534,6 @@ int lm_sample(dc_ctx* ctx, Lane& L, const float* codes, int n, int plan, const i
   const LmPart whole{L.stream, 0, n, lane_ws(L)};
   return lm_sample_parts(ctx, L, codes, &whole, 1, n_dev, seq_out, plan);
 }
-// decode rows [r0, r0+n) of the lane's buffers (codes / seq_out are the BASE pointers); n_dev: device row count
-int lm_sample_rows(dc_ctx* ctx, Lane& L, const float* codes, int r0, int n, const int32_t* n_dev, int32_t* seq_out) {
-  const LmPart part{L.stream, r0, n, lane_ws(L)};
-  return lm_sample_parts(ctx, L, codes, &part, 1, n_dev, seq_out, 0);
-}
-
 // LanguageModel:beamsearch (LanguageModel.lua:170-290), dispatched by LM:updateOutput when self.beam_size is set
 // (:129-131; no reference script sets it).  The reference walks the proposals one by one with the beams in the
 // minibatch dimension; here ALL proposals advance together (rows = proposals x beams; beam_chunk), row for row the same
@@ -710,7 +707,7 @@ int enqueue_body(dc_ctx* ctx, Lane& L, int g, bool features_only, bool events) {
     else if (side_streams) DCCHK(lm_sample_two_streams(ctx, L, L.codes, R, P, L.seq));
     else DCCHK(lm_sample(ctx, L, L.codes, R, P, nullptr, L.seq));
   }
-  STAGE_EVENT(7);
+  if (!survivors_only) STAGE_EVENT(7);
   // ---- final NMS + gather (DenseCapModel.lua:261-275) ----------------------------------------------
   for (int i = 0; i < g; ++i) {
     const size_t r0 = (size_t)i * P;
@@ -728,19 +725,31 @@ int enqueue_body(dc_ctx* ctx, Lane& L, int g, bool features_only, bool events) {
     HIPCHK(hipEventRecord(L.ev_join2, L.aux2));
     HIPCHK(hipStreamWaitEvent(s, L.ev_join2, 0));
   }
-  if (survivors_only) {
-    // identical outputs, less work: LSTM rows are independent, so decode only the rows the final NMS kept
+  // captions after the final NMS: event 7 sits between the two stages here as well, in the order they ran (harvest swaps the names)
+  if (survivors_only) STAGE_EVENT(7);
+  L.nms_before_decode = survivors_only;
+  const bool packed_decode = survivors_only && ctx->beam_size == 0;
+  if (packed_decode) {
+    // Identical outputs, less work: LSTM rows are independent, so only the rows the final NMS kept are decoded (~a quarter at
+    // 1000 proposals / 0.3).  Round 6: ONCE PER GROUP -- the kept fc7 rows of all g images packed into one row block
+    // (survivor_compact_kernel), ONE decode over it with the device-side row count (row tiles past it exit at once), routes
+    // planned on one image's P rows as in the reference order: an element's arithmetic is the same in either order and in any
+    // group (tests/test_gpu_e2e.py::test_caption_order_is_output_invariant).  final_pack reads the packed token rows back
+    // image by image.
+    KCHK(launch_survivor_compact(L.codes, L.picks2, L.count2, 64, g, P, ctx->D, L.out_feats, L.surv_total, s));
+    DCCHK(lm_sample(ctx, L, L.out_feats, R, P, L.surv_total, L.out_tokens));
+  } else if (survivors_only) {
+    // beam search after the final NMS: image by image (the beam rows of one image advance together)
     for (int i = 0; i < g; ++i) {
       const size_t r0 = (size_t)i * P;
       const int32_t *pk = L.picks2 + r0, *cnt = L.count2 + i * 64;
       KCHK(launch_gather_rows(L.codes + r0 * ctx->D, pk, cnt, P, ctx->D, L.out_feats + r0 * ctx->D, s));
-      if (ctx->beam_size > 0) DCCHK(lm_beamsearch(ctx, L, L.out_feats + r0 * ctx->D, P, L.out_tokens + r0 * ctx->T, s));   // rows past K: zero codes, ignored
-      else DCCHK(lm_sample_rows(ctx, L, L.out_feats, (int)r0, P, cnt, L.out_tokens));
+      DCCHK(lm_beamsearch(ctx, L, L.out_feats + r0 * ctx->D, P, L.out_tokens + r0 * ctx->T, s));   // rows past K: zero codes, ignored
     }
   }
   // ---- results: ONE gather launch for the group into packed records, ONE copy to the pinned host staging ---------------
   const size_t stride = pack_stride(ctx, P, features_only);
-  KCHK(launch_final_pack(L.final_boxes, L.obj, survivors_only ? L.out_tokens : L.seq, survivors_only ? 0 : 1,
+  KCHK(launch_final_pack(L.final_boxes, L.obj, survivors_only ? L.out_tokens : L.seq, packed_decode ? 2 : survivors_only ? 0 : 1,
                          features_only ? L.codes : nullptr, L.picks2, L.count2, 64, ctx->fault_dev, g, P, ctx->T, ctx->D,
                          L.out_pack, stride, s));
   STAGE_EVENT(8);
@@ -839,6 +848,7 @@ int harvest(dc_ctx* ctx, Lane& L) {
       hipEventElapsedTime(&ms, L.ev[i], L.ev[i + 1]);
       L.stage_ms[i] = ms / (float)std::max(L.g, 1);       // per image of the group
     }
+    if (L.nms_before_decode) std::swap(L.stage_ms[ST_LSTM], L.stage_ms[ST_NMS2]);    // events 6..7 timed the NMS, 7..8 the decode
   }
   L.have_times = !L.ran_graph;                            // a replayed graph carries no stage events
   const int P = L.P;
@@ -1417,6 +1427,11 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
       {"seq", L.seq, (int64_t)P * ctx->T, 4},
       {"final_nms_idx", L.picks2, (int64_t)P, 4},
       {"final_nms_count", L.count2, 1, 4},
+      // language-model state of image 0's rows (reference order: row = RoI; captions after the final NMS: row = final rank)
+      {"lm_enc", L.enc, (int64_t)P * ctx->E, 4},
+      {"lm_h", L.hstate, (int64_t)P * ctx->Hd, 4},
+      {"lm_c", L.cstate, (int64_t)P * ctx->Hd, 4},
+      {"survivor_rows", L.surv_total, 1, 4},
   };
   if (strcmp(name, "host_enqueue_us") == 0) {
     if (capacity_bytes < 4) return ctx->fail(DC_E_INVALID, "dc_debug_fetch: buffer too small");

@@ -311,10 +311,12 @@ __global__ __launch_bounds__(256) void lstm_step_tail_kernel(const float* __rest
 }
 
 // split-K finish: C = act(sum_s ws[s] + bias), fixed order
+// (m_dev: device-side row count -- the slices sit M rows apart, only rows < *m_dev were written and are finished)
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, const float* __restrict__ bias,
-                                     float* __restrict__ C, int M, int N, int ldc, int relu) {
+                                     float* __restrict__ C, int M, int N, int ldc, int relu,
+                                     const int32_t* __restrict__ m_dev) {
   const int N4 = N >> 2;
-  const size_t total = (size_t)M * N4;
+  const size_t total = (size_t)(m_dev != nullptr ? min(M, *m_dev) : M) * N4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t m = i / N4;
     const int n = (int)(i - m * N4) * 4;
@@ -489,10 +491,10 @@ hipError_t launch_lstm_step_tail(const float* pval, const int32_t* pidx, int nti
   return hipGetLastError();
 }
 hipError_t launch_splitk_reduce(const float* ws, int S, const float* bias, float* C, int M, int N, int ldc, int relu,
-                                hipStream_t s) {
+                                hipStream_t s, const int32_t* m_dev) {
   if (N % 4 || ldc % 4) return hipErrorInvalidValue;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)M * (N / 4))), dim3(256), 0, s, ws, S, bias, C, M, N, ldc,
-                     relu);
+                     relu, m_dev);
   return hipGetLastError();
 }
 hipError_t launch_splitk_reduce_pool(const float* ws, int S, const float* bias, float* C_pooled, int m_begin, int M, int N,

@@ -1674,7 +1674,9 @@ bool mfma_gemm_bf3_pays(const GemmDesc& d) {
 // keeps an even number (>= 16) of K-tiles for the K-split kernel.
 int mfma_gemm_splitk(const GemmDesc& d, size_t ws_floats) {
   if ((size_t)128 * d.K * 4 >= 0xfffffff0ull || (d.conv && (size_t)d.M * d.Cin * 4 >= CV_PAD)) return 1;
-  if (d.amax_val != nullptr || d.rowterm != nullptr || d.m_dev != nullptr) return 1;
+  // (a device-side row count does not change the choice -- round 6: the factor fixes the summation order, and the rows a final
+  // NMS kept must get the bits they get when all P rows are decoded; row tiles past the count exit, the reduce stops at it)
+  if (d.amax_val != nullptr || d.rowterm != nullptr || (d.m_dev != nullptr && d.pool)) return 1;
   const int pm = d.plan_M > 0 ? d.plan_M : d.M;       // one image's tiles: the split factor fixes the summation order
   const long tiles = (long)((pm + 127) / 128) * ((d.N + 127) / 128);
   const int nkt = d.K / BK;

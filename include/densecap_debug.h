@@ -22,7 +22,9 @@ int dc_mfma_profile(dc_ctx* ctx, int reset, int64_t* launches, double* total_ms,
 /* Copy an intermediate of the most recent forward to the host for stage-wise parity:
  * name in {"feat_hwc","rpn_heads","rpn_boxes","rpn_x1y1x2y2","rpn_p","rpn_valid",
  * "rpn_nms_idx","rpn_nms_count","roi_boxes","roi_feats","codes","obj","final_trans","final_boxes",
- * "seq","final_nms_idx","final_nms_count"} (lane 0; "seq" is only filled in the reference caption order), or
+ * "seq","final_nms_idx","final_nms_count"} (lane 0; "seq" is only filled in the reference caption order),
+ * "lm_enc","lm_h","lm_c" (image encoder output and final LSTM state, P rows: row = RoI in the reference caption order,
+ * row = final rank with captions after the final NMS -- rows past "survivor_rows" (int32) are then undefined), or
  * "arena_allocs" (int32: how many times a lane workspace has been (re)allocated -- it only grows), or
  * "host_enqueue_us" (int32: host microseconds per image spent enqueueing in the last dc_forward_batch).
  * Returns the number of elements copied (or <0). */

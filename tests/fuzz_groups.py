@@ -3,6 +3,8 @@ must give every image exactly the bits it gets alone in a one-image multi-lane c
 counts, thresholds and batch sizes (small vocabulary so that a case takes milliseconds).  One case in five runs in
 single-image mode (lanes = 1) with a group setting: include/densecap.h says the group is ignored there, i.e. every image
 gets the bits of a one-image single-lane call (round-4 advisor finding: the fuzz only drew lanes >= 2).
+FUZZ_CROSS_ORDER=1 (round 6): the batch call runs with captions AFTER the final NMS (one packed decode per group) and is
+compared with the REFERENCE caption order image by image -- the order, too, must be invisible in the outputs.
 usage: python tests/fuzz_groups.py [n_cases] [seed]"""
 import json
 import os
@@ -29,15 +31,20 @@ def main(n_cases, seed):
         if rng.integers(0, 5) == 0:
             lanes = 1
         order = bool(rng.integers(0, 2))
+        cross = os.environ.get("FUZZ_CROSS_ORDER") == "1"
+        if cross:
+            order = True
         m.setTestArgs(rpn_nms_thresh=float(rng.choice([0.3, 0.7, 1.0])), final_nms_thresh=float(rng.choice([-1.0, 0.0, 0.3, 0.5])),
                       num_proposals=P)
         m.setCaptionOrder(order)
         imgs = np.stack([make_synthetic_image(H, Wd, 5000 + 16 * case + s) for s in range(n)])
-        rec = dict(case=case, H=H, W=Wd, P=P, n=n, group=G, lanes=lanes, caption_after_nms=order)
+        rec = dict(case=case, H=H, W=Wd, P=P, n=n, group=G, lanes=lanes, caption_after_nms=order, cross_order=cross)
         try:
             m.setLanes(lanes); m.setGroup(G)
             got = m.forward_batch(imgs)
             m.setLanes(1 if lanes == 1 else 2); m.setGroup(1)
+            if cross:
+                m.setCaptionOrder(False)
             for i in range(n):
                 ref = m.forward_batch(imgs[i:i + 1])[0]
                 for x, y, name in zip(got[i], ref, ("boxes", "scores", "tokens")):

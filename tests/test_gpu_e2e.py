@@ -217,21 +217,85 @@ def test_config3_batch32_300_proposals(model, weights):
         assert t.min() >= 1 and t.max() <= weights["vocab_size"] + 1
 
 
-def test_caption_order_is_output_invariant(model, weights):
-    """dc_set_caption_order(1): final NMS first, decode only the survivors -> bit-identical outputs."""
+def _same(a, b, what=""):
+    for x, y, n in zip(a, b, ("boxes", "scores", "tokens")):
+        np.testing.assert_array_equal(x, y, err_msg="%s %s" % (what, n))
+
+
+# the five BASELINE.json shapes: configs[0] size, configs[1], configs[2] (300 proposals), configs[4], and the webcam regime
+CAPTION_ORDER_SHAPES = [(224, 288, 100, 3), (480, 720, 1000, 7), (600, 720, 1000, 0), (600, 720, 300, 2), (720, 1080, 2000, 5),
+                        (320, 480, 50, 4)]
+
+
+@pytest.mark.parametrize("shape", CAPTION_ORDER_SHAPES, ids=lambda s: "%dx%d_p%d" % (s[1], s[0], s[2]))
+def test_caption_order_is_output_invariant(model, weights, shape):
+    """dc_set_caption_order(1): final NMS first, ONE decode per group over the packed rows it kept -> the same outputs, and
+    by construction: the language-model state of every kept row (image encoder output, final h and c) carries the bits the
+    reference order gives that RoI -- the contraction routes are planned on one image's P rows in either order."""
     from densecap_amd.weights import make_synthetic_image
-    for (H, W, P, seed) in [(224, 288, 100, 3), (600, 720, 1000, 0)]:
-        model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
-        img = make_synthetic_image(H, W, seed)
+    H, W, P, seed = shape
+    E, Hd = weights["lm_enc_w"].shape[0], weights["lstm_w"].shape[1] // 4
+    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
+    img = make_synthetic_image(H, W, seed)
+    try:
+        for lanes in (3, 1):                       # multi-lane planning and single-image mode (two-stream decode in the reference order)
+            model.setLanes(lanes)
+            model.setCaptionOrder(False)
+            ref = model.forward_raw(img)
+            K = len(ref[0])
+            assert 0 < K < P
+            idx = model.debug_fetch("final_nms_idx", (P,), np.int32)[0][:K]
+            state0 = [model.debug_fetch(n, (P, d))[0][idx] for n, d in (("lm_enc", E), ("lm_h", Hd), ("lm_c", Hd))]
+            model.setCaptionOrder(True)
+            out = model.forward_raw(img)
+            _same(ref, out, "lanes=%d" % lanes)
+            assert int(model.debug_fetch("survivor_rows", (1,), np.int32)[0][0]) == K
+            for n, d, want in zip(("lm_enc", "lm_h", "lm_c"), (E, Hd, Hd), state0):
+                np.testing.assert_array_equal(model.debug_fetch(n, (P, d))[0][:K], want, err_msg="%s lanes=%d" % (n, lanes))
+    finally:
         model.setCaptionOrder(False)
-        b0, s0, t0 = model.forward_raw(img)
+        model.setLanes(3)
+
+
+@pytest.mark.parametrize("shape", [(224, 288, 100), (600, 720, 300), (600, 720, 1000)], ids=lambda s: "%dx%d_p%d" % (s[1], s[0], s[2]))
+def test_caption_order_packs_the_survivors_of_a_group(model, weights, shape):
+    """Captions after the final NMS in groups of 1..4 images (one packed decode per group, images with different survivor
+    counts side by side, a ragged last group) == the reference order image by image."""
+    from densecap_amd.weights import make_synthetic_image
+    H, W, P = shape
+    model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
+    imgs = np.stack([make_synthetic_image(H, W, 40 + s) for s in range(7)])
+    try:
+        model.setCaptionOrder(False); model.setGroup(1)
+        ref = model.forward_batch(imgs)
+        assert len({len(r[0]) for r in ref}) > 1, "the images should keep different numbers of boxes"
         model.setCaptionOrder(True)
-        b1, s1, t1 = model.forward_raw(img)
-        model.setCaptionOrder(False)
-        np.testing.assert_array_equal(b0, b1)
-        np.testing.assert_array_equal(s0, s1)
-        np.testing.assert_array_equal(t0, t1)
-        assert 0 < len(b0) < P
+        for g in (1, 2, 3, 4):
+            model.setGroup(g)
+            got = model.forward_batch(imgs)
+            for i, (a, b) in enumerate(zip(ref, got)):
+                _same(a, b, "group=%d image %d" % (g, i))
+    finally:
+        model.setCaptionOrder(False); model.setGroup(0)
+
+
+def test_caption_order_edge_counts(model, weights):
+    """Survivor counts at the edges: final NMS disabled (every RoI survives: the packed block is the whole group), a
+    threshold that keeps a handful of rows, and fewer anchors than proposals."""
+    from densecap_amd.weights import make_synthetic_image
+    imgs = np.stack([make_synthetic_image(96, 128, 60 + s) for s in range(3)])
+    try:
+        for (P, fthr) in [(64, -1.0), (64, 0.0), (64, 1.0), (5000, 0.3), (1, 0.3)]:
+            model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=fthr, num_proposals=P)
+            model.setCaptionOrder(False); model.setGroup(1)
+            ref = model.forward_batch(imgs)
+            model.setCaptionOrder(True); model.setGroup(3)
+            got = model.forward_batch(imgs)
+            for i, (a, b) in enumerate(zip(ref, got)):
+                _same(a, b, "P=%d final_thr=%g image %d" % (P, fthr, i))
+    finally:
+        model.setCaptionOrder(False); model.setGroup(0)
+        model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=100)
 
 
 def test_run_model_cli_writes_results_json(tmp_path):
@@ -394,6 +458,18 @@ def test_randomised_groups_and_lanes_are_pure_scheduling():
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "GROUP FUZZ OK: 12/12" in p.stdout
     assert '"lanes": 1' in p.stdout                      # the seed draws single-image cases
+
+
+def test_randomised_caption_order_is_invisible_in_the_outputs():
+    """tests/fuzz_groups.py with FUZZ_CROSS_ORDER=1: batches decoded AFTER the final NMS (one packed decode per group, random
+    lanes / groups / sizes / thresholds incl. a disabled final NMS) against the reference caption order image by image."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_groups.py"), "16", "11"], capture_output=True,
+                       text=True, timeout=900, env=dict(os.environ, FUZZ_CROSS_ORDER="1"))
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "GROUP FUZZ OK: 16/16" in p.stdout and '"cross_order": true' in p.stdout
 
 
 def test_lane_count_is_a_pure_scheduling_knob(model, weights):
