@@ -381,7 +381,12 @@ def main():
     ap.add_argument("--no-traffic-leg", action="store_true",
                     help="skip the live HBM-traffic / MFMA-utilisation measurement (three rocprofv3 --pmc child passes of this command on one lane); "
                          "`roofline.traffic` is then quoted from the committed profile")
+    ap.add_argument("--no-config-legs", action="store_true",
+                    help="skip the short legs on the other BASELINE.json configs (`configs` in the line: configs[2] 32 x 300 proposals, "
+                         "configs[4] 1080x720 / 2000 proposals, configs[0]'s 720x480 size)")
+    ap.add_argument("--config-leg-seconds", type=float, default=2.0, help="timed seconds per configs leg and caption order")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--stub-rank0-leg-seconds", type=float, default=0.0, help=argparse.SUPPRESS)   # a stand-in for rank 0's own legs (teardown test)
     ap.add_argument("--stub-comm-fail", default="never:-1", help=argparse.SUPPRESS)   # "create:R": StubComm cannot be created on rank R
     args = ap.parse_args()
 
@@ -749,23 +754,64 @@ def main():
         prof = prof_timed
     stage = model.stage_times()
 
+    # ---- every collective of the run is behind us: the process group goes away BEFORE rank 0's own legs ----------------
+    # (round-5 verdict, weak #10: ranks >= 1 used to sit in the closing barrier -- with the nccl backend a spinning GPU kernel
+    # under the 10-minute watchdog -- while rank 0 ran the serial roofline pass, the CPU baseline and the counter passes.)
+    # Everything below is rank 0's alone and uses no collective; the other ranks leave here.
+    had_dist = dist is not None
+    carrier = ("dc_gather_results (%s)" % comm.transport) if comm is not None else None     # what carried the gathers of the timed regions
+    if had_dist:
+        if comm is not None and not abandoned:
+            comm.close()
+            comm = None
+        dist.barrier()
+        if abandoned:
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)               # a carrier call never returned on this rank: no orderly teardown possible
+        dist.destroy_process_group()
+        dist = None
+        print("bench.py[rank %d]: process group destroyed t=%.3f" % (rank, time.time()), file=sys.stderr, flush=True)
+        if rank != 0:
+            return
+    if args.stub and args.stub_rank0_leg_seconds > 0:
+        print("bench.py[rank 0]: own legs begin t=%.3f" % time.time(), file=sys.stderr, flush=True)
+        time.sleep(args.stub_rank0_leg_seconds)
+        print("bench.py[rank 0]: own legs end t=%.3f" % time.time(), file=sys.stderr, flush=True)
+
     # Secondary figure (not `value`): final NMS first, captions only for the surviving boxes -- bit-identical
     # outputs (tests/test_gpu_e2e.py::test_caption_order_is_output_invariant), less LSTM work.
     alt = None
-    if on_gpu and dist is None and not args.no_alt_pass:
+    if on_gpu and not had_dist and not args.no_alt_pass:
         model.setCaptionOrder(True)
-        model.forward_batch_device(imgs, min(2, K), H, W)
+        # its own schedule (both knobs are pure scheduling here too: bit-identical results): the packed decode of a group of four
+        # runs ~900 rows a launch where a single image has ~225, so the pair the reference order picked is not this order's best
+        alt_sched, alt_trial = (args.lanes, args.group), None
+        if args.lanes != 1 and not group_fixed:
+            alt_trial = model.autotuneSchedule(imgs, min(n_img, K), H, W)
+            alt_sched = max(alt_trial, key=alt_trial.get)
+        model.setLanes(alt_sched[0]); model.setGroup(alt_sched[1])
+        model.forward_batch_device(imgs, K, H, W)            # warm
         sync()
-        a0 = time.perf_counter()
-        model.forward_batch_device(imgs, K, H, W)
-        sync()
-        alt = K / (time.perf_counter() - a0)
+        alt_rates, alt_results = [], None
+        for _ in range(5):
+            sync()
+            a0 = time.perf_counter()
+            alt_results = model.forward_batch_device(imgs, K, H, W)
+            sync()
+            alt_rates.append(K / (time.perf_counter() - a0))
         model.setCaptionOrder(False)
+        model.setLanes(args.lanes); model.setGroup(args.group)
+        alt = {"images_per_s": sorted(alt_rates)[len(alt_rates) // 2], "regions": alt_rates, "lanes": alt_sched[0], "group": alt_sched[1],
+               "trial": None if alt_trial is None else {"lanes%d_group%d" % k: v for k, v in alt_trial.items()},
+               "rows_decoded_per_image": float(np.mean([len(b) for b, _, _ in alt_results])),
+               # the SAME images as the last timed region of `value` (reference caption order): every array must be equal
+               "identical": bool(len(alt_results) == len(results) and all(
+                   np.array_equal(x, y) for a_, b_ in zip(alt_results, results) for x, y in zip(a_, b_)))}
     # Secondary figure (NOT `value`, fenced off from the fp32 headline): the same timed region in the opt-in split-bf16
     # arithmetic (dc_set_math_mode(1): operands as three bf16 planes, six partial products on the bf16 matrix cores, fp32
     # accumulate).  Its own roofline object prices it against the bf16 peak / 6.
     split = None
-    if on_gpu and dist is None and args.math_mode == 0 and not args.no_split_leg:
+    if on_gpu and not had_dist and args.math_mode == 0 and not args.no_split_leg:
         model.setMathMode(1)
         model.forward_batch_device(imgs, K, H, W)            # warm (and clocks settle to this mode's power draw)
         sync()
@@ -838,6 +884,78 @@ def main():
         model.setGroup(args.group)
         serial_pass = True
 
+    # ---- the other BASELINE.json configs, on THIS run's clock (round-5 verdict, weak #9: they existed only as builder-run files) --
+    # Short legs of the same product calls at the other configs' shapes, each in both caption orders: warm regions, then timed
+    # regions for >= --config-leg-seconds; the median region is reported.  Schedules are fixed (no trial): the pairs the round-5
+    # trials picked at these shapes (all pairs within 2 % there, except 300 proposals, where groups of four are worth 9 %).
+    config_legs = None
+    if (on_gpu and rank == 0 and world == 1 and not had_dist and not args.no_config_legs and args.math_mode == 0
+            and (H, W, P) == (600, 720, 1000) and "DC_BENCH_CHILD" not in os.environ):
+        config_legs = {}
+        legs = [("configs[2]", "batch of 32 synthetic 720x600 images, 300 proposals each", 600, 720, 300, 32, 2, 4),
+                ("configs[4]", "1080x720 synthetic images, 2000 proposals, 15-token cap", 720, 1080, 2000, 16, 2, 2),
+                ("configs[0]", "720x480 (run_model.lua's elephant.jpg size), 1000 proposals; synthetic image and weights", 480, 720, 1000, 32, 2, 4)]
+        for tag, what, h_, w_, p_, n_, lanes_, group_ in legs:
+            distinct = 8
+            host_c = np.stack([make_synthetic_image(h_, w_, 7000 + 100 * len(config_legs) + i) for i in range(distinct)])
+            dev_c = ctx.to_device(np.concatenate([host_c] * (n_ // distinct)))
+            model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=p_)
+            model.setLanes(lanes_); model.setGroup(group_)
+            leg = {"what": what, "height": h_, "width": w_, "proposals": p_, "images_per_region": n_, "lanes": lanes_, "group": group_}
+            res_by_order = {}
+            for order in (False, True):
+                model.setCaptionOrder(order)
+                for _ in range(2):
+                    model.forward_batch_device(dev_c.ptr, n_, h_, w_)
+                sync()
+                rates, spent, res_c = [], 0.0, None
+                while spent < args.config_leg_seconds or len(rates) < 3:
+                    sync()
+                    c0 = time.perf_counter()
+                    res_c = model.forward_batch_device(dev_c.ptr, n_, h_, w_)
+                    sync()
+                    dt_ = time.perf_counter() - c0
+                    rates.append(n_ / dt_); spent += dt_
+                res_by_order[order] = res_c
+                gf_ = stage_gflop(h_, w_, p_, T, V)
+                fl_ = 1e9 * (sum(gf_.values()) - 2.0 * h_ * w_ * 3 * 64 * 9 / 1e9)       # MFMA family: conv1_1 is its own kernel
+                rows_ = float(np.mean([len(b) for b, _, _ in res_c]))
+                if order:
+                    fl_ -= (p_ - rows_) * gf_["lstm_decode"] * 1e9 / p_                   # only the decoded rows count
+                v_ = sorted(rates)[len(rates) // 2]
+                leg["captions_after_final_nms" if order else "reference_order"] = {
+                    "value": v_, "unit": "images/s", "ms_per_step": 1e3 / v_, "regions": len(rates), "timed_seconds": spent,
+                    "frac": v_ * fl_ / 1e12 / FP32_MFMA_PEAK_TFLOPS, "algorithmic_mfma_gflop_per_image": fl_ / 1e9,
+                    "rows_decoded_per_image": rows_ if order else float(p_)}
+            model.setCaptionOrder(False)
+            leg["value"] = leg["reference_order"]["value"]
+            leg["ms_per_step"] = leg["reference_order"]["ms_per_step"]
+            leg["frac"] = leg["reference_order"]["frac"]
+            leg["caption_orders_identical"] = bool(all(np.array_equal(x, y) for a_, b_ in zip(res_by_order[False], res_by_order[True])
+                                                       for x, y in zip(a_, b_)))
+            if tag == "configs[2]":
+                # BASELINE configs[2] asks for the BilinearRoiPooling throughput of the batch: the stage as this schedule runs it
+                # (one launch per group of four), one stream, multi-lane planning, stage events
+                check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"plan_mode", 0), "dc_debug_set")
+                model.setLanes(1)
+                model.forward_batch_device(dev_c.ptr, group_, h_, w_); sync()
+                model.forward_batch_device(dev_c.ptr, group_, h_, w_); sync()
+                st_ = model.stage_times()
+                check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"plan_mode", args.plan_mode), "dc_debug_set")
+                fh_, fw_ = (h_ + 15) // 16, (w_ + 15) // 16
+                rb_ = 4.0 * 512 * (fh_ * fw_ + p_ * 49) + 16.0 * p_
+                if st_.get("bilinear_roi_pool", 0) > 0:
+                    leg["hbm_stages"] = {"bilinear_roi_pool_grouped": {
+                        "group": group_, "algorithmic_bytes_per_image": rb_, "ms_per_image": st_["bilinear_roi_pool"],
+                        "GBps": rb_ / (st_["bilinear_roi_pool"] * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBPS}}
+                if st_.get("lstm_decode", 0) > 0:
+                    leg["decode_frac"] = stage_gflop(h_, w_, p_, T, V)["lstm_decode"] / st_["lstm_decode"] / FP32_MFMA_PEAK_TFLOPS
+            leg["_check"] = (host_c[0], res_by_order[False][0])              # image 0 and its batch result: the oracle leg below
+            dev_c.free()
+            config_legs[tag] = leg
+        model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
+        model.setLanes(args.lanes); model.setGroup(args.group)
+
     if rank == 0:
         burst = world * K / elapsed
         value, value_source = burst, "median of %d timed regions of %d steps" % (nrep, K)
@@ -864,15 +982,15 @@ def main():
                                    "decode (T=15,V=10497), synthetic weights" % (W, H, P),
                        "images_per_gpu": K, "parallelism": "image-sharded x%d" % world,
                        "total_output_boxes": total_boxes,
-                       "gather": ("dc_gather_results (%s)" % comm.transport) if comm is not None else
-                                 ((None if gather_note is None else "none; " + gather_note) if dist is None else
+                       "gather": carrier if carrier is not None else
+                                 ((None if gather_note is None else "none; " + gather_note) if not had_dist else
                                   "torch.distributed.gather (%s)%s" % (args.dist_backend, "; " + gather_note if gather_note else ""))},
             "repeats": {"n": nrep, "statistic": "median", "images_per_s": [world * K / e for e in elapsed_all],
                         "timed_seconds_total": sum(elapsed_all)},
             "per_rank_images_per_s": per_rank_rates,
             "sustained": sustained,
         }
-        out["config"]["shard_table"] = shard_table(world, K, P, model.seq_length) if dist is not None else None
+        out["config"]["shard_table"] = shard_table(world, K, P, model.seq_length) if had_dist else None
         if host_legs is not None:
             out["value_host_inputs"] = {"pageable": host_legs["pageable"], "pinned": host_legs["pinned"], "unit": "images/s",
                                         "vs_value": {k: v / burst for k, v in host_legs.items()},
@@ -954,7 +1072,7 @@ def main():
                 roof["traffic_from_profile"] = None
             # ... and measured by this run itself when it can be: not under a profiler already, not a child pass, one GPU
             under_profiler = any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH", "ROCPROFILER_LIBRARY_CTOR"))
-            if on_gpu and world == 1 and dist is None and not args.no_traffic_leg and not under_profiler and "DC_BENCH_CHILD" not in os.environ:
+            if on_gpu and world == 1 and not had_dist and not args.no_traffic_leg and not under_profiler and "DC_BENCH_CHILD" not in os.environ:
                 try:
                     live = measure_traffic_live(args)
                     roof["traffic_live"] = live
@@ -1012,7 +1130,23 @@ def main():
             if sched_trials is not None:
                 out["schedule_trial_images_per_s"] = {"lanes%d_group%d" % k: v for k, v in sched_trials.items()}
             if alt is not None:
-                out["value_captions_after_final_nms"] = alt   # same outputs, decode only final-NMS survivors
+                # Captions AFTER the final NMS (dc_set_caption_order(1), what the CLIs run): the same outputs -- compared array by
+                # array with the reference-order results of the last timed region -- with the LSTM run only on the rows the final
+                # NMS kept, ONE packed decode per group.  NOT `value` (which keeps the reference's order).  Its roofline counts the
+                # FLOPs of the rows actually decoded: no credit for the rows it skips.
+                lm_row = gf["lstm_decode"] * 1e9 / P
+                fl = mfma_flops_per_image - (P - alt["rows_decoded_per_image"]) * lm_row
+                out["value_captions_after_final_nms"] = alt["images_per_s"]
+                out["roofline_captions_after_final_nms"] = {
+                    "bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "achieved": alt["images_per_s"] * fl / 1e12, "frac": alt["images_per_s"] * fl / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                    "algorithmic_gflop_per_image": fl / 1e9, "rows_decoded_per_image": alt["rows_decoded_per_image"],
+                    "rows_in_reference_order": P, "regions_images_per_s": alt["regions"], "statistic": "median of 5 regions of %d steps" % K,
+                    "outputs_identical_to_value_regions": alt["identical"], "vs_value": alt["images_per_s"] / burst,
+                    "lanes": alt["lanes"], "group": alt["group"], "schedule_trial_images_per_s": alt["trial"],
+                    "note": "DenseCapModel.lua:261-275 keeps K of the P rows; LanguageModel rows are independent (LanguageModel.lua:293-348), "
+                            "so the captions of the K kept rows are the reference's.  frac = (MFMA FLOPs of trunk, RPN, fc6/fc7 over "
+                            "P rows + language model over the K decoded rows) x images/s / peak, from this leg's own wall time"}
             if split is not None:
                 sp_tf = split["images_per_s"] * mfma_flops_per_image / 1e12
                 out["value_split_bf16"] = split["images_per_s"]
@@ -1040,10 +1174,12 @@ def main():
             # (Measured on the 256-core host of the round-5 box: 16 threads 1.21 s, 32: 1.16 s, 64: 2.35 s, 128: 5.7 s, 256: 93 s
             # per image -- oversubscribed OpenMP teams on small GEMMs.  The trial therefore climbs and stops at the first count
             # that is 1.3x slower than the best so far; what it skipped is named in `sample`.)
-            cands = sorted({c for c in (16, 32, 64, 128, ncores) if c <= ncores} | {min(ncores, 32)})
+            # (round 6: the climb is bounded -- 16 / 32 / 64 threads at most and 45 s of trial in all: beyond 64 every host measured
+            # so far was slower, and one oversubscribed image must not cost minutes)
+            cands = sorted({c for c in (16, 32, 64) if c <= ncores} | {min(ncores, 32)})
             trial, skipped = {}, []
             for c in cands:
-                if trial and min(trial.values()) * 1.3 < list(trial.values())[-1]:
+                if trial and (min(trial.values()) * 1.3 < list(trial.values())[-1] or sum(trial.values()) > 45.0):
                     skipped.append(c)
                     continue
                 torch.set_num_threads(c)
@@ -1054,7 +1190,7 @@ def main():
                 trial[c] = time.perf_counter() - t0_
             nthreads = min(trial, key=trial.get)
             torch.set_num_threads(nthreads)
-            nb = 3
+            nb = 5                                             # (round 6: five images, three before)
             oracle_out, per_image = [], []
             for i in range(nb):
                 c0 = time.perf_counter()
@@ -1119,6 +1255,22 @@ def main():
                                              "over %s of %d host cores%s" % (nb, W, H, P, sorted(trial), ncores,
                                                                              (" (stopped once a count ran 1.3x slower than the best; "
                                                                               "not tried: %s)" % skipped) if skipped else "")}
+            if config_legs:
+                # one image of every configs leg against the oracle: the leg's own batch result, identical or replayed
+                from tests import parity as PAR
+                for tag, leg in config_legs.items():
+                    img0, res0 = leg.pop("_check")
+                    try:
+                        st_ = {}
+                        ora_ = O.forward_test(img0, weights, 0.7, 0.3, leg["proposals"], 15, stages=st_)
+                        model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=leg["proposals"])
+                        rep_ = PAR.final_or_replay(model, O, weights, img0, res0, ora_, st_, leg["proposals"])
+                        flips = len(rep_.get("rpn_flips", [])) + len(rep_.get("final_list_flips", [])) + len(rep_.get("token_near_ties", []))
+                        leg["parity_in_run"] = {"images": 1, "K": len(res0[0]), "K_oracle": len(ora_[0]), "matched": rep_.get("matched"),
+                                                "identical_to_oracle": flips == 0, "decisions_replayed": flips, "passed": True}
+                    except Exception as e:                      # noqa: BLE001 -- a failed check is reported, not hidden
+                        leg["parity_in_run"] = {"images": 1, "passed": False, "error": ("%s: %s" % (type(e).__name__, e))[:300]}
+                model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
             if split is not None:
                 ident3 = 0
                 for i, (ob, osc, oseq) in enumerate(oracle_out[:len(split["results"])]):
@@ -1131,18 +1283,19 @@ def main():
                     ident3 += 1 if ok3 else 0
                 out["parity"]["in_run_split_bf16"] = {"images": min(nb, len(split["results"])), "identical_to_oracle": ident3,
                                                       "rule": "same as in_run (a near-tie may legitimately flip: tests/parity.py replays those)"}
+        if config_legs:
+            for leg in config_legs.values():
+                leg.pop("_check", None)              # (--no-cpu-baseline: no oracle leg ran)
+                leg.setdefault("parity_in_run", {"images": 0, "passed": None, "note": "skipped with --no-cpu-baseline"})
+            out["configs"] = config_legs
         _libc.fflush(None)                       # whatever C code buffered so far (the RCCL banner) goes out BEFORE the line
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)                            # nothing after it reaches stdout (teardown messages of native libraries)
-    if comm is not None:
+    if comm is not None and not abandoned:
         comm.close()
-    if dist is not None:
-        dist.barrier()
     if abandoned:
         sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)                   # a carrier call never returned on this rank: no orderly teardown possible
-    if dist is not None:
-        dist.destroy_process_group()
+        os._exit(0)                   # a carrier call never returned: no orderly teardown possible
 
 
 if __name__ == "__main__":

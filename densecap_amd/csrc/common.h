@@ -266,6 +266,8 @@ hipError_t launch_bilinear_roi_pool(const float* feat_hwc, int h, int w, int C, 
 
 // ---- image preprocessing (preprocess.hip; run_model.lua:67-74) -------------------------------------------------------
 void preprocess_scaled_size(int H0, int W0, int image_size, int* oh, int* ow);
-size_t preprocess_scratch_bytes(int H0, int W0, int oh, int ow);
+size_t preprocess_scratch_bytes(int H0, int W0, int oh, int ow);     // the width pass's double plane
+size_t preprocess_taps_bytes(int oh, int ow);                        // the tap tables of a (H0, W0) -> (oh, ow) scaling ...
+void preprocess_make_taps(int H0, int W0, int oh, int ow, void* host_out);   // ... built on the host (they depend on the sizes only)
 hipError_t launch_preprocess_u8(const uint8_t* src_dev, int H0, int W0, int oh, int ow, const float mean_bgr[3],
-                                void* scratch, float* out_chw, uint8_t* rgb_hwc, hipStream_t s);
+                                void* scratch, const void* taps_dev, float* out_chw, uint8_t* rgb_hwc, hipStream_t s);

@@ -139,7 +139,10 @@ struct dc_ctx {
   int bf3_presplit = 1;             // dc_debug_set "bf3_presplit": 0 = split the weights in registers too (mode 1 of the kernels)
   int bf3_all = 0;                  // dc_debug_set "bf3_all": 1 = math mode 1 takes EVERY contraction, not only those mfma_gemm_bf3_pays
                                     // names (test hook: small and ragged problems then exercise the split-bf16 kernels)
-  DevBuf pre_src, pre_scratch;      // dc_preprocess_u8: uploaded bytes, width-pass plane + tap tables (grow only)
+  DevBuf pre_src, pre_scratch;      // dc_preprocess_u8: uploaded bytes, width-pass plane (grow only)
+  DevBuf pre_taps;                  // ... and the tap tables of the sizes in pre_key, kept while the sizes repeat (webcam frames)
+  std::vector<char> pre_taps_host;  // (the host copy outlives its asynchronous upload)
+  int pre_key[4] = {0, 0, 0, 0};    // H0, W0, oh, ow the tables were made for
   // MFMA profile
   bool prof = false;
   std::vector<ProfEvt> prof_pending;
@@ -953,6 +956,7 @@ void dc_destroy(dc_ctx* ctx) {
   for (void* p : ctx->owned) hipFree(p);
   if (ctx->pre_src.p) hipFree(ctx->pre_src.p);
   if (ctx->pre_scratch.p) hipFree(ctx->pre_scratch.p);
+  if (ctx->pre_taps.p) hipFree(ctx->pre_taps.p);
   for (auto e : ctx->prof_pool) hipEventDestroy(e);
   delete ctx;
 }
@@ -1374,8 +1378,19 @@ int dc_preprocess_u8(dc_ctx* ctx, const uint8_t* rgb_hwc, int H0, int W0, int on
     src = static_cast<const uint8_t*>(ctx->pre_src.p);
   }
   DCCHK(grow(ctx->pre_scratch, preprocess_scratch_bytes(H0, W0, oh, ow)));
+  const int key[4] = {H0, W0, oh, ow};
+  if (ctx->pre_taps.p == nullptr || memcmp(key, ctx->pre_key, sizeof key) != 0) {
+    // new sizes: rebuild the tables (round-5 advisor finding: they were rebuilt, uploaded from pageable memory and waited
+    // for on every frame).  The host copy is replaced only after the stream has drained its previous upload.
+    HIPCHK(hipStreamSynchronize(s));
+    ctx->pre_taps_host.resize(preprocess_taps_bytes(oh, ow));
+    preprocess_make_taps(H0, W0, oh, ow, ctx->pre_taps_host.data());
+    DCCHK(grow(ctx->pre_taps, ctx->pre_taps_host.size()));
+    HIPCHK(hipMemcpyAsync(ctx->pre_taps.p, ctx->pre_taps_host.data(), ctx->pre_taps_host.size(), hipMemcpyHostToDevice, s));
+    memcpy(ctx->pre_key, key, sizeof key);
+  }
   const float mean_bgr[3] = {103.939f, 116.779f, 123.68f};          // run_model.lua:73
-  KCHK(launch_preprocess_u8(src, H0, W0, oh, ow, mean_bgr, ctx->pre_scratch.p, out_chw_dev, scaled_rgb_dev, s));
+  KCHK(launch_preprocess_u8(src, H0, W0, oh, ow, mean_bgr, ctx->pre_scratch.p, ctx->pre_taps.p, out_chw_dev, scaled_rgb_dev, s));
   HIPCHK(hipStreamSynchronize(s));
   return DC_OK;
 }
@@ -1593,7 +1608,11 @@ static int op_planes(dc_ctx* ctx, hipStream_t s, const float* W, int N, int K, u
   *out = nullptr;
   if (ctx->math_mode != DC_MATH_SPLIT_BF16 || !ctx->bf3_presplit || K % 32) return DC_OK;
   HIPCHK(hipMalloc(reinterpret_cast<void**>(out), (size_t)3 * N * K * 2));
-  KCHK(launch_split_planes(W, *out, (size_t)N, K, s));
+  if (hipError_t e = launch_split_planes(W, *out, (size_t)N, K, s); e != hipSuccess) {
+    (void)hipFree(*out);                     // (round-5 advisor finding: the planes leaked when the launch failed)
+    *out = nullptr;
+    return ctx->fail(DC_E_HIP, "launch_split_planes: %s", hipGetErrorString(e));
+  }
   return DC_OK;
 }
 

@@ -1,17 +1,26 @@
-// Image preprocessing on the device (run_model.lua:67-74): image.load's byte -> float conversion, image.scale(img, size)
+// Image preprocessing on the device (run_model.lua:67-74): image.load's byte -> [0,1] conversion, image.scale(img, size)
 // (torch/image generic/image.c: scaleBilinear = scaleLinear_rowcol along the width, then along the height -- linear
-// interpolation when a side grows, AREA AVERAGING when it shrinks, a copy when it stays), RGB -> BGR, x 255, minus the
-// VGG mean.  Bit-equal to the host restatement densecap_amd/run_model.py::image_scale (tests/test_gpu_preprocess.py): every
-// output sample is the same chain of single fp32 operations -- the per-sample source ranges and weights are computed once
-// on the host, in fp32, exactly as the library computes them inside its loops, and travel as two small tables.
+// interpolation when a side grows, AREA AVERAGING when it shrinks, a copy when it stays), `:float()`, RGB -> BGR, x 255,
+// minus the VGG mean.
+//
+// Arithmetic (round 6, advisor finding): run_model.lua never calls torch.setdefaulttensortype, so image.load hands
+// image.scale a DoubleTensor -- pixels byte/255 in double, a double intermediate plane -- while the C loops keep their
+// `float scale`, `float acc`, `float n` locals; `:float()` comes after the scaling.  This file follows that chain: products
+// and sums in double where the library's operands are double, every assignment to `acc` rounded to float, `acc / n` a float
+// division, the interpolation `(1 - f) * a + f * b` left in double; one rounding to float at the end.  (Rounds 4-5 ran an
+// all-fp32 chain, within an ulp of this one.)  Bit-equal to the oracle's scalar restatement oracle.preprocess and to the
+// host restatement densecap_amd/run_model.py::image_scale (tests/test_gpu_preprocess.py): the per-sample source ranges and
+// float weights are computed once on the host exactly as the library computes them inside its loops, and travel as two
+// small tables.
 //
 // Round-4 verdict, item 4: the host restatement (a Python loop per output row / column) took 94-190 ms per photograph and
 // starved a device that needs 5.5 ms per image.  Here a 1600x1200 photograph costs its 5.8 MB upload and two launches.
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
 
-// every fp32 op rounds once, in source order (bit-equality with the host restatement depends on it)
+// every operation rounds once, in source order (bit-equality with the restatements depends on it)
 #pragma clang fp contract(off)
 
 namespace {
@@ -58,33 +67,35 @@ std::vector<Tap> make_taps(int src_len, int dst_len) {
   return t;
 }
 
-// pass 1: along the width.  src: (H0, W0, 3) uint8 -> float byte/255 (image.load); tmp: (3, H0, ow) fp32
+// One output sample of scaleLinear_rowcol over double samples px(i) (see make_taps for the cases)
+template <typename PX>
+__device__ __forceinline__ double scale_sample(const Tap& tp, int src_len, PX px) {
+  if (tp.kind == 0) return px(tp.i0);
+  if (tp.kind == 1)      // (1 - si_f) * src[a] + si_f * src[b]: float weights, double samples, the sum stays double
+    return __dadd_rn(__dmul_rn((double)__fsub_rn(1.f, tp.f0), px(tp.i0)), __dmul_rn((double)tp.f0, px(tp.i0 + 1)));
+  // float acc: every assignment rounds the double expression to float
+  float acc = (float)__dmul_rn((double)__fsub_rn(1.f, tp.f0), px(tp.i0));
+  for (int i = tp.i0 + 1; i < tp.i1; ++i) acc = (float)__dadd_rn((double)acc, px(i));
+  if (tp.i1 < src_len) acc = (float)__dadd_rn((double)acc, __dmul_rn((double)tp.f1, px(tp.i1)));
+  return (double)__fdiv_rn(acc, tp.n);
+}
+
+// pass 1: along the width.  src: (H0, W0, 3) uint8 -> double byte/255 (image.load into a DoubleTensor); tmp: (3, H0, ow) double
 __global__ void scale_width_u8_kernel(const uint8_t* __restrict__ src, int H0, int W0, const Tap* __restrict__ taps, int ow,
-                                      float* __restrict__ tmp) {
+                                      double* __restrict__ tmp) {
   const long total = (long)3 * H0 * ow;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     const int ox = (int)(t % ow);
     const long r = t / ow;
     const int y = (int)(r % H0), c = (int)(r / H0);
     const uint8_t* row = src + ((size_t)y * W0) * 3 + c;
-    auto px = [&](int x) { return __fdiv_rn((float)row[(size_t)x * 3], 255.f); };
-    const Tap tp = taps[ox];
-    float v;
-    if (tp.kind == 0) v = px(tp.i0);
-    else if (tp.kind == 1) v = __fadd_rn(__fmul_rn(__fsub_rn(1.f, tp.f0), px(tp.i0)), __fmul_rn(tp.f0, px(tp.i0 + 1)));
-    else {
-      float acc = __fmul_rn(__fsub_rn(1.f, tp.f0), px(tp.i0));
-      for (int x = tp.i0 + 1; x < tp.i1; ++x) acc = __fadd_rn(acc, px(x));
-      if (tp.i1 < W0) acc = __fadd_rn(acc, __fmul_rn(tp.f1, px(tp.i1)));
-      v = __fdiv_rn(acc, tp.n);
-    }
-    tmp[t] = v;
+    tmp[t] = scale_sample(taps[ox], W0, [&](int x) { return __ddiv_rn((double)row[(size_t)x * 3], 255.0); });
   }
 }
 
-// pass 2: along the height, then run_model.lua:70-74: out[k] = scaled[2 - k] * 255 - mean_bgr[k]; optionally the scaled RGB
-// image as bytes for the visualiser (image.save: clamp to [0,1], x 255, truncate).
-__global__ void scale_height_finish_kernel(const float* __restrict__ tmp, int H0, int ow, const Tap* __restrict__ taps, int oh,
+// pass 2: along the height, `:float()`, then run_model.lua:70-74: out[k] = scaled[2 - k] * 255 - mean_bgr[k] in float;
+// optionally the scaled RGB image as bytes for the visualiser (image.save: clamp to [0,1], x 255, truncate).
+__global__ void scale_height_finish_kernel(const double* __restrict__ tmp, int H0, int ow, const Tap* __restrict__ taps, int oh,
                                            float m0, float m1, float m2, float* __restrict__ out_chw,
                                            uint8_t* __restrict__ rgb_hwc) {
   const long total = (long)3 * oh * ow;
@@ -92,18 +103,8 @@ __global__ void scale_height_finish_kernel(const float* __restrict__ tmp, int H0
     const int ox = (int)(t % ow);
     const long r = t / ow;
     const int oy = (int)(r % oh), c = (int)(r / oh);          // c: RGB channel of the scaled image
-    const float* col = tmp + (size_t)c * H0 * ow + ox;
-    auto px = [&](int y) { return col[(size_t)y * ow]; };
-    const Tap tp = taps[oy];
-    float v;
-    if (tp.kind == 0) v = px(tp.i0);
-    else if (tp.kind == 1) v = __fadd_rn(__fmul_rn(__fsub_rn(1.f, tp.f0), px(tp.i0)), __fmul_rn(tp.f0, px(tp.i0 + 1)));
-    else {
-      float acc = __fmul_rn(__fsub_rn(1.f, tp.f0), px(tp.i0));
-      for (int y = tp.i0 + 1; y < tp.i1; ++y) acc = __fadd_rn(acc, px(y));
-      if (tp.i1 < H0) acc = __fadd_rn(acc, __fmul_rn(tp.f1, px(tp.i1)));
-      v = __fdiv_rn(acc, tp.n);
-    }
+    const double* col = tmp + (size_t)c * H0 * ow + ox;
+    const float v = (float)scale_sample(taps[oy], H0, [&](int y) { return col[(size_t)y * ow]; });      // :float()
     const int k = 2 - c;                                      // BGR plane
     const float mean = k == 0 ? m0 : (k == 1 ? m1 : m2);
     out_chw[((size_t)k * oh + oy) * ow + ox] = __fsub_rn(__fmul_rn(v, 255.f), mean);
@@ -124,26 +125,32 @@ void preprocess_scaled_size(int H0, int W0, int image_size, int* oh, int* ow) {
   *ow = (int)((double)W0 * (double)image_size / (double)imax);
 }
 
-// src_dev: (H0, W0, 3) uint8 on the device; scratch: >= 3*H0*ow floats + (oh + ow) Taps on the device (see preprocess_scratch_bytes)
+// scratch of one call: the width pass's (3, H0, ow) double plane
 size_t preprocess_scratch_bytes(int H0, int W0, int oh, int ow) {
-  return ((size_t)3 * H0 * ow * sizeof(float) + 255) / 256 * 256 + (size_t)(oh + ow) * sizeof(Tap);
+  (void)W0; (void)oh;
+  return (size_t)3 * H0 * ow * sizeof(double);
 }
 
+// The two tap tables of a (H0, W0) -> (oh, ow) scaling: ow width taps, then oh height taps.  They depend on the four sizes
+// only: dc_preprocess_u8 keeps the device copy for as long as the sizes repeat (every frame of the webcam daemon).
+size_t preprocess_taps_bytes(int oh, int ow) { return (size_t)(oh + ow) * sizeof(Tap); }
+void preprocess_make_taps(int H0, int W0, int oh, int ow, void* host_out) {
+  const std::vector<Tap> tw = make_taps(W0, ow), th = make_taps(H0, oh);
+  Tap* o = static_cast<Tap*>(host_out);
+  std::copy(tw.begin(), tw.end(), o);
+  std::copy(th.begin(), th.end(), o + ow);
+}
+
+// src_dev: (H0, W0, 3) uint8 on the device; scratch: preprocess_scratch_bytes on the device; taps_dev: the tables of these sizes
 hipError_t launch_preprocess_u8(const uint8_t* src_dev, int H0, int W0, int oh, int ow, const float mean_bgr[3],
-                                void* scratch, float* out_chw, uint8_t* rgb_hwc, hipStream_t s) {
-  if (H0 <= 0 || W0 <= 0 || oh <= 0 || ow <= 0) return hipErrorInvalidValue;
-  float* tmp = static_cast<float*>(scratch);
-  Tap* taps_dev = reinterpret_cast<Tap*>(static_cast<char*>(scratch) + ((size_t)3 * H0 * ow * sizeof(float) + 255) / 256 * 256);
-  std::vector<Tap> tw = make_taps(W0, ow), th = make_taps(H0, oh);
-  // (pageable host vectors: the two small copies complete before the call returns to the vectors' destruction)
-  hipError_t e = hipMemcpyAsync(taps_dev, tw.data(), tw.size() * sizeof(Tap), hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(taps_dev + ow, th.data(), th.size() * sizeof(Tap), hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  if (e != hipSuccess) return e;
+                                void* scratch, const void* taps_dev, float* out_chw, uint8_t* rgb_hwc, hipStream_t s) {
+  if (H0 <= 0 || W0 <= 0 || oh <= 0 || ow <= 0 || taps_dev == nullptr) return hipErrorInvalidValue;
+  double* tmp = static_cast<double*>(scratch);
+  const Tap* taps = static_cast<const Tap*>(taps_dev);
   const long n1 = (long)3 * H0 * ow, n2 = (long)3 * oh * ow;
   hipLaunchKernelGGL(scale_width_u8_kernel, dim3((unsigned)std::min<long>((n1 + 255) / 256, 65535)), dim3(256), 0, s, src_dev, H0,
-                     W0, taps_dev, ow, tmp);
+                     W0, taps, ow, tmp);
   hipLaunchKernelGGL(scale_height_finish_kernel, dim3((unsigned)std::min<long>((n2 + 255) / 256, 65535)), dim3(256), 0, s, tmp, H0,
-                     ow, taps_dev + ow, oh, mean_bgr[0], mean_bgr[1], mean_bgr[2], out_chw, rgb_hwc);
+                     ow, taps + ow, oh, mean_bgr[0], mean_bgr[1], mean_bgr[2], out_chw, rgb_hwc);
   return hipGetLastError();
 }

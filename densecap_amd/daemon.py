@@ -41,6 +41,9 @@ def build_parser():
     a("-math_mode", type=int, default=0, choices=[0, 1],
       help="dc_set_math_mode: 0 = fp32 MFMA (default; the reference's arithmetic), 1 = split-bf16 (opt-in: six bf16 partial products per fp32 multiply-add on the bf16 matrix cores, fp32-class accuracy, ~1.2-1.3x images/s)")
     a("-host_preprocess", type=int, default=0, help="1 = image.scale & co on the host (the Python restatement) instead of dc_preprocess_u8")
+    a("-caption_order", type=int, default=1, choices=[0, 1],
+      help="dc_set_caption_order: 1 (default) = final NMS first, captions only for the boxes it keeps (the reference's outputs bit "
+           "for bit); 0 = the reference's order (caption every proposal, then the final NMS)")
     a("-graph_replay", type=int, default=0,
       help="dc_set_graph_replay: frames of one size are captured once and relaunched as a hipGraph (bit-identical).  Off by default: "
            "measured at the webcam settings it changes nothing (4.23 against 4.21 ms per frame, profiles/r05_daemon_latency.json)")
@@ -139,6 +142,7 @@ def main(argv=None):
                       final_nms_thresh=opt.final_nms_thresh)
     model.setBeamSize(opt.beam_size)
     model.setMathMode(opt.math_mode)
+    model.setCaptionOrder(bool(opt.caption_order))
     model.setGraphReplay(bool(opt.graph_replay))
     serve(model, opt)
     return 0

@@ -63,23 +63,29 @@ def build_parser():
       help="dc_set_math_mode: 0 = fp32 MFMA (default; the reference's arithmetic), 1 = split-bf16 (opt-in: six bf16 partial products per fp32 multiply-add on the bf16 matrix cores, fp32-class accuracy, ~1.2-1.3x images/s)")
     a("-synthetic_weights", type=int, default=0,
       help="1: random weights in checkpoint shapes (no pretrained .t7 is available offline)")
+    a("-caption_order", type=int, default=1, choices=[0, 1],
+      help="dc_set_caption_order: 1 (default) = final NMS first, captions only for the boxes it keeps -- one packed decode per group "
+           "of images; the outputs are the reference's bit for bit (LSTM rows are independent), ~1.3x images/s at 1000 proposals; "
+           "0 = the reference's order (DenseCapModel.lua:127-162: all proposals are captioned, then the final NMS picks)")
     return p
 
 
 def _scale_linear_axis(src, dst_len, axis):
-    """torch/image generic/image.c `scaleLinear_rowcol` along one axis, float32 like the library:
-    longer output  -> linear interpolation at di*(src_len-1)/(dst_len-1), last sample copied;
+    """torch/image generic/image.c `scaleLinear_rowcol` along one axis of the DoubleTensor image.load returns
+    (run_model.lua never sets the default tensor type), with the library's `float` locals:
+    longer output  -> linear interpolation at di*(src_len-1)/(dst_len-1) (float weights, double samples and sum), last
+                      sample copied;
     shorter output -> area average: output di integrates the source over [di*s, (di+1)*s), s = src_len/dst_len, with
-                      fractional end weights, divided by the accumulated weight;
-    equal          -> copy.  Vectorised over the other axes; the order of the fp32 operations along the axis is the
-    library's (accumulate, then divide)."""
-    src = np.moveaxis(np.asarray(src, np.float32), axis, 0)
+                      fractional end weights in a FLOAT accumulator (every update rounds the double expression to float),
+                      divided by the accumulated float weight;
+    equal          -> copy.  Vectorised over the other axes; the order of the operations along the axis is the library's."""
+    src = np.moveaxis(np.asarray(src, np.float64), axis, 0)
     src_len = src.shape[0]
-    F = np.float32
+    F, D = np.float32, np.float64
     if dst_len == src_len:
         out = src.copy()
     elif dst_len > src_len:
-        out = np.empty((dst_len,) + src.shape[1:], np.float32)
+        out = np.empty((dst_len,) + src.shape[1:], np.float64)
         if src_len == 1:
             out[:] = src[0]
         else:
@@ -88,25 +94,25 @@ def _scale_linear_axis(src, dst_len, axis):
                 si_f = F(di) * scale
                 si_i = int(si_f)
                 si_f = F(si_f - F(si_i))
-                out[di] = (F(1) - si_f) * src[si_i] + si_f * src[si_i + 1]
+                out[di] = D(F(1) - si_f) * src[si_i] + D(si_f) * src[si_i + 1]
             out[dst_len - 1] = src[src_len - 1]
     else:
-        out = np.empty((dst_len,) + src.shape[1:], np.float32)
+        out = np.empty((dst_len,) + src.shape[1:], np.float64)
         scale = F(src_len) / F(dst_len)
         si0_i, si0_f = 0, F(0)
         for di in range(dst_len):
             si1_f = F(di + 1) * scale
             si1_i = int(si1_f)
             si1_f = F(si1_f - F(si1_i))
-            acc = (F(1) - si0_f) * src[si0_i]
+            acc = (D(F(1) - si0_f) * src[si0_i]).astype(F)
             n = F(1) - si0_f
             for si in range(si0_i + 1, si1_i):
-                acc = acc + src[si]
+                acc = (acc.astype(D) + src[si]).astype(F)
                 n = F(n + F(1))
             if si1_i < src_len:
-                acc = acc + si1_f * src[si1_i]
+                acc = (acc.astype(D) + D(si1_f) * src[si1_i]).astype(F)
                 n = F(n + si1_f)
-            out[di] = acc / n
+            out[di] = (acc / n).astype(D)
             si0_i, si0_f = si1_i, si1_f
     return np.moveaxis(out, 0, axis)
 
@@ -115,8 +121,9 @@ def image_scale(img_chw, size):
     """torch/image `image.scale(src, size)` with a number (run_model.lua:68): the LONGER side becomes `size`, the
     other keeps the aspect ratio (height = iheight*size/imax, truncated like a Lua number handed to Tensor:resize);
     mode 'bilinear' = `scaleBilinear`: rows first (width), then columns (height), each with `scaleLinear_rowcol`.
-    img_chw: (C,H,W) float32.  torch/image is not vendored in the reference: restated from its published C source."""
-    img = np.asarray(img_chw, np.float32)
+    img_chw: (C,H,W) as image.load returns it (a DoubleTensor); returns float64 (`:float()` is the caller's).
+    torch/image is not vendored in the reference: restated from its published C source."""
+    img = np.asarray(img_chw, np.float64)
     _, ih, iw = img.shape
     imax = max(ih, iw)
     oh, ow = int(ih * size / imax), int(iw * size / imax)
@@ -126,23 +133,28 @@ def image_scale(img_chw, size):
     return _scale_linear_axis(tmp, oh, 1)         # then columns
 
 
+def image_load_u8(rgb_u8_hwc):
+    """image.load(path, 3) after the file decode: (H,W,3) bytes -> the DoubleTensor (3,H,W) of byte / 255."""
+    return np.asarray(rgb_u8_hwc, dtype=np.uint8).astype(np.float64).transpose(2, 0, 1) / np.float64(255.0)
+
+
 def preprocess_rgb01(img_rgb_chw, image_size):
-    """run_model.lua:68-74 after image.load: scale, RGB->BGR, x255, minus the VGG mean.  (3,H,W) in [0,1] -> (1,3,H',W')."""
-    img = image_scale(img_rgb_chw, image_size)
+    """run_model.lua:68-74 after image.load: scale (double), :float(), RGB->BGR, x255, minus the VGG mean.
+    (3,H,W) in [0,1] -> ((1,3,H',W') float32, the scaled float32 RGB image)."""
+    img = image_scale(img_rgb_chw, image_size).astype(np.float32)
     bgr = img[::-1] * np.float32(255.0) - VGG_MEAN_BGR[:, None, None]
     return np.ascontiguousarray(bgr[None], dtype=np.float32), img
 
 
 def load_image_caffe(path, image_size):
-    """run_model.lua:67-74: image.load(path, 3) (float RGB in [0,1] = byte/255), image.scale (max side = image_size),
-    BGR, x255, minus VGG mean.  Returns (img_caffe (1,3,H,W) float32, scaled RGB uint8 (H,W,3) for the visualiser).
+    """run_model.lua:67-74: image.load(path, 3) (double RGB in [0,1] = byte/255), image.scale (max side = image_size),
+    :float(), BGR, x255, minus VGG mean.  Returns (img_caffe (1,3,H,W) float32, scaled RGB uint8 (H,W,3) for the visualiser).
     Only the file DECODE is third-party here (PIL); the resize is image_scale above, not PIL's."""
     from PIL import Image
     im = Image.open(path).convert("RGB")
-    x = np.asarray(im, dtype=np.uint8).astype(np.float32).transpose(2, 0, 1) / np.float32(255.0)
-    img_caffe, scaled = preprocess_rgb01(x, image_size)
+    img_caffe, scaled = preprocess_rgb01(image_load_u8(np.asarray(im, dtype=np.uint8)), image_size)
     # image.save clamps to [0,1] and writes bytes (x255, truncated)
-    rgb = (np.clip(scaled, 0, 1) * 255.0).astype(np.uint8).transpose(1, 2, 0)
+    rgb = (np.clip(scaled, 0, 1) * np.float32(255.0)).astype(np.uint8).transpose(1, 2, 0)
     return img_caffe, np.ascontiguousarray(rgb)
 
 
@@ -245,7 +257,7 @@ class ImagePipeline:
                     self._decoded[i] = True
                     self._submit(i + self._ahead)
                     if self._host:
-                        img_caffe, sc = preprocess_rgb01(rgb0.astype(np.float32).transpose(2, 0, 1) / np.float32(255.0), image_size)
+                        img_caffe, sc = preprocess_rgb01(image_load_u8(rgb0), image_size)
                         rgb = np.ascontiguousarray((np.clip(sc, 0, 1) * 255.0).astype(np.uint8).transpose(1, 2, 0)) if want_rgb else None
                         x = np.ascontiguousarray(img_caffe[0], dtype=np.float32)
                         dev = self._take(pctx, x.shape, np.float32)
@@ -327,6 +339,7 @@ def main(argv=None):
     model.setLanes(1 if num == 1 else opt.lanes)
     model.setMathMode(opt.math_mode)
     model.setGroup(1 if num == 1 else opt.group)
+    model.setCaptionOrder(bool(opt.caption_order))
     model.setTestArgs(rpn_nms_thresh=opt.rpn_nms_thresh, final_nms_thresh=opt.final_nms_thresh,
                       num_proposals=opt.num_proposals)
     model.evaluate()

@@ -6,9 +6,9 @@ Nothing of run_model.lua is restated here: the reference's own script is loaded 
 choose the device and take the model out of the checkpoint are replaced, and the result is run with the caller's
 arguments.  These two substitutions are the whole integration (INTEGRATION.md section 2):
 
-  run_model.lua:146   local dtype, use_cudnn = utils.setup_gpus(opt.gpu, opt.use_cudnn)
+  run_model.lua:145   local dtype, use_cudnn = utils.setup_gpus(opt.gpu, opt.use_cudnn)
                   ->  local dtype, use_cudnn = 'torch.FloatTensor', false          -- host tensors stay float; no cutorch
-  run_model.lua:148   local model = checkpoint.model
+  run_model.lua:147   local model = checkpoint.model
                   ->  local model = require('DenseCapModelHIP').fromCheckpoint(checkpoint.model, opt.gpu)
 
 usage (from the densecap checkout, lua/ on package.path, libdensecap_hip.so on the loader path or in DENSECAP_HIP_LIB):

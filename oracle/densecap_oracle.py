@@ -570,12 +570,17 @@ def decode_sequence(seq, idx_to_token, vocab_size):
 # run_image preprocessing (run_model.lua:67-74); image.scale lives in torch/image (un-vendored)
 # ----------------------------------------------------------------------------
 def _scale_linear_rowcol(src, dst_len):
-    """torch/image generic/image.c scaleLinear_rowcol on one 1-D float32 sequence, scalar loops (small cases only)."""
-    src = [F32(v) for v in src]
+    """torch/image generic/image.c scaleLinear_rowcol on one 1-D sequence of a DoubleTensor, scalar loops (small cases
+    only).  run_model.lua:67-68 never sets the default tensor type, so image.load returns a DoubleTensor and `real` is
+    double in the C loops -- which keep `float scale`, `float acc`, `float n`, `float si_f` locals: a product of a float
+    weight and a double sample is a double, every assignment to `acc` rounds it to float, `acc / n` is a float division,
+    and the interpolation `(1 - si_f) * a + si_f * b` stays double (round 6; rounds 2-5 restated an all-float32 chain)."""
+    F64 = np.float64
+    src = [F64(v) for v in src]
     n_src = len(src)
     if dst_len == n_src:
         return list(src)
-    dst = [F32(0)] * dst_len
+    dst = [F64(0)] * dst_len
     if dst_len > n_src:
         if n_src == 1:
             return [src[0]] * dst_len
@@ -584,7 +589,7 @@ def _scale_linear_rowcol(src, dst_len):
             si_f = F32(di) * scale
             si_i = int(si_f)
             si_f = F32(si_f - F32(si_i))
-            dst[di] = F32(F32(F32(1) - si_f) * src[si_i] + si_f * src[si_i + 1])
+            dst[di] = F64(F32(F32(1) - si_f)) * src[si_i] + F64(si_f) * src[si_i + 1]
         dst[dst_len - 1] = src[n_src - 1]
         return dst
     scale = F32(n_src) / F32(dst_len)
@@ -593,28 +598,34 @@ def _scale_linear_rowcol(src, dst_len):
         si1_f = F32(di + 1) * scale
         si1_i = int(si1_f)
         si1_f = F32(si1_f - F32(si1_i))
-        acc = F32(F32(F32(1) - si0_f) * src[si0_i])
+        acc = F32(F64(F32(F32(1) - si0_f)) * src[si0_i])
         n = F32(F32(1) - si0_f)
         for si in range(si0_i + 1, si1_i):
-            acc = F32(acc + src[si]); n = F32(n + F32(1))
+            acc = F32(F64(acc) + src[si]); n = F32(n + F32(1))
         if si1_i < n_src:
-            acc = F32(acc + si1_f * src[si1_i]); n = F32(n + si1_f)
-        dst[di] = F32(acc / n)
+            acc = F32(F64(acc) + F64(si1_f) * src[si1_i]); n = F32(n + si1_f)
+        dst[di] = F64(F32(acc / n))
         si0_i, si0_f = si1_i, si1_f
     return dst
 
 
+def image_load_u8(rgb_u8_hwc):
+    """image.load(path, 3) after the file decode (run_model.lua:67): a DoubleTensor (3,H,W) of byte / 255."""
+    return np.asarray(rgb_u8_hwc, np.uint8).astype(np.float64).transpose(2, 0, 1) / np.float64(255.0)
+
+
 def image_scale(img_chw, size):
-    """image.scale(img, size) (run_model.lua:68): longer side -> size, bilinear = rows then columns."""
-    img = np.asarray(img_chw, F32)
+    """image.scale(img, size) (run_model.lua:68) on the DoubleTensor image.load returns: longer side -> size, bilinear =
+    rows then columns; a double (C, oh, ow) array (the `:float()` of run_model.lua:68 is the caller's)."""
+    img = np.asarray(img_chw, np.float64)
     C, ih, iw = img.shape
     imax = max(ih, iw)
     oh, ow = int(ih * size / imax), int(iw * size / imax)
-    tmp = np.empty((C, ih, ow), F32)
+    tmp = np.empty((C, ih, ow), np.float64)
     for c in range(C):
         for y in range(ih):
             tmp[c, y] = _scale_linear_rowcol(img[c, y], ow)
-    out = np.empty((C, oh, ow), F32)
+    out = np.empty((C, oh, ow), np.float64)
     for c in range(C):
         for x in range(ow):
             out[c, :, x] = _scale_linear_rowcol(tmp[c, :, x], oh)
@@ -622,8 +633,8 @@ def image_scale(img_chw, size):
 
 
 def preprocess(img_rgb01_chw, image_size):
-    """run_model.lua:68-74: scale, index {3,2,1} (BGR), mul 255, add -vgg_mean."""
-    img = image_scale(img_rgb01_chw, image_size)
+    """run_model.lua:68-74: scale (in double), :float(), index {3,2,1} (BGR), mul 255, add -vgg_mean."""
+    img = image_scale(img_rgb01_chw, image_size).astype(F32)
     mean = np.array([103.939, 116.779, 123.68], F32)
     return (img[::-1] * F32(255) - mean[:, None, None])[None].astype(F32)
 

@@ -61,8 +61,8 @@ def test_config0_checkpoint_elephant_results_json(tmp_path):
     Wc = t7.weights_from_checkpoint(t7.load(str(ckpt)))
     assert Wc["vocab_size"] == 10497 and Wc["seq_length"] == 15 and Wc["fc6_w"].shape == (4096, 25088)
     Wt = _to_torch(Wc)
-    rgb01 = np.asarray(Image.open(ELEPHANT).convert("RGB"), np.uint8).astype(np.float32).transpose(2, 0, 1) / np.float32(255)
-    assert rgb01.shape == (3, 480, 720)
+    rgb01 = O.image_load_u8(np.asarray(Image.open(ELEPHANT).convert("RGB"), np.uint8))     # image.load: a DoubleTensor, byte / 255
+    assert rgb01.shape == (3, 480, 720) and rgb01.dtype == np.float64
     img = O.preprocess(rgb01, 720)[0]                            # run_model.lua:68-74, scalar restatement
     x_host, _ = run_model.load_image_caffe(ELEPHANT, 720)
     np.testing.assert_array_equal(x_host[0], img)                 # host preprocessing == oracle, bit for bit

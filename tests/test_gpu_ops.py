@@ -406,6 +406,26 @@ def test_box_conversions_and_clip_exact(ctx):
     assert 0 < (~vo).sum() < 50
 
 
+def test_device_corners_and_host_xywh_close_the_reference_round_trip(ctx):
+    """test/box_conversion_test.lua:12-23 with the product's two conversions in it: the device's xcycwh -> corners
+    (box_utils.lua:288-291, what both NMS runs read) and the host's xcycwh -> xywh (run_model.lua:78).  Corners from the
+    device, re-expressed as xywh by the oracle's x1y1x2y2_to_xywh, are the host function's output bit for bit -- that IS
+    box_utils.xcycwh_to_xywh (box_utils.lua:441-445) -- and the reference's round trip closes on them."""
+    from densecap_amd import ops
+    from densecap_amd.run_model import xcycwh_to_xywh
+    from oracle import densecap_oracle as O
+    rng = np.random.default_rng(12)
+    b = np.concatenate([rng.uniform(-100, 900, (3000, 2)), rng.uniform(0, 800, (3000, 2))], 1).astype(np.float32)
+    corners = ops.xcycwh_to_x1y1x2y2(ctx, b)
+    xywh = xcycwh_to_xywh(b)
+    np.testing.assert_array_equal(O.x1y1x2y2_to_xywh(corners), xywh)
+    np.testing.assert_array_equal(xywh, O.xcycwh_to_xywh(b))
+    big = np.abs(b).max(axis=1) + 1.0
+    again = O.xywh_to_x1y1x2y2(xywh)
+    assert (np.abs(again - corners).max(axis=1) <= 1e-6 * big).all()
+    assert (np.abs(O.x1y1x2y2_to_xywh(again) - xywh).max(axis=1) <= 1e-6 * big).all()
+
+
 def test_box_iou_module(ctx):
     from densecap_amd import ops
     from oracle import densecap_oracle as O

@@ -1,4 +1,5 @@
-"""dc_preprocess_u8 (run_model.lua:67-74 on the device; round-4 verdict item 4): bit-equal to the host restatement
+"""dc_preprocess_u8 (run_model.lua:67-74 on the device; round-4 verdict item 4): bit-equal to the ORACLE's scalar restatement
+oracle.preprocess (round-5 verdict, weak #7: directly, on the small shapes) and to the host restatement
 densecap_amd/run_model.py::image_scale + BGR / x255 / mean, over shrinking, growing and unchanged sides; the pipelined CLI
 gives the results of the one-by-one host path; groups in forward_images / extract_features_images change nothing."""
 import json
@@ -22,9 +23,8 @@ def ctx():
 
 def _host(rgb_u8, size):
     from densecap_amd import run_model as R
-    x = rgb_u8.astype(np.float32).transpose(2, 0, 1) / np.float32(255.0)
-    img_caffe, scaled = R.preprocess_rgb01(x, size)
-    rgb = (np.clip(scaled, 0, 1) * 255.0).astype(np.uint8).transpose(1, 2, 0)
+    img_caffe, scaled = R.preprocess_rgb01(R.image_load_u8(rgb_u8), size)
+    rgb = (np.clip(scaled, 0, 1) * np.float32(255.0)).astype(np.uint8).transpose(1, 2, 0)
     return img_caffe[0], np.ascontiguousarray(rgb)
 
 
@@ -43,6 +43,24 @@ def test_device_preprocessing_is_bit_equal_to_the_host_restatement(ctx, H0, W0, 
     assert got.shape == want.shape == (3,) + ops.preprocess_size(ctx.lib, H0, W0, size)
     np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
     np.testing.assert_array_equal(got_rgb, want_rgb)
+
+
+@pytest.mark.parametrize("H0,W0,size", [(97, 41, 64), (64, 64, 64), (1, 9, 33), (31, 17, 200), (60, 90, 45), (45, 23, 46), (50, 75, 75)])
+def test_device_preprocessing_is_bit_equal_to_the_oracle(ctx, H0, W0, size):
+    """dc_preprocess_u8 against oracle.preprocess itself (scalar loops of torch/image's scaleLinear_rowcol on image.load's
+    DoubleTensor, float accumulators; run_model.lua:67-74) -- shrinking, growing, mixed and unchanged sides."""
+    from densecap_amd import ops
+    from oracle import densecap_oracle as O
+    rng = np.random.default_rng(1000 * H0 + W0)
+    rgb = rng.integers(0, 256, (H0, W0, 3)).astype(np.uint8)
+    want = O.preprocess(O.image_load_u8(rgb), size)[0]
+    out, _ = ops.preprocess_u8(ctx, rgb, size)
+    got = out.numpy()
+    assert got.shape == want.shape and got.dtype == want.dtype == np.float32
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+    # the same sizes again: the cached tap tables (kept while the sizes repeat) serve the second call
+    rgb2 = rng.integers(0, 256, (H0, W0, 3)).astype(np.uint8)
+    np.testing.assert_array_equal(ops.preprocess_u8(ctx, rgb2, size)[0].numpy(), O.preprocess(O.image_load_u8(rgb2), size)[0])
 
 
 def test_preprocess_rejects_what_it_cannot_scale(ctx):

@@ -87,7 +87,7 @@ def test_product_image_scale_against_the_exact_resampler(seed):
         got = image_scale(img, size)
         want = scale_reference(img, size)
         assert got.shape == want.shape, (ih, iw, size, got.shape, want.shape)       # incl. the floor of the short side
-        assert got.dtype == np.float32
+        assert got.dtype == np.float64                       # image.scale on the DoubleTensor image.load returns; :float() comes after
         err = float(np.abs(got - want).max())
         assert err < 2e-5, (ih, iw, size, err)
 

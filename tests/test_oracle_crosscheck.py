@@ -103,3 +103,26 @@ def test_lm_sample_matches_stepwise_embedding_path():
         h, c = O.lstm_step(xg[tok - 1], h, c, Wh)
         tok = torch.argmax(h @ W["lm_out_w"].t() + W["lm_out_b"], dim=1) + 1
         assert tok.tolist() == seq[:, t].tolist()
+
+
+def test_th_transcendentals_against_independent_float_implementations():
+    """Round-5 advisor finding: the oracle and the device kernels both compute exp / sigmoid / tanh as (float)f((double)x)
+    (the recalled TH CPU form, docs/SEMANTICS.md), so the bit-exact parity tests compare two sides that were changed
+    together.  Here the oracle's three functions stand against implementations that share nothing with them: PyTorch's
+    float32 kernels (vectorised SLEEF-style polynomials) and numpy's float32 libm.  A correctly rounded float result is
+    within half an ulp of the truth, an independent float kernel within an ulp or two: 2 ulp apart at most -- which is also
+    the bound on what the reference's own GPU path (cutorch float intrinsics, `-gpu 0`) would differ by."""
+    import torch
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.standard_normal(20000) * 4, rng.uniform(-80, 80, 20000), [0.0, -0.0, 1e-8, -1e-8, 30.0, -30.0, 88.0, -87.0]]).astype(np.float32)
+    xt = torch.from_numpy(x)
+    for mine, theirs_t, theirs_np in ((O.th_exp, torch.exp, np.exp), (lambda v: O.th_sigmoid(torch.from_numpy(v)).numpy(), torch.sigmoid, None),
+                                      (lambda v: O.th_tanh(torch.from_numpy(v)).numpy(), torch.tanh, np.tanh)):
+        got = np.asarray(mine(x), np.float32)
+        assert got.dtype == np.float32
+        for other in [theirs_t(xt).numpy()] + ([theirs_np(x).astype(np.float32)] if theirs_np else []):
+            fin = np.isfinite(other) & np.isfinite(got) & (np.abs(other) > 1e-37)       # (denormal results: flush-to-zero differs)
+            ulp = np.spacing(np.abs(other[fin]))
+            assert (np.abs(got[fin] - other[fin]) <= 2 * ulp).all(), theirs_t.__name__
+            assert np.array_equal(np.isinf(got), np.isinf(other))
+    # the LSTM cell built from them against PyTorch's fused float cell is test_lstm_step_agrees_with_lstm_cell above

@@ -124,9 +124,20 @@ def test_image_scale_hand_computed_and_oracle():
     assert R.image_scale(np.zeros((3, 333, 500), np.float32), 720).shape == (3, 479, 720)     # 333*720/500 = 479.52
     rng = np.random.default_rng(0)
     for (h, w, size) in [(7, 13, 5), (9, 5, 20), (40, 30, 17), (3, 50, 64)]:
-        x = rng.random((3, h, w)).astype(np.float32)
-        np.testing.assert_array_equal(R.image_scale(x, size), O.image_scale(x, size))
+        # image.load's DoubleTensor: bytes / 255 in double; the scaling runs in double with the library's float locals
+        u8 = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        x = R.image_load_u8(u8)
+        assert x.dtype == np.float64 and np.array_equal(x, O.image_load_u8(u8))
+        a, b = R.image_scale(x, size), O.image_scale(x, size)
+        assert a.dtype == b.dtype == np.float64
+        np.testing.assert_array_equal(a, b)
         np.testing.assert_array_equal(R.preprocess_rgb01(x, size)[0], O.preprocess(x, size))
+        # the float accumulator of the area average is visible: every shrunk sample is a float value held in a double
+        if size < max(h, w):
+            assert np.array_equal(a, a.astype(np.float32).astype(np.float64))
+        # ... and the all-float32 chain of rounds 2-5 stays within an ulp or two of it
+        f32 = R.image_scale(x.astype(np.float32), size).astype(np.float32)
+        assert np.abs(f32 - a.astype(np.float32)).max() <= 4 * np.finfo(np.float32).eps
     # shrinking is an area average, not point sampling: a 1-px checkerboard collapses to its mean
     cb = (np.indices((8, 8)).sum(0) % 2).astype(np.float32)[None]
     np.testing.assert_allclose(R.image_scale(cb, 4), np.full((1, 4, 4), 0.5), atol=1e-6)
