@@ -126,3 +126,44 @@ def test_th_transcendentals_against_independent_float_implementations():
             assert (np.abs(got[fin] - other[fin]) <= 2 * ulp).all(), theirs_t.__name__
             assert np.array_equal(np.isinf(got), np.isinf(other))
     # the LSTM cell built from them against PyTorch's fused float cell is test_lstm_step_agrees_with_lstm_cell above
+
+
+def test_rpn_probability_agrees_with_a_stable_softmax_away_from_overflow():
+    """LocalizationLayer.lua:304-308 computes p(object) as pow(e1 + e2, -1) * e1 with no max subtraction.  Away from the
+    overflow the restatement must be the two-class softmax: against torch.softmax in float64 on moderate logits."""
+    import torch
+    rng = np.random.default_rng(8)
+    k, h, w = 12, 5, 7
+    box_head = (rng.standard_normal((4 * k, h, w)) * 0.1).astype(np.float32)
+    score_head = (rng.standard_normal((2 * k, h, w)) * 5).astype(np.float32)
+    d = O.rpn_decode(box_head, score_head, 160, 224, clip_boxes=False)            # every row kept, in row order
+    want = torch.softmax(torch.from_numpy(d["scores2"]).double(), dim=1)[:, 0].numpy()
+    assert d["p"].shape == (k * h * w,) and np.abs(d["p"] - want).max() < 2e-7
+    # which of the two score channels is "object": the FIRST of a pair (LocalizationLayer.lua:305 pos = scores[{{},1}])
+    assert ((d["scores2"][:, 0] > d["scores2"][:, 1]) == (d["p"] > 0.5)).all()
+
+
+def test_beam_search_of_width_one_is_a_greedy_walk_from_the_cell_seeded_state():
+    """LM:beamsearch (LanguageModel.lua:170-290) with one beam, against a walk written out by hand: image step, START step,
+    first word = arg-max, then -- LanguageModel.lua:221-226 as written -- BOTH states of the beam restart from the CELL state,
+    arg-max of every further step until END (log-probabilities zeroed from then on: the first index wins)."""
+    import torch
+    from densecap_amd.weights import make_synthetic_weights
+    Wt = make_synthetic_weights(seed=5, vocab_size=40, seq_length=6)
+    Wt = {k_: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k_, v in Wt.items()}
+    T, V1 = 6, 41
+    Hd = Wt["lstm_w"].shape[1] // 4
+    D = Wt["lstm_w"].shape[0] - Hd
+    Wx, Wh = Wt["lstm_w"][:D], Wt["lstm_w"][D:]
+    codes = torch.relu(torch.from_numpy(np.random.default_rng(1).standard_normal((9, 4096)).astype(np.float32)))
+    got = O.lm_beamsearch(codes, Wt, T, 1)
+    for i in range(len(codes)):
+        enc = torch.relu(codes[i:i + 1] @ Wt["lm_enc_w"].t() + Wt["lm_enc_b"])
+        h, c = O.lstm_step(Wt["lstm_b"] + enc @ Wx, torch.zeros(1, Hd), torch.zeros(1, Hd), Wh)
+        h, c = O.lstm_step(Wt["lstm_b"] + Wt["lm_emb"][V1 - 1:V1] @ Wx, h, c, Wh)
+        want = [int(torch.argmax(h @ Wt["lm_out_w"].t() + Wt["lm_out_b"])) + 1]
+        h = c.clone()                                                      # the slip of :224, replicated
+        for t in range(1, T):
+            h, c = O.lstm_step(Wt["lstm_b"] + Wt["lm_emb"][want[-1] - 1:want[-1]] @ Wx, h, c, Wh)
+            want.append(1 if V1 in want else int(torch.argmax(h @ Wt["lm_out_w"].t() + Wt["lm_out_b"])) + 1)
+        assert got[i].tolist() == want, (i, got[i].tolist(), want)
