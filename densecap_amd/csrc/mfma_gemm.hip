@@ -922,18 +922,22 @@ template <int TM, int TN, bool CONV, int NS, bool AMAX = false, int BF3 = 0>
 __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   start_stagger(d);
+  int Meff = d.M;
+  if (d.m_dev != nullptr) {             // device-side row count (e.g. boxes surviving the final NMS)
+    // The grid was sized for d.M rows; only the row tiles below the count are live.  Round 6: the LIVE tiles take the first
+    // block ids (the tile map is rebuilt for the live row-tile count), so they start at once and spread over all CUs; the
+    // blocks past them exit.  (Before, live and dead tiles alternated in id order -- with m-fastest ids one in four at 221 of
+    // 1000 rows -- and the live ones landed on a fraction of the CUs: 64 us per decode step against 35 for a 221-row launch.)
+    const int me = *d.m_dev;
+    if (me < Meff) Meff = me;
+    ntm = (Meff + 64 * TM - 1) / (64 * TM);
+    if ((int)blockIdx.x >= ntm * ntn) return;
+  }
   const int bid = xcd_remap(blockIdx.x, ntm * ntn);
   int tile_m, tile_n;
   if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
   else           { tile_n = bid % ntn; tile_m = bid / ntn; }
-  const int m0 = tile_m * (64 * TM);
-  int Meff = d.M;
-  if (d.m_dev != nullptr) {             // device-side row count (e.g. boxes surviving the final NMS)
-    const int me = *d.m_dev;
-    if (me < Meff) Meff = me;
-    if (m0 >= Meff) return;
-  }
-  v2_tile<TM, TN, CONV, NS, AMAX, BF3>(d, m0, tile_n * (64 * TN), tile_n, Meff, smem);
+  v2_tile<TM, TN, CONV, NS, AMAX, BF3>(d, tile_m * (64 * TM), tile_n * (64 * TN), tile_n, Meff, smem);
 }
 
 // 128x64-tile launches with a FINER LAST ROUND (the decode-step GEMM, conv1_2 .. conv3_3).  The 128x64 tiles of one launch
@@ -945,13 +949,22 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_kernel(GemmDesc d, int ntm, 
 // for every v2 shape), so results are bit-identical to the plain launch.
 template <bool CONV, int NS, bool AMAX, int BF3 = 0>
 __global__ __launch_bounds__(256) void mfma_gemm_v2_mixed_kernel(GemmDesc d, int ntm, int ntn, int m_fastest, int nbig,
-                                                                 int nwalk) {
+                                                                 int nwalk, int slots) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   start_stagger(d);
   int Meff = d.M;
   if (d.m_dev != nullptr) {
+    // device-side row count: the tile map -- live row tiles, whole rounds, split last round -- is rebuilt for the LIVE tile
+    // count with the host's rule (launch_mixed), inside the grid the host sized for d.M rows (see mfma_gemm_v2_kernel)
     const int me = *d.m_dev;
     if (me < Meff) Meff = me;
+    ntm = (Meff + 127) / 128;
+    const int total = ntm * ntn;
+    nbig = total / slots * slots;
+    int tail = total - nbig;
+    if (!(nbig > 0 && tail > 0 && 4 * tail <= 3 * slots) || nbig + 2 * tail > (int)gridDim.x) { nbig = total; tail = 0; }
+    nwalk = nbig;
+    if ((int)blockIdx.x >= nbig + 2 * tail) return;
   }
   const int b = blockIdx.x;
   if (b < nwalk) {
@@ -986,18 +999,18 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_mixed_kernel(GemmDesc d, int
 template <bool CONV, int BF3>
 __global__ __launch_bounds__(256, 2) void mfma_gemm_bf3_128_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  int Meff = d.M;
+  if (d.m_dev != nullptr) {             // (live tiles first: see mfma_gemm_v2_kernel)
+    const int me = *d.m_dev;
+    if (me < Meff) Meff = me;
+    ntm = (Meff + 127) / 128;
+    if ((int)blockIdx.x >= ntm * ntn) return;
+  }
   const int bid = xcd_remap(blockIdx.x, ntm * ntn);
   int tile_m, tile_n;
   if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
   else           { tile_n = bid % ntn; tile_m = bid / ntn; }
-  const int m0 = tile_m * 128;
-  int Meff = d.M;
-  if (d.m_dev != nullptr) {
-    const int me = *d.m_dev;
-    if (me < Meff) Meff = me;
-    if (m0 >= Meff) return;
-  }
-  v2_tile<2, 2, CONV, 2, false, BF3>(d, m0, tile_n * 128, tile_n, Meff, smem);
+  v2_tile<2, 2, CONV, 2, false, BF3>(d, tile_m * 128, tile_n * 128, tile_n, Meff, smem);
 }
 
 // =========================================================================================
@@ -1313,6 +1326,13 @@ template <bool CONV>
 __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, int ntn, int m_fastest) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   start_stagger(d);
+  int Meff = d.M;
+  if (d.m_dev != nullptr) {             // (live tiles first: see mfma_gemm_v2_kernel)
+    const int me = *d.m_dev;
+    if (me < Meff) Meff = me;
+    ntm = Meff > d.m_begin ? (Meff - d.m_begin + 127) / 128 : 0;
+    if ((int)blockIdx.x >= ntm * ntn * d.splitk) return;
+  }
   int bid = xcd_remap(blockIdx.x, ntm * ntn * d.splitk);
   const int slice = bid % d.splitk;                  // K slice of this workgroup (split-K), fastest index
   bid /= d.splitk;
@@ -1320,12 +1340,6 @@ __global__ __launch_bounds__(256) void mfma_gemm_ks_kernel(GemmDesc d, int ntm, 
   if (m_fastest) { tile_m = bid % ntm; tile_n = bid / ntm; }
   else           { tile_n = bid % ntn; tile_m = bid / ntn; }
   const int m0 = d.m_begin + tile_m * 128, n0 = tile_n * 128;
-  int Meff = d.M;
-  if (d.m_dev != nullptr) {
-    const int me = *d.m_dev;
-    if (me < Meff) Meff = me;
-    if (m0 >= Meff) return;
-  }
   const int nkt = d.K / BK / d.splitk;               // this workgroup's K range (the whole K unless split-K)
   if constexpr (!CONV) {
     if (Meff - m0 <= 64) {                             // a <= 64-row tile (50-proposal batch, last tile of 300 rows)
@@ -1472,14 +1486,14 @@ hipError_t launch_mixed(const GemmDesc& d, hipStream_t stream, int ntm, int ntn,
     const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_mixed_kernel<CONV, 2, AMAX, BF3>);
     if (hipError_t e = ensure_dyn_lds(fn, lds2); e != hipSuccess) return e;
     hipLaunchKernelGGL((mfma_gemm_v2_mixed_kernel<CONV, 2, AMAX, BF3>), dim3(nwalk + 2 * tail), dim3(256), lds2, stream, d, ntm, ntn,
-                       m_fastest, nbig, nwalk);
+                       m_fastest, nbig, nwalk, slots);
     return hipGetLastError();
   }
   if constexpr (BF3 != 2) {
     const void* fn = reinterpret_cast<const void*>(&mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX, BF3>);
     if (hipError_t e = ensure_dyn_lds(fn, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL((mfma_gemm_v2_mixed_kernel<CONV, 3, AMAX, BF3>), dim3(nwalk + 2 * tail), dim3(256), lds, stream, d, ntm, ntn,
-                       m_fastest, nbig, nwalk);
+                       m_fastest, nbig, nwalk, slots);
     return hipGetLastError();
   }
   return hipErrorInvalidValue;
