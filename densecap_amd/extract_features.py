@@ -90,20 +90,22 @@ def main(argv=None):
     # extract_features.lua:79-91 as a pipeline: files decoded ahead on io threads, image.scale & co on the device
     pipe = ImagePipeline(paths, opt.image_size, opt.gpu, model.ctx, io_threads=opt.io_threads,
                          chunk=max(1, opt.lanes) * max(1, opt.group) * 2, host_preprocess=bool(opt.host_preprocess), want_rgb=False)
-    for chunk in pipe:
-        for i, _, _ in chunk:
-            print("Processing image %d / %d" % (i + 1, N))
-        outs = model.extractFeatures_images_device([d for _, d, _ in chunk])
-        for (i, dev, _), (boxes_xcycwh, feats) in zip(chunk, outs):
-            pipe.recycle(dev)
-            if len(boxes_xcycwh) < M:     # the reference's boxes[{{1, M}}] raises on a short result as well
-                raise SystemExit("image %s: only %d boxes survive the final NMS, -boxes_per_image is %d"
-                                 % (paths[i], len(boxes_xcycwh), M))
-            if all_feats is None:
-                all_feats = np.zeros((N, M, feats.shape[1]), np.float32)
-            all_boxes[i] = xcycwh_to_xywh(boxes_xcycwh)[:M]
-            all_feats[i] = feats[:M]
-    pipe.close()
+    try:
+        for chunk in pipe:
+            for i, _, _ in chunk:
+                print("Processing image %d / %d" % (i + 1, N))
+            outs = model.extractFeatures_images_device([d for _, d, _ in chunk])
+            for (i, dev, _), (boxes_xcycwh, feats) in zip(chunk, outs):
+                pipe.recycle(dev)
+                if len(boxes_xcycwh) < M:     # the reference's boxes[{{1, M}}] raises on a short result as well
+                    raise SystemExit("image %s: only %d boxes survive the final NMS, -boxes_per_image is %d"
+                                     % (paths[i], len(boxes_xcycwh), M))
+                if all_feats is None:
+                    all_feats = np.zeros((N, M, feats.shape[1]), np.float32)
+                all_boxes[i] = xcycwh_to_xywh(boxes_xcycwh)[:M]
+                all_feats[i] = feats[:M]
+    finally:
+        pipe.close()
     if opt.timing:
         dt = time.perf_counter() - t_loop
         print("TIMING %d images in %.3f s = %.1f images/s (decode + preprocess + extractFeatures; lanes %d, group %d, %d io "

@@ -242,17 +242,22 @@ class ImagePipeline:
         self._decoded = [None] * self.num
         self._ahead = 3 * self.chunk
         self._ready = queue.Queue(maxsize=2 * self.chunk)      # bounds the device memory in flight
-        # device buffers are recycled by shape (a directory is mostly one or two sizes): hipMalloc / hipFree synchronise the device
-        self._spare, self._lock = {}, threading.Lock()
+        # device buffers are recycled by shape: hipMalloc / hipFree synchronise the device.  A directory is mostly one or two
+        # sizes, a Visual Genome split (-input_split) is hundreds of aspect ratios: the pool keeps the MAX_SHAPES most recently
+        # used shapes and frees the rest (round-5 advisor finding: it only ever grew)
+        import collections
+        self._spare, self._lock = collections.OrderedDict(), threading.Lock()
         self._host = bool(host_preprocess)
+        self._stop, self._pctx = False, None
         for i in range(min(self._ahead, self.num)):
             self._submit(i)
 
         def worker():
-            pctx = None
             try:
-                pctx = ops.Context(gpu)                  # a dc_ctx is not thread-safe: this thread never touches the model's
+                pctx = self._pctx = ops.Context(gpu)     # a dc_ctx is not thread-safe: this thread never touches the model's
                 for i in range(self.num):
+                    if self._stop:                       # close() before the last image (the consumer raised)
+                        break
                     rgb0 = self._decoded[i].result()
                     self._decoded[i] = True
                     self._submit(i + self._ahead)
@@ -282,17 +287,27 @@ class ImagePipeline:
         if i < self.num and self._decoded[i] is None:
             self._decoded[i] = self.pool.submit(_decode_file, self.paths[i])
 
+    MAX_SHAPES = 8          # distinct (shape, dtype) keys whose spare buffers are kept
+
     def _take(self, ctx, shape, dtype):
+        key, buf, evicted = (tuple(shape), np.dtype(dtype).str), None, []
         with self._lock:
-            lst = self._spare.get((tuple(shape), np.dtype(dtype).str))
-            if lst:
-                return lst.pop()
-        return ctx.empty(shape, dtype)
+            lst = self._spare.get(key)
+            if lst is not None:
+                self._spare.move_to_end(key)
+                if lst:
+                    buf = lst.pop()
+            while len(self._spare) > self.MAX_SHAPES:
+                evicted += self._spare.popitem(last=False)[1]
+        for b in evicted:       # on the preparation thread: the buffers belong to its context
+            b.free()
+        return buf if buf is not None else ctx.empty(shape, dtype)
 
     def recycle(self, buf):
-        # (never freed from the consuming thread: the buffer belongs to the preparation thread's context)
+        # (never freed from the consuming thread while the preparation thread runs: the buffer belongs to that thread's context)
         with self._lock:
             self._spare.setdefault((buf.shape, buf.dtype.str), []).append(buf)
+            self._spare.move_to_end((buf.shape, buf.dtype.str))
 
     def __iter__(self):
         done, chunk = False, []
@@ -309,8 +324,36 @@ class ImagePipeline:
                 chunk = []
 
     def close(self):
+        """Stops the preparation thread (also when the consumer gives up early: the thread may be blocked on a full queue),
+        frees the spare device buffers and closes the thread's context.  Idempotent."""
+        import queue
+        self._stop = True
+        while True:
+            try:
+                item = self._ready.get(timeout=0.05) if self._thread.is_alive() else self._ready.get_nowait()
+            except queue.Empty:
+                if not self._thread.is_alive():
+                    break
+                continue
+            if isinstance(item, tuple):
+                self.recycle(item[1])
         self._thread.join()
-        self.pool.shutdown()
+        self.pool.shutdown(wait=True, cancel_futures=True)
+        with self._lock:
+            bufs = [b for lst in self._spare.values() for b in lst]
+            self._spare.clear()
+        for b in bufs:          # the preparation thread has exited: its context is ours now
+            b.free()
+        if self._pctx is not None:
+            self._pctx.close()
+            self._pctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
 
 def main(argv=None):
@@ -373,16 +416,18 @@ def main(argv=None):
             rj["img_name"] = name
             results[i] = rj
 
-    for chunk in pipe:
-        for i, _, _ in chunk:
-            print("%d/%d processing image %s" % (i + 1, num, paths[i]))
-        outs = model.forward_images_device([d for _, d, _ in chunk])
-        for (i, dev, rgb), out in zip(chunk, outs):
-            pipe.recycle(dev)
-            writes.append(pool.submit(finish, i, rgb, out))
-    for w in writes:
-        w.result()
-    pipe.close()
+    try:
+        for chunk in pipe:
+            for i, _, _ in chunk:
+                print("%d/%d processing image %s" % (i + 1, num, paths[i]))
+            outs = model.forward_images_device([d for _, d, _ in chunk])
+            for (i, dev, rgb), out in zip(chunk, outs):
+                pipe.recycle(dev)
+                writes.append(pool.submit(finish, i, rgb, out))
+        for w in writes:
+            w.result()
+    finally:
+        pipe.close()
     if opt.timing:
         dt = time.perf_counter() - t_loop
         print("TIMING %d images in %.3f s = %.1f images/s (decode + preprocess + forward + captions + image files; "

@@ -195,13 +195,22 @@ end
 -- (3, H, W) float tensor forward_test_device takes, plus H, W.  (image.load + image.scale + BGR, x255, mean; bit-equal to the
 -- library's own C loops.)  The caller frees the pointer with C.dc_free(self.ctx, ptr).
 function Model:preprocess(img_hwc_bytes, image_size)
+  assert(torch.type(img_hwc_bytes) == 'torch.ByteTensor' and img_hwc_bytes:dim() == 3 and img_hwc_bytes:size(3) == 3,
+         'preprocess: expected a ByteTensor of shape (H, W, 3)')
   local H0, W0 = img_hwc_bytes:size(1), img_hwc_bytes:size(2)
   local ph, pw = ffi.new('int[1]'), ffi.new('int[1]')
   assert(C.dc_preprocess_size(H0, W0, image_size, ph, pw) == 0, 'image.scale leaves no pixels')
+  -- the contiguous copy stays referenced by a local until the call has returned (a temporary could be collected between
+  -- the evaluation of the arguments and the C call: ffi.cast allocates)
+  local bytes = img_hwc_bytes:contiguous()
   local pp = ffi.new('void*[1]')
   hip.check(self.ctx, C.dc_malloc(self.ctx, pp, 3 * ph[0] * pw[0] * 4), 'dc_malloc')
-  hip.check(self.ctx, C.dc_preprocess_u8(self.ctx, img_hwc_bytes:contiguous():data(), H0, W0, 0, image_size,
-                                         ffi.cast('float*', pp[0]), nil), 'dc_preprocess_u8')
+  local rc = C.dc_preprocess_u8(self.ctx, bytes:data(), H0, W0, 0, image_size, ffi.cast('float*', pp[0]), nil)
+  if rc ~= 0 then
+    C.dc_free(self.ctx, pp[0])                        -- hip.check raises: give the buffer back first
+    hip.check(self.ctx, rc, 'dc_preprocess_u8')
+  end
+  bytes = nil
   return pp[0], ph[0], pw[0]
 end
 function Model:convert(dtype, use_cudnn) return self end

@@ -158,3 +158,42 @@ def test_extract_features_images_groups_equal_one_by_one(ctx):
     finally:
         m.setGroup(0)
         m.ctx.close()
+
+
+def test_image_pipeline_pool_is_bounded_and_close_does_not_hang(ctx, tmp_path):
+    """Round-5 advisor finding: ImagePipeline kept a spare device buffer for every (shape, dtype) it ever met and its
+    preparation thread stayed blocked on a full queue when the consumer raised.  Many aspect ratios (the -input_split case):
+    the pool holds at most MAX_SHAPES keys; close() in the middle of a run returns, frees the spares and closes the context."""
+    from PIL import Image
+    from densecap_amd import run_model as R
+    rng = np.random.default_rng(3)
+    paths = []
+    for i in range(40):
+        p = tmp_path / ("a%02d.png" % i)
+        Image.fromarray(rng.integers(0, 256, (40 + 3 * i, 90, 3), dtype=np.uint8)).save(p)       # 40 distinct sizes
+        paths.append(str(p))
+    pipe = R.ImagePipeline(paths, 96, 0, ctx, io_threads=2, chunk=4, want_rgb=True)
+    seen = 0
+    try:
+        for chunk in pipe:
+            for i, dev, rgb in chunk:
+                assert dev.shape[0] == 3 and rgb.shape[2] == 3
+                pipe.recycle(dev)
+                seen += 1
+            with pipe._lock:
+                assert len(pipe._spare) <= pipe.MAX_SHAPES + 2       # (+ what came back since the preparation thread last looked)
+    finally:
+        pipe.close()
+    assert seen == 40 and not pipe._spare and pipe._pctx is None
+    pipe.close()                                                     # idempotent
+    # a consumer that gives up after the first chunk: the preparation thread is blocked on the full queue by then
+    pipe = R.ImagePipeline(paths, 96, 0, ctx, io_threads=2, chunk=2, want_rgb=False)
+    with pytest.raises(RuntimeError, match="gave up"):
+        with pipe:
+            for chunk in pipe:
+                for _, dev, _ in chunk:
+                    pipe.recycle(dev)
+                import time
+                time.sleep(0.3)
+                raise RuntimeError("consumer gave up")
+    assert not pipe._thread.is_alive() and not pipe._spare and pipe._pctx is None
