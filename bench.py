@@ -366,6 +366,10 @@ def main():
     ap.add_argument("--math-mode", type=int, default=0, choices=[0, 1],
                     help="dc_set_math_mode for the WHOLE run: 0 = fp32 MFMA (default, the headline), 1 = split-bf16 (opt-in mode; the line's "
                          "dtype / roofline then describe that mode and say so)")
+    ap.add_argument("--caption-order", type=int, default=0, choices=[0, 1],
+                    help="profiler / lab option, NOT the headline: 1 = every region of this run in the captions-after-the-final-NMS "
+                         "schedule (dc_set_caption_order(1), what the CLIs run); the line says so in config.caption_order, counts the "
+                         "language-model FLOPs of the decoded rows only and carries no value_captions_after_final_nms leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-pass", action="store_true",
                     help="skip the secondary caption-order measurement (keeps rocprof kernel statistics to one workload)")
@@ -457,6 +461,9 @@ def main():
         model.setLanes(args.lanes if args.lanes > 0 else 3)
         model.setGroup(max(args.group, 0))
         model.setMathMode(args.math_mode)
+        if args.caption_order:
+            model.setCaptionOrder(True)
+            args.no_alt_pass = True
         ctx = model.ctx
         if args.plan_mode >= 0:
             check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"plan_mode", args.plan_mode), "dc_debug_set")
@@ -1004,6 +1011,15 @@ def main():
             gf = stage_gflop(H, W, P, T, V)
             ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
             mfma_flops_per_image = prof["flops"] / max(nprof, 1)
+            if args.caption_order:
+                # the library's launch profile counts a launch's host-side row count; the packed decode runs the rows the final
+                # NMS kept (device-side count): price the language model on those
+                kept_rows = total_boxes / float(max(world * K, 1))
+                skipped = (P - kept_rows) * gf["lstm_decode"] * 1e9 / P
+                mfma_flops_per_image -= skipped
+                ach = (prof["flops"] - skipped * nprof) / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
+                out["config"]["caption_order"] = ("captions after the final NMS (--caption-order 1: a profiler option, not the headline "
+                                                  "command); %.1f of %d rows decoded per image, language-model FLOPs counted on those" % (kept_rows, P))
             roof = {
                 "bound": "mfma",
                 "kernel": "fp32 MFMA contraction family (v_mfma_f32_32x32x2_f32): mfma_gemm_ks_kernel<CONV> (K-split "

@@ -6,6 +6,7 @@
 // so that, fed the oracle's inputs, the picks are identical to box_utils.nms
 // (densecap/box_utils.lua:154-256).
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -392,11 +393,12 @@ __global__ __launch_bounds__(256) void nms_cross_kernel(const float* __restrict_
 }
 
 // (b) intra-window upper-triangular bit mask.  wave q of block (cg, rc): rows of chunk rc (window
-// relative) against column chunk cg*4+q; bit j set <=> row suppresses column j, j > row.
+// relative) against column chunk cg*4+q; bit j set <=> row suppresses column j, j > row.  With `nearband` (windows the band
+// scan takes) also the three blocks below the diagonal and the whole diagonal block, packed four words a row.
 __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ sboxes, const float* __restrict__ sarea,
                                                        const int32_t* __restrict__ nvalid,
                                                        const NmsState* __restrict__ st, int r0, int r1, float thresh,
-                                                       int wwords, u64* __restrict__ mask) {
+                                                       int wwords, u64* __restrict__ mask, u64* __restrict__ nearband) {
   const int n = min(*nvalid, r1);
   if (st->done || r0 >= n) return;
   const int rc = blockIdx.y, q = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -410,16 +412,26 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__
     cb[q][lane][4] = sarea[cj];
   }
   __syncthreads();
-  if (cc < rc || r0 + cc * 64 >= n) return;
+  // blocks on and above the diagonal, and (round 6) the three just below it: nms_scan_band_kernel reads those as "which rows of
+  // the previous three chunks suppress this row" (the test is symmetric in its two boxes)
+  if (cc < rc - 3 || r0 + cc * 64 >= n) return;
   const int row = r0 + rc * 64 + lane;
   if (row >= n) return;
   const f32x4 bi = *reinterpret_cast<const f32x4*>(sboxes + (size_t)row * 4);
   const float ai = sarea[row];
   const int jn = min(64, n - (r0 + cc * 64));
+  // (the diagonal block is computed whole when the band scan will read it: its lower triangle -- "which EARLIER rows of my own
+  // chunk suppress me", the transpose of the upper one, the test being symmetric -- lets that kernel resolve a chunk by
+  // fixed-point sweeps instead of one scalar step per pick)
+  const bool whole_diag = nearband != nullptr && cc == rc;
   u64 word = 0;
-  for (int j = (cc == rc ? lane + 1 : 0); j < jn; ++j)
-    if (nms_suppresses(bi, ai, cb[q][j][0], cb[q][j][1], cb[q][j][2], cb[q][j][3], cb[q][j][4], thresh))
-      word |= (1ull << j);
+  for (int j = (cc == rc && !whole_diag ? lane + 1 : 0); j < jn; ++j)
+    if (j != lane || cc != rc)
+      if (nms_suppresses(bi, ai, cb[q][j][0], cb[q][j][1], cb[q][j][2], cb[q][j][3], cb[q][j][4], thresh))
+        word |= (1ull << j);
+  // the words nms_scan_band_kernel keeps in LDS, packed (32 bytes a row: one contiguous 128 KiB read instead of 4096 lines)
+  if (nearband != nullptr && cc <= rc) nearband[(size_t)(row - r0) * 4 + (rc - cc)] = word;
+  if (whole_diag) word &= ~((2ull << lane) - 1ull);          // the window mask keeps the upper triangle only
   mask[(size_t)(row - r0) * wwords + cc] = word;
 }
 
@@ -521,6 +533,175 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const u64* __restrict__ m
   if (tid == 0) {
     st->count = s_cnt;
     if (full || n >= ntot) { st->done = 1; *count_out = s_cnt; }
+  }
+}
+
+// (c') the same greedy scan for a window of <= NMS_BAND_ROWS rows, without a memory round trip per chunk (round 6).
+// nms_scan_kernel above pays, per 64-row chunk, one scalar readlane step per pick (~120 cycles each) and one memory round trip:
+// the picks of chunk w fetch their mask rows (written by workgroups on all eight XCDs, so they come from the Infinity Cache)
+// before chunk w+1 can be resolved -- 1.4 us x 64 chunks = 90 us for the RPN list.  Here:
+//  * everything the NEXT three chunks need is in LDS before the loop starts, at addresses that do not depend on the picks.
+//    nms_mask_kernel packs four words per row side by side (`nearband`, 32 bytes a row, one contiguous 128 KiB read): the
+//    row's WHOLE diagonal word (plane 0 of `band`) and the words of the three chunks BEFORE the row's own (planes 1..3) -- the
+//    blocks just below the diagonal, which that kernel now computes too.  The IoU test is symmetric in its two boxes, so bit p
+//    of word c - k of a row of chunk c says "row p of chunk c - k, if picked, suppresses me".
+//  * wave 0 resolves chunk after chunk out of LDS.  A row is dead if an earlier window or a pick four or more chunks back
+//    removed it (`removed`) or if its three sub-diagonal words meet the pick sets of the last three chunks (three ANDs and a
+//    ballot -- no reduction over picks, no atomics).  Inside the chunk the greedy choice is the one solution of a triangular
+//    system, found by fixed-point sweeps over the lower triangle of the diagonal block (a ballot per sweep, 3-6 sweeps).
+//  * waves 1..3 take the chunks in turn (chunk p: wave 1 + p % 3): as soon as chunk p is published they fetch the FAR words
+//    (chunk p+4 onwards; lane = word, so a pick's words are one contiguous run) of ALL its picks in one round trip (16 / 32 /
+//    64 loads in flight, addresses past the pick count clamped so that no load hides behind a branch) and OR them into
+//    `removed`; wave 0 looks at that helper's progress flag only before chunk p+4.
+//  * no barrier inside the loop: the hand-offs are LDS flags (the LDS operations of a wave execute in order, so what was
+//    written before a flag is visible to whoever sees the flag).
+// RPN list (20,520 boxes, 1000 picks): 90 -> 30 us; final NMS (1000 boxes): 27 -> 14 us (tools/nms_trace.sh).  Same picks as
+// nms_scan_kernel, bit for bit (tests/test_gpu_ops.py::test_nms_band_scan_equals_the_chunk_scan).
+constexpr int NMS_BAND_ROWS = 4096, NMS_BAND_WORDS = 4;
+constexpr size_t NMS_BAND_LDS = (size_t)NMS_BAND_ROWS * NMS_BAND_WORDS * sizeof(u64);
+#define NMS_COMPILER_FENCE() asm volatile("" ::: "memory")
+__global__ __launch_bounds__(256) void nms_scan_band_kernel(const u64* __restrict__ mask, int wwords,
+                                                            const u64* __restrict__ nearband,
+                                                            const int32_t* __restrict__ nvalid,
+                                                            const int32_t* __restrict__ order, int r0, int r1,
+                                                            int max_boxes, const u64* __restrict__ removed0,
+                                                            int32_t* __restrict__ picks, int32_t* __restrict__ pick_pos,
+                                                            NmsState* __restrict__ st, int32_t* __restrict__ count_out) {
+  extern __shared__ __attribute__((aligned(16))) u64 band[];       // [NMS_BAND_WORDS][NMS_BAND_ROWS]
+  __shared__ u64 removed[NMS_BAND_ROWS / 64];
+  __shared__ int s_np[4];
+  __shared__ int s_rows[4][64];           // ring of four chunks: picks (window-relative rows) of chunk w in slot w & 3
+  __shared__ int s_published;             // chunks resolved by wave 0; kStop once wave 0 is through
+  __shared__ int s_applied[3];            // chunks whose far words helper wave h has folded into `removed`
+  // (flags are read / written as relaxed workgroup-scope atomics: plain ds_read / ds_write, never cached in a register;
+  // `volatile` would turn every access into a flat load behind vmcnt(0) and serialise the helpers' global loads)
+  auto flag_load = [](int* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  auto flag_store = [](int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  __shared__ int s_result[2];             // {count, full}
+  constexpr int kStop = 1 << 30;
+  const int ntot = *nvalid;
+  if (st->done) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (r0 >= ntot) {                       // nothing left: close the run
+    if (tid == 0) { st->done = 1; *count_out = st->count; }
+    return;
+  }
+  const int n = min(ntot, r1);
+  const int nrows = n - r0;               // <= NMS_BAND_ROWS (launch_nms)
+  const int nw = (nrows + 63) >> 6;
+  for (int v = tid; v < nw; v += 256) removed[v] = removed0[(r0 >> 6) + v];
+  if (tid == 0) { s_published = 0; s_applied[0] = 0; s_applied[1] = 0; s_applied[2] = 0; }
+  // the band: nms_mask_kernel packed words c, c-1, c-2, c-3 of every row side by side; 16 loads of 16 bytes in flight per thread
+  {
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2* nb = reinterpret_cast<const u64x2*>(nearband);
+    const int pairs = nw * 64 * 2, last = nrows * 2 - 1;
+    for (int j0 = tid; j0 < pairs; j0 += 256 * 16) {
+      u64x2 v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = nb[min(j0 + i * 256, last)];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int j = j0 + i * 256, row = j >> 1, k0 = (j & 1) * 2, c = row >> 6;
+        if (j < pairs) {
+          band[k0 * NMS_BAND_ROWS + row] = (row < nrows && c - k0 >= 0) ? v[i][0] : 0ull;
+          band[(k0 + 1) * NMS_BAND_ROWS + row] = (row < nrows && c - k0 - 1 >= 0) ? v[i][1] : 0ull;
+        }
+      }
+    }
+  }
+  const int count_in = st->count;
+  __syncthreads();
+  if (wid == 0) {
+    u64 al1 = 0, al2 = 0, al3 = 0;        // pick sets of chunks w-1, w-2, w-3
+    int cnt = count_in;
+    bool full = false;
+    for (int w = 0; w < nw; ++w) {
+      if (w >= 4) {                       // the far words of the picks of chunk w-4 (and, in order, of all before) are in
+        const int p = w - 4;
+        while (flag_load(&s_applied[p % 3]) <= p / 3) __builtin_amdgcn_s_sleep(1);
+        NMS_COMPILER_FENCE();
+      }
+      const int row = w * 64 + lane;      // window-relative
+      const u64 diag = band[row];
+      const u64 t1 = band[NMS_BAND_ROWS + row], t2 = band[2 * NMS_BAND_ROWS + row], t3 = band[3 * NMS_BAND_ROWS + row];
+      const bool near = (((t1 & al1) | (t2 & al2)) | (t3 & al3)) != 0ull;
+      u64 alive = ~(removed[w] | __ballot(near));
+      if (nrows - w * 64 < 64) alive &= (1ull << (nrows - w * 64)) - 1ull;
+      const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)alive);
+      const unsigned ahi = __builtin_amdgcn_readfirstlane((unsigned)(alive >> 32));
+      const u64 alive_u = ((u64)ahi << 32) | alo;
+      // the greedy choice inside the chunk: row j stays iff it is alive and no EARLIER row of the chunk that stays suppresses it --
+      // a triangular system with one solution.  Sweeps x_j <- alive_j & !(below_j & X) from X = alive: after k sweeps the first k
+      // rows are final, and a sweep that changes nothing has found the solution (usually 3-6 sweeps; the scalar walk it replaces
+      // took one readlane step per pick, ~120 cycles each)
+      const u64 below = diag & ((1ull << lane) - 1ull);
+      const bool alive_j = (alive_u >> lane) & 1ull;
+      u64 al = alive_u;
+      for (int sweep = 0; sweep < 65; ++sweep) {
+        const u64 nx = __ballot(alive_j && (below & al) == 0ull);
+        if (nx == al) break;
+        al = nx;
+      }
+      if (max_boxes >= 0) {
+        const int room = max_boxes - cnt;
+        while (__builtin_popcountll(al) > room) al &= ~(1ull << (63 - __builtin_clzll(al)));
+      }
+      if ((al >> lane) & 1ull) {
+        const int pos = __builtin_popcountll(al & ((1ull << lane) - 1ull));
+        pick_pos[cnt + pos] = r0 + row;
+        s_rows[w & 3][pos] = row;
+      }
+      if (lane == 0) s_np[w & 3] = __builtin_popcountll(al);
+      cnt += __builtin_popcountll(al);
+      NMS_COMPILER_FENCE();
+      if (lane == 0) flag_store(&s_published, w + 1);
+      al3 = al2; al2 = al1; al1 = al;
+      if (max_boxes >= 0 && cnt >= max_boxes) { full = true; break; }
+    }
+    NMS_COMPILER_FENCE();
+    if (lane == 0) { s_result[0] = cnt; s_result[1] = full ? 1 : 0; }
+    NMS_COMPILER_FENCE();
+    if (lane == 0) flag_store(&s_published, kStop);
+  } else {
+    const int hw = wid - 1;
+    for (int p = hw; p + 4 < nw; p += 3) {               // (chunks whose picks have no far word need no helper)
+      int pub;
+      while ((pub = flag_load(&s_published)) <= p) __builtin_amdgcn_s_sleep(1);
+      if (pub >= kStop) break;                           // wave 0 is through: nobody reads `removed` any more
+      NMS_COMPILER_FENCE();
+      const int np = s_np[p & 3];
+      const int* rows = s_rows[p & 3];
+      const int word = p + 4 + lane, wordc = min(word, wwords - 1);
+      // all picks of the chunk in ONE round trip (16, 32 or 64 loads in flight; addresses past the pick count are clamped)
+      u64 acc = 0ull;
+      auto fetch = [&](auto tag) {
+        constexpr int G = decltype(tag)::value;
+        u64 g[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          const int r = __builtin_amdgcn_readfirstlane(rows[u < np ? u : 0]);
+          g[u] = mask[(size_t)r * wwords + wordc];
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) acc |= (u < np) ? g[u] : 0ull;
+      };
+      if (np <= 16) fetch(std::integral_constant<int, 16>());
+      else if (np <= 32) fetch(std::integral_constant<int, 32>());
+      else fetch(std::integral_constant<int, 64>());
+      if (word < nw && acc) atomicOr(&removed[word], acc);
+      NMS_COMPILER_FENCE();
+      if (lane == 0) flag_store(&s_applied[hw], p / 3 + 1);
+    }
+  }
+  // picks of this window: sorted position -> original index, off the per-chunk critical path
+  __syncthreads();
+  const int c_end = s_result[0];
+  for (int i = count_in + tid; i < c_end; i += 256) picks[i] = order[pick_pos[i]];
+  __syncthreads();
+  if (tid == 0) {
+    st->count = c_end;
+    if (s_result[1] || n >= ntot) { st->done = 1; *count_out = c_end; }
   }
 }
 
@@ -647,6 +828,7 @@ hipError_t launch_rpn_decode(const float* heads, int nimg, int h, int w, int k, 
   return hipGetLastError();
 }
 
+static int g_nms_band = 1;            // windows of <= NMS_BAND_ROWS rows take nms_scan_band_kernel
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // window k covers sorted rows [win_start(k), win_start(k+1))
 // windows: 4096 boxes, then 32768 at a time (the scan kernel's LDS bit set holds 32768).  The pick budget is
@@ -671,7 +853,7 @@ static size_t nms_mask_words(int n) {
 static size_t nms_removed_words(int n) { return ((size_t)n + 63) / 64; }
 size_t nms_workspace_bytes(int n) {
   return align256((size_t)n * 4) * 6 + align256((size_t)n * 16) + align256(NMS_BUCKETS * 4) * 3 + align256(256) * 2 +
-         align256(nms_removed_words(n) * 8) + align256(nms_mask_words(n) * 8);
+         align256(nms_removed_words(n) * 8) + align256(nms_mask_words(n) * 8) + align256(NMS_BAND_LDS);
 }
 hipError_t nms_workspace_bind(NmsWorkspace& ws, void* base, int n) {
   char* p = static_cast<char*>(base);
@@ -692,7 +874,8 @@ hipError_t nms_workspace_bind(NmsWorkspace& ws, void* base, int n) {
   ws.removed0 = reinterpret_cast<unsigned long long*>(p); p += align256(nms_removed_words(n) * 8);
   ws.zero_bytes = (size_t)(p - reinterpret_cast<char*>(ws.hist));
   ws.off = reinterpret_cast<int32_t*>(p); p += align256(NMS_BUCKETS * 4);
-  ws.mask = reinterpret_cast<u64*>(p);
+  ws.mask = reinterpret_cast<u64*>(p); p += align256(ws.mask_words * 8);
+  ws.nearband = reinterpret_cast<u64*>(p);
   return hipSuccess;
 }
 
@@ -718,20 +901,29 @@ hipError_t launch_nms(NmsWorkspace& ws, const float* boxes, const float* scores,
     const int r1 = std::min(n, win_start(k + 1, graded));
     const int rows = std::max(r1 - r0, 0);
     const int wchunks = (rows + 63) / 64;
+    const bool band = g_nms_band && rows > 0 && rows <= NMS_BAND_ROWS;
     if (rows > 0) {
       if (k > 0)
         hipLaunchKernelGGL(nms_cross_kernel, dim3(wchunks, 4), dim3(256), 0, s, ws.sboxes, ws.sarea, ws.nvalid, st,
                            ws.pick_pos, r0, r1, thresh, ws.removed0);
       hipLaunchKernelGGL(nms_mask_kernel, dim3((wchunks + 3) / 4, wchunks), dim3(256), 0, s, ws.sboxes, ws.sarea,
-                         ws.nvalid, st, r0, r1, thresh, wchunks, ws.mask);
+                         ws.nvalid, st, r0, r1, thresh, wchunks, ws.mask, band ? ws.nearband : nullptr);
     }
-    // rows == 0 still runs the scan once: it closes the run (writes *count) when the list is exhausted
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(256), 0, s, ws.mask, wchunks, ws.nvalid, ws.order, r0,
-                       std::max(r1, r0), max_boxes, ws.removed0, picks, ws.pick_pos, st, count);
-    if (rows <= 0) break;
+    if (rows <= 0) break;                // (the last window's scan closes the run: min(*nvalid, r1) >= *nvalid there)
+    if (band) {
+      const void* fn = reinterpret_cast<const void*>(&nms_scan_band_kernel);
+      if ((e = ensure_dyn_lds(fn, NMS_BAND_LDS)) != hipSuccess) return e;
+      hipLaunchKernelGGL(nms_scan_band_kernel, dim3(1), dim3(256), NMS_BAND_LDS, s, ws.mask, wchunks, ws.nearband, ws.nvalid, ws.order, r0,
+                         r1, max_boxes, ws.removed0, picks, ws.pick_pos, st, count);
+    } else {
+      hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(256), 0, s, ws.mask, wchunks, ws.nvalid, ws.order, r0, r1, max_boxes,
+                         ws.removed0, picks, ws.pick_pos, st, count);
+    }
   }
   return hipGetLastError();
 }
+// measurement / test hook (dc_debug_set "nms_band"): 0 = every window through nms_scan_kernel
+void nms_set_scan_band(int on) { g_nms_band = on ? 1 : 0; }
 
 hipError_t launch_final_pack(const float* final_boxes, const float* obj, const int32_t* tokens, int tok_gather,
                              const float* codes, const int32_t* picks, const int32_t* count, int count_stride,

@@ -228,6 +228,7 @@ struct NmsWorkspace {
   int32_t* nvalid = nullptr;      // (1)
   unsigned long long* removed0 = nullptr;  // (ceil(n/64)) bits suppressed by picks of earlier windows
   unsigned long long* mask = nullptr;      // window bit mask
+  unsigned long long* nearband = nullptr;  // (4096, 4) words c, c-1, c-2, c-3 of every row of a window of <= 4096 rows
   size_t mask_words = 0;
   size_t zero_bytes = 0;          // hist..removed0 are contiguous and zeroed per call
 };
@@ -237,6 +238,7 @@ hipError_t nms_workspace_bind(NmsWorkspace& ws, void* base, int n);
 hipError_t launch_nms(NmsWorkspace& ws, const float* boxes, const float* scores, const uint8_t* valid, int n,
                       const int32_t* n_dev, float thresh, int max_boxes, int32_t* picks, int32_t* count,
                       hipStream_t s);
+void nms_set_scan_band(int on);          // test hook: 0 = the per-chunk scan kernel for every window
 // out[i] = src[idx[i]] rows of `width` floats for i < *count (rows >= *count zero-filled up to cap)
 hipError_t launch_gather_rows(const float* src, const int32_t* idx, const int32_t* count, int cap, int width,
                               float* out, hipStream_t s);

@@ -1514,6 +1514,11 @@ int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value) {
     ctx->beam_chunk_floats = value;
     return DC_OK;
   }
+  if (strcmp(name, "nms_band") == 0) {                 // process-wide: 0 = nms_scan_kernel for every NMS window
+    if (value < 0 || value > 1) return ctx->fail(DC_E_INVALID, "dc_debug_set: nms_band must be 0 or 1");
+    nms_set_scan_band((int)value);
+    return DC_OK;
+  }
   if (strcmp(name, "v2_stages") == 0) {
     if (value != 0 && value != 2 && value != 3) return ctx->fail(DC_E_INVALID, "dc_debug_set: v2_stages must be 0, 2 or 3");
     ctx->v2_stages = (int)value;

@@ -55,6 +55,9 @@ int64_t dc_debug_fetch(dc_ctx* ctx, const char* name, void* host_buf, int64_t ca
  *   "v2_stages"          LDS ring depth of the 128x64-tile contraction kernel: 0 = by tile count (default: two stages, three
  *                        workgroups per CU, once a launch has >= 3 tiles per CU; three stages otherwise), 2 or 3 forced.
  *                        Same K order either way: bit-identical results.
+ *   "nms_band"           1 (default) / 0, process-wide: NMS windows of <= 4096 sorted rows are scanned by nms_scan_band_kernel (the
+ *                        near-diagonal words of the suppression mask resident in LDS) / every window by nms_scan_kernel (one
+ *                        memory round trip per 64-row chunk).  Identical picks (tests/test_gpu_ops.py); A/B measurement only.
  * Returns DC_OK or DC_E_INVALID for an unknown name / bad value. */
 int dc_debug_set(dc_ctx* ctx, const char* name, int64_t value);
 /* Planning query -- pure (no context, no GPU: a missing device counts as 256 CUs; the environment variable DC_PLAN_CU_COUNT,

@@ -579,6 +579,38 @@ def test_nms_beyond_65536_boxes(ctx, n, maxb):
     assert got.tolist() == ref.tolist() and len(ref) >= (1000 if maxb else 2000)
 
 
+def _clustered_boxes5(rng, n, per, ties=True):
+    """near-duplicate clusters whose members carry independent scores: a pick suppresses boxes anywhere later in the sorted list"""
+    ncl = (n + per - 1) // per
+    cxy = rng.uniform(0, 3000, (ncl, 1, 2)); wh = rng.uniform(30, 80, (ncl, 1, 2))
+    xy = cxy + rng.uniform(-6, 6, (ncl, per, 2))
+    b = np.concatenate([xy, xy + wh + rng.uniform(-6, 6, (ncl, per, 2))], 2).reshape(-1, 4)[:n]
+    sc = rng.uniform(0, 1, (n, 1))
+    return np.concatenate([b, np.round(sc, 3) if ties else sc], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,per,thr,maxb", [(4096, 40, 0.5, None), (4096, 8, 0.3, None), (4000, 100, 0.7, 300), (3000, 3, 0.6, None),
+                                            (20520, 30, 0.7, 1000), (20520, 200, 0.5, 1000), (1000, 5, 0.3, None), (130, 10, 0.5, None),
+                                            (4097, 64, 0.4, None), (36720, 20, 0.7, 2000)])
+def test_nms_band_scan_equals_the_chunk_scan(ctx, n, per, thr, maxb):
+    """Round 6: windows of <= 4096 rows are scanned by nms_scan_band_kernel (near words of the mask in LDS, far words fetched two
+    chunks behind the resolving wave); dc_debug_set("nms_band", 0) puts every window back on nms_scan_kernel.  Clustered
+    boxes make picks suppress candidates many chunks later -- the far path -- and both kernels must give the oracle's list."""
+    from densecap_amd import ops
+    from densecap_amd._lib import check
+    from oracle import densecap_oracle as O
+    b = _clustered_boxes5(np.random.default_rng(n * 7 + per), n, per)
+    ref = O.nms(b, thr, maxb).tolist()
+    try:
+        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"nms_band", 0), "dc_debug_set")
+        chunk = ops.nms(ctx, b, thr, maxb).tolist()
+    finally:
+        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"nms_band", 1), "dc_debug_set")
+    band = ops.nms(ctx, b, thr, maxb).tolist()
+    assert chunk == ref and band == ref
+    assert len(ref) < n                                      # (something was suppressed)
+
+
 def test_nms_valid_mask_equals_compaction(ctx):
     # LocalizationLayer.lua:285-298 compacts by `valid` before NMS; masking is equivalent
     from densecap_amd import ops

@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 # one lane = one stream for the profiled images (per-launch events switch the two-stream decode off); the short legs only
-LEAN="--no-cpu-baseline --no-alt-pass --no-host-input-leg --sustain-seconds 0 --no-settle --no-split-leg --no-traffic-leg --gather torch"
+LEAN="--no-cpu-baseline --no-alt-pass --no-host-input-leg --sustain-seconds 0 --no-settle --no-split-leg --no-traffic-leg --no-config-legs --gather torch"
 BENCH="python $REPO/bench.py --lanes 1 --group 1 $LEAN"
 run() {  # name, bench args, rocprof args...
   local name=$1 args=$2; shift 2
@@ -36,6 +36,12 @@ run mlplan_mfma "--steps 3 --warmup 1 --repeats 1" --kernel-trace --pmc SQ_VALU_
 BENCH="python $REPO/bench.py $LEAN"
 run default "--steps 10 --warmup 3 --repeats 2" --kernel-trace --stats
 grep '^{' /tmp/rp_default.json > "$OUT/bench_default_under_rocprof.json"
+# round 6: the captions-after-the-final-NMS schedule (what the CLIs run; `value_captions_after_final_nms`): one stream, the
+# multi-lane planning and the group of four the timed leg picks -- the packed decode launches of a group are in this trace
+BENCH="python $REPO/bench.py --lanes 1 --plan-mode 0 --group 4 --caption-order 1 $LEAN"
+run capnms "--steps 12 --warmup 4 --repeats 1" --kernel-trace --stats
+grep '^{' /tmp/rp_capnms.json > "$OUT/bench_capnms_under_rocprof.json"
+run capnms_mfma "--steps 4 --warmup 4 --repeats 1" --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT
 # the opt-in split-bf16 mode (round 5): kernel names + durations, MFMA busy and clock of ITS kernels (one stream, multi-lane planning)
 BENCH="python $REPO/bench.py --lanes 1 --plan-mode 0 --group 1 --math-mode 1 $LEAN"
 run split "--steps 10 --warmup 3 --repeats 1" --kernel-trace --stats
@@ -51,6 +57,13 @@ python bench.py --height 480 --width 720 --proposals 1000 --steps 32 $Q > "$OUT/
 python bench.py --proposals 300 --steps 32 $Q > "$OUT/bench_config3_p300.json" 2>/dev/null     # (images per group picked by the untimed trial)
 python bench.py --height 720 --width 1080 --proposals 2000 --steps 12 --warmup 2 $Q > "$OUT/bench_config5.json" 2>/dev/null
 python bench.py --math-mode 1 --steps 32 --no-split-leg $Q > "$OUT/bench_split_bf16_mode.json" 2>/dev/null
+python tools/latency_check.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/latency_check.txt"
+bash tools/decode_trace.sh "$OUT/decode_trace_small_rows.txt" 13 50 128 221 256 300 900 > /dev/null 2>&1
+for cfg in "600 720 1000 1" "600 720 1000 4" "600 720 300 1" "600 720 300 4" "320 480 50 1"; do
+  bash tools/survivor_trace.sh "$OUT/survivor_decode_trace.txt" $cfg > /dev/null 2>&1
+done
+rm -rf /tmp/rp_webcam; ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/rp_webcam -o w -- python $REPO/bench.py --height 320 --width 480 --proposals 50 --lanes 1 --group 1 --steps 10 --warmup 3 --repeats 1 --caption-order 1 $LEAN > /dev/null 2>&1 )
+python tools/layer_times.py $(find /tmp/rp_webcam -name "w_kernel_trace.csv" | head -1) --height 320 --width 480 --proposals 50 > "$OUT/webcam_layers.txt" 2>&1
 python tools/gemm_bench.py 5 --serial > "$OUT/gemm_bench_serial.txt" 2>/dev/null
 python tools/gemm_bench.py 5 > "$OUT/gemm_bench_multilane.txt" 2>/dev/null
 python tools/gemm_bench.py 5 --math-mode=1 > "$OUT/gemm_bench_split_bf16.txt" 2>/dev/null
