@@ -591,6 +591,7 @@ __global__ __launch_bounds__(256) void nms_scan_band_kernel(const u64* __restric
   const int nw = (nrows + 63) >> 6;
   for (int v = tid; v < nw; v += 256) removed[v] = removed0[(r0 >> 6) + v];
   if (tid == 0) { s_published = 0; s_applied[0] = 0; s_applied[1] = 0; s_applied[2] = 0; }
+  s_rows[tid >> 6][tid & 63] = 0;
   // the band: nms_mask_kernel packed words c, c-1, c-2, c-3 of every row side by side; 16 loads of 16 bytes in flight per thread
   {
     typedef u64 u64x2 __attribute__((ext_vector_type(2)));
@@ -686,7 +687,8 @@ __global__ __launch_bounds__(256) void nms_scan_band_kernel(const u64* __restric
 #pragma unroll
         for (int u = 0; u < G; ++u) acc |= (u < np) ? g[u] : 0ull;
       };
-      if (np <= 16) fetch(std::integral_constant<int, 16>());
+      if (np <= 0) {}                                     // a chunk without picks: its slot of s_rows holds nothing to read
+      else if (np <= 16) fetch(std::integral_constant<int, 16>());
       else if (np <= 32) fetch(std::integral_constant<int, 32>());
       else fetch(std::integral_constant<int, 64>());
       if (word < nw && acc) atomicOr(&removed[word], acc);

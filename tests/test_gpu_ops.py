@@ -591,7 +591,7 @@ def _clustered_boxes5(rng, n, per, ties=True):
 
 @pytest.mark.parametrize("n,per,thr,maxb", [(4096, 40, 0.5, None), (4096, 8, 0.3, None), (4000, 100, 0.7, 300), (3000, 3, 0.6, None),
                                             (20520, 30, 0.7, 1000), (20520, 200, 0.5, 1000), (1000, 5, 0.3, None), (130, 10, 0.5, None),
-                                            (4097, 64, 0.4, None), (36720, 20, 0.7, 2000)])
+                                            (4097, 64, 0.4, None), (36720, 20, 0.7, 2000), (4096, 1024, 0.3, None), (3024, 3024, 0.2, 100)])
 def test_nms_band_scan_equals_the_chunk_scan(ctx, n, per, thr, maxb):
     """Round 6: windows of <= 4096 rows are scanned by nms_scan_band_kernel (near words of the mask in LDS, far words fetched two
     chunks behind the resolving wave); dc_debug_set("nms_band", 0) puts every window back on nms_scan_kernel.  Clustered
