@@ -62,6 +62,10 @@ bash tools/decode_trace.sh "$OUT/decode_trace_small_rows.txt" 13 50 128 221 256 
 for cfg in "600 720 1000 1" "600 720 1000 4" "600 720 300 1" "600 720 300 4" "320 480 50 1"; do
   bash tools/survivor_trace.sh "$OUT/survivor_decode_trace.txt" $cfg > /dev/null 2>&1
 done
+for cfg in "600 720 1000" "600 720 300" "320 480 50" "720 1080 2000"; do
+  for band in 0 1; do bash tools/nms_trace.sh "$OUT/nms_chain_trace.txt" $cfg $band > /dev/null 2>&1; done
+done
+for seed in 21 22; do timeout 300 python tests/fuzz_nms.py 8000 $seed 2>&1 | tail -1 >> "$OUT/fuzz_nms.txt"; done
 rm -rf /tmp/rp_webcam; ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/rp_webcam -o w -- python $REPO/bench.py --height 320 --width 480 --proposals 50 --lanes 1 --group 1 --steps 10 --warmup 3 --repeats 1 --caption-order 1 $LEAN > /dev/null 2>&1 )
 python tools/layer_times.py $(find /tmp/rp_webcam -name "w_kernel_trace.csv" | head -1) --height 320 --width 480 --proposals 50 > "$OUT/webcam_layers.txt" 2>&1
 python tools/gemm_bench.py 5 --serial > "$OUT/gemm_bench_serial.txt" 2>/dev/null
