@@ -843,10 +843,31 @@ def main():
             split_results = gather(model.forward_batch_device(imgs, K, H, W))[0]
             sync()
             rates.append(K / (time.perf_counter() - s0))
+        # the same mode in the captions-after-the-final-NMS schedule (what the CLIs run with -math_mode 1): the two opt-in knobs
+        # together, the highest rate the library delivers.  The alt leg's schedule; results compared with this leg's above.
+        split_alt = None
+        if alt is not None:
+            model.setCaptionOrder(True)
+            model.setLanes(alt["lanes"]); model.setGroup(alt["group"])
+            model.forward_batch_device(imgs, K, H, W)
+            sync()
+            rates2, res2 = [], None
+            for _ in range(3):
+                sync()
+                s0 = time.perf_counter()
+                res2 = model.forward_batch_device(imgs, K, H, W)
+                sync()
+                rates2.append(K / (time.perf_counter() - s0))
+            model.setCaptionOrder(False)
+            model.setLanes(args.lanes)
+            split_alt = {"images_per_s": sorted(rates2)[1], "regions": rates2, "lanes": alt["lanes"], "group": alt["group"],
+                         "rows_decoded_per_image": float(np.mean([len(b) for b, _, _ in res2])),
+                         "identical_to_the_reference_order_in_this_mode": bool(len(res2) == len(split_results) and all(
+                             np.array_equal(x, y) for a_, b_ in zip(res2, split_results) for x, y in zip(a_, b_)))}
         model.setMathMode(0)
         model.setGroup(args.group)
         split = {"images_per_s": sorted(rates)[1], "regions": rates, "results": split_results, "group": split_group,
-                 "group_trial": split_group_trial}
+                 "group_trial": split_group_trial, "captions_after_final_nms": split_alt}
     serial_pass = False
     stage_live, single_image_latency_ms, stage_group = None, None, None
     nprof = K * nrep
@@ -983,7 +1004,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.math_mode == 0 else "split-bf16 (opt-in: fp32 operands as three bf16 planes, six bf16 MFMA products, fp32 accumulate)",
             "data": "synthetic" if on_gpu else "stub",
             "config": {"workload": "forward_test: one %dx%d image, VGG-16 trunk + %d proposals + greedy LSTM "
                                    "decode (T=15,V=10497), synthetic weights" % (W, H, P),
@@ -1009,6 +1030,9 @@ def main():
             out["config"]["gather_order_verified"] = gather_order_verified
         if on_gpu:
             gf = stage_gflop(H, W, P, T, V)
+            # the peak this run's arithmetic is priced against: fp32 MFMA, or -- for a whole run in the opt-in split-bf16 mode
+            # (--math-mode 1) -- the dense bf16 MFMA peak / 6 (six bf16 products per fp32 multiply-add), as roofline_split_bf16 does
+            RUN_PEAK = FP32_MFMA_PEAK_TFLOPS if args.math_mode == 0 else BF16_MFMA_PEAK_TFLOPS / 6.0
             ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
             mfma_flops_per_image = prof["flops"] / max(nprof, 1)
             if args.caption_order:
@@ -1018,6 +1042,7 @@ def main():
                 skipped = (P - kept_rows) * gf["lstm_decode"] * 1e9 / P
                 mfma_flops_per_image -= skipped
                 ach = (prof["flops"] - skipped * nprof) / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
+                gf = dict(gf, lstm_decode=gf["lstm_decode"] * kept_rows / P)       # per-stage fractions below: the rows actually decoded
                 out["config"]["caption_order"] = ("captions after the final NMS (--caption-order 1: a profiler option, not the headline "
                                                   "command); %.1f of %d rows decoded per image, language-model FLOPs counted on those" % (kept_rows, P))
             roof = {
@@ -1029,8 +1054,8 @@ def main():
                           "128x128: conv4_1; 64x64: RPN heads, LSTM gates of the image step)",
                 # `achieved` / `frac` are filled below from the TIMED schedule (round-4 verdict: the fraction tied to the driver's
                 # clock is the headline); the serial one-stream pass with per-launch HIP events stays as achieved_serial / frac_serial
-                "achieved": None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
-                "achieved_serial": ach, "frac_serial": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "achieved": None, "peak": RUN_PEAK, "unit": "TFLOP/s" if args.math_mode == 0 else "TFLOP/s (fp32-equivalent; peak = dense bf16 MFMA / 6)", "frac": None,
+                "achieved_serial": ach, "frac_serial": ach / RUN_PEAK, "traffic": None,
                 "algorithmic_bytes_per_launch": mfma_family_bytes(H, W, P, T, V)[0] / mfma_family_bytes(H, W, P, T, V)[1],
                 "algorithmic_bytes_per_image": mfma_family_bytes(H, W, P, T, V)[0],
                 "launches_per_image": prof["launches"] / float(max(nprof, 1)),
@@ -1045,14 +1070,14 @@ def main():
             # "conv MFMA util" is trunk_frac)
             for key, name in (("vgg16_trunk", "trunk_frac"), ("fc6_fc7", "fc_frac"), ("lstm_decode", "decode_frac")):
                 if stage.get(key, 0) > 0:
-                    roof[name] = gf[key] / stage[key] / FP32_MFMA_PEAK_TFLOPS
+                    roof[name] = gf[key] / stage[key] / RUN_PEAK
             if stage_live:
                 # the live single-image schedule (two-stream decode, final NMS on a third stream), no per-launch events
                 roof["single_image_mode"] = {
                     "latency_ms": single_image_latency_ms,
                     "stage_ms": stage_live,
-                    "trunk_frac": gf["vgg16_trunk"] / stage_live["vgg16_trunk"] / FP32_MFMA_PEAK_TFLOPS if stage_live.get("vgg16_trunk", 0) > 0 else None,
-                    "decode_frac": gf["lstm_decode"] / stage_live["lstm_decode"] / FP32_MFMA_PEAK_TFLOPS if stage_live.get("lstm_decode", 0) > 0 else None,
+                    "trunk_frac": gf["vgg16_trunk"] / stage_live["vgg16_trunk"] / RUN_PEAK if stage_live.get("vgg16_trunk", 0) > 0 else None,
+                    "decode_frac": gf["lstm_decode"] / stage_live["lstm_decode"] / RUN_PEAK if stage_live.get("lstm_decode", 0) > 0 else None,
                     "note": "dc_set_lanes(1) as run_model uses it; trunk_frac / fc_frac / decode_frac above are the ONE-stream pass with per-launch events"}
             roof["stage_gflop_per_image"] = gf
             roof["serial_ms_per_image"] = sum(stage.values()) if stage else None
@@ -1060,14 +1085,14 @@ def main():
             roof["timed_region_effective_tflops"] = K * mfma_flops_per_image / elapsed / 1e12      # per GPU
             # `frac` above is the SERIAL schedule (one lane, kernels back to back, per-launch events); this one is the
             # schedule that was actually timed: algorithmic MFMA FLOPs of the region / its wall time / peak, per GPU
-            roof["frac_timed_region"] = roof["timed_region_effective_tflops"] / FP32_MFMA_PEAK_TFLOPS
+            roof["frac_timed_region"] = roof["timed_region_effective_tflops"] / RUN_PEAK
             roof["achieved"] = roof["timed_region_effective_tflops"]
             roof["frac"] = roof["frac_timed_region"]
             roof["frac_is"] = ("the TIMED multi-lane schedule: algorithmic MFMA FLOPs of the median region / its wall time / peak "
                                "(= frac_timed_region); frac_serial / achieved_serial = one stream, HIP events around every launch, "
                                "avg_launch_ms their mean -- the per-kernel figure the rocprofv3 stats under profiles/ agree with")
             if sustained is not None:
-                roof["frac_sustained"] = (sustained["images_per_s"] / world) * mfma_flops_per_image / 1e12 / FP32_MFMA_PEAK_TFLOPS
+                roof["frac_sustained"] = (sustained["images_per_s"] / world) * mfma_flops_per_image / 1e12 / RUN_PEAK
             # HBM bytes per MFMA launch cannot be measured from inside the process: quoted from the committed rocprofv3
             # PMC passes of this same command with --lanes 1 (tools/collect_profiles.sh + tools/pmc_summary.py)
             try:
@@ -1154,8 +1179,8 @@ def main():
                 fl = mfma_flops_per_image - (P - alt["rows_decoded_per_image"]) * lm_row
                 out["value_captions_after_final_nms"] = alt["images_per_s"]
                 out["roofline_captions_after_final_nms"] = {
-                    "bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "achieved": alt["images_per_s"] * fl / 1e12, "frac": alt["images_per_s"] * fl / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                    "bound": "mfma", "unit": "TFLOP/s", "peak": RUN_PEAK,
+                    "achieved": alt["images_per_s"] * fl / 1e12, "frac": alt["images_per_s"] * fl / 1e12 / RUN_PEAK,
                     "algorithmic_gflop_per_image": fl / 1e9, "rows_decoded_per_image": alt["rows_decoded_per_image"],
                     "rows_in_reference_order": P, "regions_images_per_s": alt["regions"], "statistic": "median of 5 regions of %d steps" % K,
                     "outputs_identical_to_value_regions": alt["identical"], "vs_value": alt["images_per_s"] / burst,
@@ -1178,6 +1203,18 @@ def main():
                             "fp32 MFMA.  fp32-equivalent = the same algorithmic FLOPs as `roofline`; peak = dense bf16 MFMA peak / 6. "
                             "Few-tile contractions stay on the fp32 route in this mode (counted at the same FLOPs).  Under this "
                             "load the board sustains ~1.55-1.8 GHz, not 2.4, and boxes differ by ~5 % (profiles/r05_split_bf16.md)"}
+                sa = split.get("captions_after_final_nms")
+                if sa is not None:
+                    # both opt-in knobs together (run_model -math_mode 1 with its default caption order); language-model FLOPs of the
+                    # decoded rows only, priced against the same bf16 peak / 6
+                    fl2 = mfma_flops_per_image - (P - sa["rows_decoded_per_image"]) * gf["lstm_decode"] * 1e9 / P
+                    out["value_split_bf16_captions_after_final_nms"] = sa["images_per_s"]
+                    out["roofline_split_bf16"]["captions_after_final_nms"] = {
+                        "value": sa["images_per_s"], "unit": "images/s", "regions_images_per_s": sa["regions"], "lanes": sa["lanes"],
+                        "group": sa["group"], "rows_decoded_per_image": sa["rows_decoded_per_image"],
+                        "achieved": sa["images_per_s"] * fl2 / 1e12, "frac": sa["images_per_s"] * fl2 / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 6.0),
+                        "identical_to_the_reference_order_in_this_mode": sa["identical_to_the_reference_order_in_this_mode"],
+                        "vs_value": sa["images_per_s"] / burst}
             out["stage_ms_serial_image"] = stage
         if on_gpu and world == 1 and not args.no_cpu_baseline:
             # the restated reference CPU path (oracle) on a bounded sample of the same workload

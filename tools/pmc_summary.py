@@ -215,6 +215,40 @@ def main():
             if e["total_us"] > 50:
                 print("  %-52s calls=%4d avg_us=%9.1f %s" % (f[:52], e["calls"], e["avg_us"],
                       " ".join("%s=%.3g" % (k, v) for k, v in e.items() if k not in ("calls", "total_us", "avg_us"))))
+    # round 6: the captions-after-the-final-NMS schedule (bench.py --lanes 1 --plan-mode 0 --group 4 --caption-order 1): the
+    # packed decode launches of a group of four are in this trace; durations per family + MFMA busy of its kernels
+    if os.path.exists(os.path.join(d, "capnms_kernel_trace.csv")):
+        cp = collections.OrderedDict()
+        for r in csv.DictReader(open(os.path.join(d, "capnms_kernel_trace.csv"))):
+            f = fam(r["Kernel_Name"])
+            e = cp.setdefault(f, collections.OrderedDict(calls=0, total_us=0.0))
+            e["calls"] += 1
+            e["total_us"] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        for f, e in cp.items():
+            e["avg_us"] = e["total_us"] / e["calls"]
+        fn = os.path.join(d, "capnms_mfma_counter_collection.csv")
+        if os.path.exists(fn):
+            tr = trace("capnms_mfma")
+            acc2 = collections.defaultdict(lambda: collections.defaultdict(float))
+            seen = collections.defaultdict(set)
+            for r in csv.DictReader(open(fn)):
+                f = fam(r["Kernel_Name"])
+                acc2[f][r["Counter_Name"]] += float(r["Counter_Value"])
+                if r["Dispatch_Id"] not in seen[f] and r["Dispatch_Id"] in tr:
+                    seen[f].add(r["Dispatch_Id"])
+                    t = tr[r["Dispatch_Id"]]
+                    acc2[f]["_dur_us"] += (int(t["End_Timestamp"]) - int(t["Start_Timestamp"])) / 1e3
+            for f, c in acc2.items():
+                if f in cp and c.get("GRBM_GUI_ACTIVE", 0) > 0 and c.get("_dur_us", 0) > 0 and f.startswith("mfma_gemm"):
+                    gui = c["GRBM_GUI_ACTIVE"] / 8.0
+                    cp[f]["mfma_util"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024.0)
+                    cp[f]["clock_ghz"] = gui / c["_dur_us"] / 1e3
+        summ["_captions_after_final_nms_group4"] = cp
+        print("_captions_after_final_nms_group4 (bench.py --lanes 1 --plan-mode 0 --group 4 --caption-order 1)")
+        for f, e in cp.items():
+            if e["total_us"] > 50:
+                print("  %-52s calls=%4d avg_us=%9.1f %s" % (f[:52], e["calls"], e["avg_us"],
+                      " ".join("%s=%.3g" % (k, v) for k, v in e.items() if k not in ("calls", "total_us", "avg_us"))))
     json.dump(summ, open(prefix + "_pmc_summary.json", "w"), indent=1)
     for key in ("_layers_single_image_plan", "_layers_multi_lane_plan"):
         tab = summ.get(key)
@@ -230,7 +264,9 @@ def main():
                   "bench_webcam_480_p50.json", "bench_config3_p300.json", "bench_config5.json", "bench_config0_720x480.json",
                   "gemm_bench_serial.txt", "gemm_bench_multilane.txt", "decode_bench.txt", "parity_report.json",
                   "split_kernel_stats.csv", "bench_split_lanes1.json", "bench_split_bf16_mode.json", "gemm_bench_split_bf16.txt",
-                  "cli_throughput.json", "mfma_bf16_numerics.txt", "split_bf16_error_ratios.txt"):
+                  "cli_throughput.json", "mfma_bf16_numerics.txt", "split_bf16_error_ratios.txt",
+                  "capnms_kernel_stats.csv", "bench_capnms_under_rocprof.json", "latency_check.txt", "decode_trace_small_rows.txt",
+                  "survivor_decode_trace.txt", "nms_chain_trace.txt", "fuzz_nms.txt", "webcam_layers.txt"):
         if os.path.exists(os.path.join(d, extra)):
             shutil.copy(os.path.join(d, extra), prefix + "_" + extra.replace("default_kernel_stats", "kernel_stats_default_lanes"))
     for f, e in summ.items():
