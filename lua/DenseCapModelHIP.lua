@@ -186,6 +186,13 @@ function Model:setGraphReplay(on)
   hip.check(self.ctx, C.dc_set_graph_replay(self.ctx, on and 1 or 0), 'dc_set_graph_replay')
   return self
 end
+-- caption order (include/densecap.h: dc_set_caption_order): false = the reference's (LM:sample on all num_proposals rows, then
+-- the final NMS, DenseCapModel.lua:127-162,261-275), true = the final NMS first and ONE packed decode of the rows it keeps --
+-- the same boxes, scores and tokens bit for bit, about a quarter of the decode work at 1000 proposals
+function Model:setCaptionOrder(after_final_nms)
+  hip.check(self.ctx, C.dc_set_caption_order(self.ctx, after_final_nms and 1 or 0), 'dc_set_caption_order')
+  return self
+end
 -- arithmetic of the large contractions: 0 = fp32 MFMA (default, the reference's arithmetic), 1 = split-bf16 (opt-in; include/densecap.h)
 function Model:setMathMode(mode)
   hip.check(self.ctx, C.dc_set_math_mode(self.ctx, mode or 0), 'dc_set_math_mode')

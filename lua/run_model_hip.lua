@@ -10,6 +10,9 @@ arguments.  These two substitutions are the whole integration (INTEGRATION.md se
                   ->  local dtype, use_cudnn = 'torch.FloatTensor', false          -- host tensors stay float; no cutorch
   run_model.lua:147   local model = checkpoint.model
                   ->  local model = require('DenseCapModelHIP').fromCheckpoint(checkpoint.model, opt.gpu)
+                                            :setCaptionOrder(os.getenv('DENSECAP_CAPTION_ORDER') ~= '0')
+      (captions after the final NMS, as `python -m densecap_amd.run_model` defaults to: identical outputs, the decode runs on the
+       rows the final NMS keeps; DENSECAP_CAPTION_ORDER=0 restores the reference's order)
 
 usage (from the densecap checkout, lua/ on package.path, libdensecap_hip.so on the loader path or in DENSECAP_HIP_LIB):
     th /path/to/lua/run_model_hip.lua -input_dir imgs -max_images 10 -output_vis_dir vis/data
@@ -25,7 +28,7 @@ local SUBSTITUTIONS = {
   {"local dtype, use_cudnn = utils%.setup_gpus%(opt%.gpu, opt%.use_cudnn%)",
    "local dtype, use_cudnn = 'torch.FloatTensor', false"},
   {"local model = checkpoint%.model",
-   "local model = require('DenseCapModelHIP').fromCheckpoint(checkpoint.model, opt.gpu)"},
+   "local model = require('DenseCapModelHIP').fromCheckpoint(checkpoint.model, opt.gpu):setCaptionOrder(os.getenv('DENSECAP_CAPTION_ORDER') ~= '0')"},
 }
 for _, s in ipairs(SUBSTITUTIONS) do
   local n
