@@ -28,8 +28,8 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 HBM_PEAK_GBPS = 8000.0
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
-PMC_PROFILE = os.path.join("profiles", "r05_pmc_summary.json")
-PARITY_REPORT = os.path.join("profiles", "r05_parity_report.json")
+PMC_PROFILE = os.path.join("profiles", "r06_pmc_summary.json")
+PARITY_REPORT = os.path.join("profiles", "r06_parity_report.json")
 
 VGG = [(3, 64, 0), (64, 64, 1), (64, 128, 0), (128, 128, 1), (128, 256, 0), (256, 256, 0), (256, 256, 1),
        (256, 512, 0), (512, 512, 0), (512, 512, 1), (512, 512, 0), (512, 512, 0), (512, 512, 0)]
