@@ -6,6 +6,7 @@
 // so that, fed the oracle's inputs, the picks are identical to box_utils.nms
 // (densecap/box_utils.lua:154-256).
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -830,7 +831,9 @@ hipError_t launch_rpn_decode(const float* heads, int nimg, int h, int w, int k, 
   return hipGetLastError();
 }
 
-static int g_nms_band = 1;            // windows of <= NMS_BAND_ROWS rows take nms_scan_band_kernel
+// windows of <= NMS_BAND_ROWS rows take nms_scan_band_kernel (DC_NMS_BAND=0 in the environment or dc_debug_set "nms_band" 0:
+// every window through nms_scan_kernel -- an A/B and bisecting switch, the picks are the same)
+static int g_nms_band = [] { const char* e = getenv("DC_NMS_BAND"); return e != nullptr && e[0] == '0' ? 0 : 1; }();
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // window k covers sorted rows [win_start(k), win_start(k+1))
 // windows: 4096 boxes, then 32768 at a time (the scan kernel's LDS bit set holds 32768).  The pick budget is

@@ -962,9 +962,17 @@ __global__ __launch_bounds__(256) void mfma_gemm_v2_mixed_kernel(GemmDesc d, int
     const int total = ntm * ntn;
     nbig = total / slots * slots;
     int tail = total - nbig;
-    if (!(nbig > 0 && tail > 0 && 4 * tail <= 3 * slots) || nbig + 2 * tail > (int)gridDim.x) { nbig = total; tail = 0; }
-    nwalk = nbig;
-    if ((int)blockIdx.x >= nbig + 2 * tail) return;
+    if (!(nbig > 0 && tail > 0 && 4 * tail <= 3 * slots)) { nbig = total; tail = 0; }
+    const int G = (int)gridDim.x;
+    if (nbig + 2 * tail <= G) {
+      nwalk = nbig;                                     // one workgroup per live tile
+    } else {
+      // fewer workgroups than live tiles: the host launched a tile WALK (dc_debug_set "walk": nwalk slots + the split round) --
+      // the live tiles are walked by as many workgroups as there are, a multiple of 8 so that a workgroup stays on its XCD
+      nbig = total; tail = 0;
+      nwalk = G >= 8 ? (G & ~7) : G;
+    }
+    if ((int)blockIdx.x >= nwalk + 2 * tail) return;
   }
   const int b = blockIdx.x;
   if (b < nwalk) {

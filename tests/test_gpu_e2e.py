@@ -868,6 +868,42 @@ def test_ring_depth_is_invisible_in_decode(model, weights):
         check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"v2_stages", 0), "dc_debug_set")
 
 
+def test_tile_walk_and_ring_depth_are_invisible_under_a_device_row_count(model, weights):
+    """Round 6: with a device-side row count (captions after the final NMS) every contraction kernel rebuilds its tile map for the
+    LIVE row tiles.  A launch the host made as a tile WALK (dc_debug_set "walk": fewer workgroups than tiles) must then walk the
+    live tiles with the workgroups there are -- the first version mapped one tile per workgroup and left the tiles past the grid
+    uncomputed: garbage tokens, then a fault in the xg row gather (found by tests/fuzz_e2e.py seed 61 case 95: 755x524, uncapped
+    proposals, final threshold 1.0 = 5,977 kept rows of 19,008, single-image mode).  Same bits with the walk and the ring depths
+    forced, in both caption orders, at that case's size and at 720x600 / 1000."""
+    from densecap_amd._lib import check
+    from densecap_amd.weights import make_synthetic_image
+    ctx = model.ctx
+    try:
+        for (H, W, P, fthr, lanes) in ((755, 524, -1, 1.0, 1), (600, 720, 1000, 0.3, 1), (600, 720, 1000, 0.3, 2)):
+            img = make_synthetic_image(H, W, 1095)
+            model.setLanes(lanes)
+            model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=fthr, num_proposals=P)
+            base = None
+            for order in (False, True):
+                for walk, st in ((0, 0), (1, 3), (1, 2), (0, 2)):
+                    model.setCaptionOrder(order)
+                    check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"walk", walk), "dc_debug_set")
+                    check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"v2_stages", st), "dc_debug_set")
+                    out = model.forward_raw(img)
+                    assert out[2].min() >= 1 and out[2].max() <= model.vocab_size + 1
+                    if base is None:
+                        base = out
+                    for a, b in zip(out, base):
+                        np.testing.assert_array_equal(a, b)
+            assert len(base[0]) > (3000 if P < 0 else 100)
+    finally:
+        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"walk", 0), "dc_debug_set")
+        check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"v2_stages", 0), "dc_debug_set")
+        model.setCaptionOrder(False)
+        model.setLanes(3)
+        model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=1000)
+
+
 def test_webcam_regime_forward(model, weights):
     """forward_test at the webcam settings (480 px, 50 proposals, single_machine_demo.lua:25-26), single-image mode, against
     the oracle (every stage) -- also with captions after the final NMS (device-side row count) and for a pair of images in
