@@ -99,7 +99,37 @@ def hybrid_nms(b5_oracle, b5_hip, thr, max_boxes=None, k=FLIP_K):
     gs, ge = so[order], err[order]
     fragile = (gs[:-1] - gs[1:]) <= k * (ge[:-1] + ge[1:])
     final = order.copy()
-    i = 0
+    # Round 6 (tests/fuzz_e2e.py seeds 65 / 67: uncapped lists of 20,000+ boxes at threshold 1.0, i.e. the whole sorted order):
+    # a box may legitimately move past SEVERAL neighbours, across a pair that is itself not fragile, so runs of fragile ADJACENT
+    # pairs do not describe every admissible ranking.  The rule proper: the HIP ranking is admissible iff EVERY pair it orders
+    # differently from the oracle (an inversion) has an oracle gap within k x the discrepancy observed for its two scores.
+    # Inversions only occur between boxes whose two ranks are close: pairs up to the largest rank displacement apart are
+    # checked (vectorised per distance).  If the HIP ranking is admissible it IS the replayed ranking.
+    rank_h = np.lexsort((np.arange(n), -sh))
+    pos_h = np.empty(n, np.int64); pos_h[rank_h] = np.arange(n)
+    ph = pos_h[order]                                   # HIP rank of the box at each oracle rank
+    disp = int(np.abs(ph - np.arange(n)).max())
+    admissible = disp > 0 and disp <= 4096
+    for d in range(1, disp + 1 if admissible else 0):
+        inv = ph[:-d] > ph[d:]                          # oracle ranks i < i+d, HIP has them the other way round
+        if inv.any() and not ((gs[:-d] - gs[d:])[inv] <= k * (ge[:-d] + ge[d:])[inv]).all():
+            admissible = False
+            break
+    if admissible:
+        moved = rank_h != order                         # report the displaced stretches as the adjacent-run rule does
+        i = 0
+        while i < n:
+            if not moved[i]:
+                i += 1
+                continue
+            j = i
+            while j < n and moved[j]:
+                j += 1
+            flips.append("score order of rows %s (oracle gap %.3g, observed score discrepancy %.3g)" % (
+                order[i:j][:6].tolist(), float(gs[i] - gs[j - 1]), float(ge[i:j].max())))
+            i = j
+        final = rank_h.copy()
+    i = n if admissible else 0
     while i < n - 1:
         if not fragile[i]:
             i += 1
@@ -346,10 +376,10 @@ def _strict_check_stages(model, weights, img, P, rpn_thr, final_thr, T, O, torch
     D = int(weights["fc7_w"].shape[0])
     codes, _ = model.debug_fetch("codes", (Pcap, D))
     report["fc7_codes_rel_err"] = rel_err(codes[hi], st["codes"][oi])
-    assert report["fc7_codes_rel_err"] <= REL
+    assert report["fc7_codes_rel_err"] <= REL, "fc7 codes: relative error %.3g" % report["fc7_codes_rel_err"]
     obj, _ = model.debug_fetch("obj", (Pcap,))
     report["obj_rel_err"] = row_rel_err(obj[hi], st["obj"][oi])
-    assert report["obj_rel_err"] <= REL
+    assert report["obj_rel_err"] <= REL, "objectness: max row error %.3g" % report["obj_rel_err"]
     fb, _ = model.debug_fetch("final_boxes", (Pcap, 4))
     report["final_boxes_pre_nms_rel_err"] = row_rel_err(fb[hi], st["final_boxes_pre_nms"][oi])
     assert report["final_boxes_pre_nms_rel_err"] <= REL

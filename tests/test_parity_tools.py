@@ -34,3 +34,33 @@ def test_hybrid_nms_replays_a_perturbed_run_and_names_the_flips():
             differing += 1
             assert flips, "lists differ but no flipped decision was reported"
     assert differing > 0                                         # the scenario the replay exists for did occur
+
+
+def test_hybrid_nms_admits_a_box_that_moves_past_several_neighbours():
+    """Round 6 (tests/fuzz_e2e.py seeds 65 / 67, uncapped lists of 20,000+ boxes at threshold 1.0): the admissible rankings are
+    those whose every INVERSION against the oracle lies within k x the discrepancy observed for its two scores -- a box whose
+    own score moved a lot may pass neighbours that are themselves rock solid, which runs of fragile ADJACENT pairs cannot
+    express.  And an inversion beyond that margin must still be refused."""
+    from tests import parity
+    n = 40
+    boxes = np.stack([np.arange(n) * 50.0, np.zeros(n), np.arange(n) * 50.0 + 10, np.full(n, 10.0)], 1)     # disjoint boxes
+    so = (1.0 - np.arange(n) * 1e-5).astype(np.float32)                       # oracle scores, 1e-5 apart
+    sh = so.copy()
+    sh[20] += np.float32(3.5e-5)                                                # box 20 moves up past 19, 18, 17 (3 neighbours)
+    bo = np.concatenate([boxes, so[:, None]], 1).astype(np.float32)
+    bh = np.concatenate([boxes, sh[:, None]], 1).astype(np.float32)
+    want = np.lexsort((np.arange(n), -sh.astype(np.float64)))
+    assert want.tolist().index(20) == 17
+    picks, flips = parity.hybrid_nms(bo, bh, 1.0, None, k=1.0)                 # gap 3e-5 <= 1.0 x (3.5e-5 + 0) for every inversion
+    assert picks.tolist() == want.tolist() and len(flips) == 1
+    assert parity.k_needed(bo, bh, 1.0, None, want) == 1.0
+    picks, _ = parity.hybrid_nms(bo, bh, 1.0, None, k=0.5)                     # 3e-5 > 0.5 x 3.5e-5: not admissible at k = 0.5
+    assert picks.tolist() != want.tolist()
+    # a swap with NO observed discrepancy to justify it is refused whatever k
+    sh2 = so.copy(); sh2[[5, 9]] = sh2[[9, 5]]
+    bh2 = np.concatenate([boxes, sh2[:, None]], 1).astype(np.float32)
+    want2 = np.lexsort((np.arange(n), -sh2.astype(np.float64)))
+    err = np.abs(sh2 - so)
+    assert err[5] > 0                                                          # (the swap itself is the discrepancy: 4e-5 each)
+    picks, _ = parity.hybrid_nms(bo, bh2, 1.0, None, k=0.25)                   # gap 4e-5 > 0.25 x 8e-5
+    assert picks.tolist() != want2.tolist()
