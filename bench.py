@@ -826,7 +826,7 @@ def main():
         split_group, split_group_trial = args.group, None
         if args.lanes != 1 and not group_fixed:
             split_group_trial = {}
-            for g in (1, 2, 4):
+            for g in (1, 2, 4, 8):
                 model.setGroup(g)
                 model.forward_batch_device(imgs, K, H, W)
                 sync()

@@ -113,7 +113,7 @@ hipError_t launch_splitk_reduce_pool(const float* ws, int S, const float* bias, 
 bool mfma_gemm_can_pool(const GemmDesc& d);
 // Largest image group a launch may carry (dc_set_group).  Split-K factors are functions of ONE image's problem, so the
 // partial-output workspace test assumes a group of this size: an image gets the same factor in every group.
-constexpr int kGemmMaxGroup = 4;
+constexpr int kGemmMaxGroup = 8;
 // split factor launch_mfma_gemm would like for this problem (1 = none)
 int mfma_gemm_splitk(const GemmDesc& d, size_t ws_floats);      // ws_floats: capacity of the partial-output workspace
 // Tail plan for problems whose 128x128 tile count is not a multiple of the 256 CUs: rows [0, m_split) run as

@@ -345,7 +345,7 @@ int conv3x3_pool(dc_ctx* ctx, hipStream_t s, const float* in, const float* w, co
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 // num_proposals = -1 (LocalizationLayer.lua:322-324: uncapped RPN NMS): capacity = every anchor of this image size
 int effective_proposals(const dc_ctx* ctx, int H, int W);
-constexpr size_t kSplitkWsFloats = (size_t)3200 * 128 * 128;  // 200 MiB per lane: split-K partial outputs (up to 8 x a four-image group's 4 x 384 x 4096 fc6 rows), tail plans, stream-K slots
+constexpr size_t kSplitkWsFloats = (size_t)6400 * 128 * 128;  // 400 MiB per lane: split-K partial outputs (up to 8 x an eight-image group's 8 x 384 x 4096 fc6 rows), tail plans, stream-K slots
 
 Ws lane_ws(const Lane& L) { return Ws{L.splitk_ws, L.splitk_ws ? kSplitkWsFloats : 0}; }
 

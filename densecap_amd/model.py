@@ -190,7 +190,7 @@ class DenseCapModel:
         self.setLanes(max(rates, key=rates.get))
         return rates
 
-    def autotuneSchedule(self, dev_ptr, n, H, W, lanes=(2, 3, 4), groups=(1, 2, 4), reps=2):
+    def autotuneSchedule(self, dev_ptr, n, H, W, lanes=(2, 3, 4), groups=(1, 2, 4, 8), reps=2):
         """Pick the lane count AND the images per group together (both are pure scheduling knobs: results are bit-identical
         for any lanes >= 2 and any group): the best lane count depends on the group size -- 300 proposals: 2 lanes x groups
         of four 312 images/s, 4 lanes x groups of four 299, 2 lanes x single images 285.  Returns {(lanes, group): images/s};
@@ -211,7 +211,7 @@ class DenseCapModel:
         self.setLanes(l); self.setGroup(g)
         return rates
 
-    def autotuneGroup(self, dev_ptr, n, H, W, candidates=(1, 2, 4), reps=2):
+    def autotuneGroup(self, dev_ptr, n, H, W, candidates=(1, 2, 4, 8), reps=2):
         """Pick the images-per-group setting (dc_set_group: a scheduling knob like the lane count -- results are
         bit-identical) at the current lane count.  With few proposals per image the RoI stages of one image leave the
         chip's tile rounds badly filled and a group of four shares them (300 proposals: +9 % images/s at two lanes); at
@@ -252,7 +252,7 @@ class DenseCapModel:
         return self
 
     def setGroup(self, images):
-        """Images per group inside a batch call: 0/1 = every image on its own (default), 2..4 = the images of a group share
+        """Images per group inside a batch call: 0/1 = every image on its own (default), 2..8 = the images of a group share
         the launches of the dense stages (bit-identical results; 1000 proposals: +4.5 % images/s on one lane, nothing with
         two or more lanes; 300 proposals: +9 % at two lanes with groups of four)."""
         check(self.ctx.h, self.lib.dc_set_group(self.ctx.h, int(images)), "dc_set_group")

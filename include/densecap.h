@@ -139,7 +139,7 @@ int dc_forward_images(dc_ctx* ctx, const float* const* imgs, const int* H, const
  * rows advance as two blocks on two streams (same arithmetic per row); per-kernel profiling (dc_mfma_profile)
  * keeps every kernel on one stream.  Results are bit-identical for a given lanes setting however images are batched. */
 int dc_set_lanes(dc_ctx* ctx, int lanes);
-/* Images per GROUP inside dc_forward_batch, 1 .. 4 (0 or 1 = every image on its own, the default): the images of a
+/* Images per GROUP inside dc_forward_batch, 1 .. 8 (0 or 1 = every image on its own, the default; up to 4 through round 5): the images of a
  * group share the launches of the dense stages (the convolutions run over all of them, fc6 / fc7 and the decode over all
  * their RoI rows: fuller tile rounds, a fraction of the launches per image) and of the batched per-image kernels (RPN
  * decode, RoI pooling, gathers); the NMS runs follow each other.  Every decision that changes a sum's order (kernel
@@ -147,7 +147,8 @@ int dc_set_lanes(dc_ctx* ctx, int lanes);
  * in (bit-identical, like the lane count; tests/fuzz_groups.py).  In single-image mode (dc_set_lanes(1)) the setting is
  * ignored and images travel alone: that mode shares a layer's partial last tile round along K, a plan made for one
  * image's tile count.  Measured at 720x600 / 1000 proposals: 183 images/s with groups of four on two or four lanes against
- * 182 ungrouped; 317 against 285 at 300 proposals. */
+ * 182 ungrouped; 317 against 285 at 300 proposals; round 6: groups of eight on two lanes 184 against 181 with groups of four,
+ * with captions after the final NMS 239-240 against 238 (a packed decode of ~1800 rows a launch). */
 int dc_set_group(dc_ctx* ctx, int images);
 /* Caption order. 0 (default) = the reference's order: LanguageModel:sample runs on all num_proposals
  * RoIs and the final NMS then keeps K rows (DenseCapModel.lua:127-162,261-275).  1 = run the final NMS

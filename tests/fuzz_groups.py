@@ -27,7 +27,7 @@ def main(n_cases, seed):
         if rng.integers(0, 5) == 0:
             H = int(rng.integers(500, 800)); Wd = int(rng.integers(640, 1100))
         P = int(rng.choice([1, 3, 50, 64, 100, 128, 300, 1000, -1]))
-        n = int(rng.integers(2, 10)); G = int(rng.integers(1, 5)); lanes = int(rng.integers(2, 5))
+        n = int(rng.integers(2, 10)); G = int(rng.choice([1, 2, 3, 4, 4, 6, 8])); lanes = int(rng.integers(2, 5))
         if rng.integers(0, 5) == 0:
             lanes = 1
         order = bool(rng.integers(0, 2))

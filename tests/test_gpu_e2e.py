@@ -259,7 +259,7 @@ def test_caption_order_is_output_invariant(model, weights, shape):
 
 @pytest.mark.parametrize("shape", [(224, 288, 100), (600, 720, 300), (600, 720, 1000)], ids=lambda s: "%dx%d_p%d" % (s[1], s[0], s[2]))
 def test_caption_order_packs_the_survivors_of_a_group(model, weights, shape):
-    """Captions after the final NMS in groups of 1..4 images (one packed decode per group, images with different survivor
+    """Captions after the final NMS in groups of 1..8 images (one packed decode per group, images with different survivor
     counts side by side, a ragged last group) == the reference order image by image."""
     from densecap_amd.weights import make_synthetic_image
     H, W, P = shape
@@ -270,7 +270,7 @@ def test_caption_order_packs_the_survivors_of_a_group(model, weights, shape):
         ref = model.forward_batch(imgs)
         assert len({len(r[0]) for r in ref}) > 1, "the images should keep different numbers of boxes"
         model.setCaptionOrder(True)
-        for g in (1, 2, 3, 4):
+        for g in (1, 2, 3, 4, 6, 8):
             model.setGroup(g)
             got = model.forward_batch(imgs)
             for i, (a, b) in enumerate(zip(ref, got)):
@@ -727,12 +727,12 @@ def test_image_groups_do_not_change_results(model, weights):
             model.setTestArgs(rpn_nms_thresh=0.7, final_nms_thresh=0.3, num_proposals=P)
             imgs = np.stack([make_synthetic_image(H, W, 70 + s) for s in range(n)])
             outs = {}
-            for group in (1, 2, 3, 4, 0):
+            for group in (1, 2, 3, 4, 6, 8, 0):
                 model.setGroup(group)
                 outs[group] = model.forward_batch(imgs)
             for i in range(n):
                 single = model.forward_raw(imgs[i])
-                for group in (1, 2, 3, 4, 0):
+                for group in (1, 2, 3, 4, 6, 8, 0):
                     for x, y in zip(outs[group][i], single):
                         np.testing.assert_array_equal(x, y, err_msg="%dx%d P=%d group %d image %d" % (W, H, P, group, i))
                 assert len(single[0]) > 0
@@ -753,7 +753,7 @@ def test_image_groups_do_not_change_results(model, weights):
                 for x, y in zip(grouped[i], model.forward_raw(imgs[i])):
                     np.testing.assert_array_equal(x, y, err_msg="case %d (%dx%d, P=%d, group %d) image %d" % (case, W, H, P, G, i))
         with pytest.raises(Exception):
-            model.setGroup(5)
+            model.setGroup(9)
     finally:
         model.setGroup(0)
         model.setCaptionOrder(False)
