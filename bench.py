@@ -914,15 +914,16 @@ def main():
 
     # ---- the other BASELINE.json configs, on THIS run's clock (round-5 verdict, weak #9: they existed only as builder-run files) --
     # Short legs of the same product calls at the other configs' shapes, each in both caption orders: warm regions, then timed
-    # regions for >= --config-leg-seconds; the median region is reported.  Schedules are fixed (no trial): the pairs the round-5
-    # trials picked at these shapes (all pairs within 2 % there, except 300 proposals, where groups of four are worth 9 %).
+    # regions for >= --config-leg-seconds; the median region is reported.  Schedules are fixed (no trial): two lanes x groups of
+    # eight, the pair a 12-pair sweep put first at every one of these shapes in both caption orders (round 6; the others within
+    # 1-3 %, single images 9-12 % behind at 300 proposals).
     config_legs = None
     if (on_gpu and rank == 0 and world == 1 and not had_dist and not args.no_config_legs and args.math_mode == 0
             and (H, W, P) == (600, 720, 1000) and "DC_BENCH_CHILD" not in os.environ):
         config_legs = {}
-        legs = [("configs[2]", "batch of 32 synthetic 720x600 images, 300 proposals each", 600, 720, 300, 32, 2, 4),
-                ("configs[4]", "1080x720 synthetic images, 2000 proposals, 15-token cap", 720, 1080, 2000, 16, 2, 2),
-                ("configs[0]", "720x480 (run_model.lua's elephant.jpg size), 1000 proposals; synthetic image and weights", 480, 720, 1000, 32, 2, 4)]
+        legs = [("configs[2]", "batch of 32 synthetic 720x600 images, 300 proposals each", 600, 720, 300, 32, 2, 8),
+                ("configs[4]", "1080x720 synthetic images, 2000 proposals, 15-token cap", 720, 1080, 2000, 16, 2, 8),
+                ("configs[0]", "720x480 (run_model.lua's elephant.jpg size), 1000 proposals; synthetic image and weights", 480, 720, 1000, 32, 2, 8)]
         for tag, what, h_, w_, p_, n_, lanes_, group_ in legs:
             distinct = 8
             host_c = np.stack([make_synthetic_image(h_, w_, 7000 + 100 * len(config_legs) + i) for i in range(distinct)])

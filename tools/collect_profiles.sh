@@ -37,11 +37,11 @@ BENCH="python $REPO/bench.py $LEAN"
 run default "--steps 10 --warmup 3 --repeats 2" --kernel-trace --stats
 grep '^{' /tmp/rp_default.json > "$OUT/bench_default_under_rocprof.json"
 # round 6: the captions-after-the-final-NMS schedule (what the CLIs run; `value_captions_after_final_nms`): one stream, the
-# multi-lane planning and the group of four the timed leg picks -- the packed decode launches of a group are in this trace
-BENCH="python $REPO/bench.py --lanes 1 --plan-mode 0 --group 4 --caption-order 1 $LEAN"
-run capnms "--steps 12 --warmup 4 --repeats 1" --kernel-trace --stats
+# multi-lane planning and the group of eight the timed leg picks -- the packed decode launches of a group are in this trace
+BENCH="python $REPO/bench.py --lanes 1 --plan-mode 0 --group 8 --caption-order 1 $LEAN"
+run capnms "--steps 16 --warmup 8 --repeats 1" --kernel-trace --stats
 grep '^{' /tmp/rp_capnms.json > "$OUT/bench_capnms_under_rocprof.json"
-run capnms_mfma "--steps 4 --warmup 4 --repeats 1" --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT
+run capnms_mfma "--steps 8 --warmup 8 --repeats 1" --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT
 # the opt-in split-bf16 mode (round 5): kernel names + durations, MFMA busy and clock of ITS kernels (one stream, multi-lane planning)
 BENCH="python $REPO/bench.py --lanes 1 --plan-mode 0 --group 1 --math-mode 1 $LEAN"
 run split "--steps 10 --warmup 3 --repeats 1" --kernel-trace --stats
@@ -59,7 +59,7 @@ python bench.py --height 720 --width 1080 --proposals 2000 --steps 12 --warmup 2
 python bench.py --math-mode 1 --steps 32 --no-split-leg $Q > "$OUT/bench_split_bf16_mode.json" 2>/dev/null
 python tools/latency_check.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/latency_check.txt"
 bash tools/decode_trace.sh "$OUT/decode_trace_small_rows.txt" 13 50 128 221 256 300 900 > /dev/null 2>&1
-for cfg in "600 720 1000 1" "600 720 1000 4" "600 720 300 1" "600 720 300 4" "320 480 50 1"; do
+for cfg in "600 720 1000 1" "600 720 1000 4" "600 720 1000 8" "600 720 300 1" "600 720 300 8" "320 480 50 1"; do
   bash tools/survivor_trace.sh "$OUT/survivor_decode_trace.txt" $cfg > /dev/null 2>&1
 done
 for cfg in "600 720 1000" "600 720 300" "320 480 50" "720 1080 2000"; do

@@ -215,7 +215,7 @@ def main():
             if e["total_us"] > 50:
                 print("  %-52s calls=%4d avg_us=%9.1f %s" % (f[:52], e["calls"], e["avg_us"],
                       " ".join("%s=%.3g" % (k, v) for k, v in e.items() if k not in ("calls", "total_us", "avg_us"))))
-    # round 6: the captions-after-the-final-NMS schedule (bench.py --lanes 1 --plan-mode 0 --group 4 --caption-order 1): the
+    # round 6: the captions-after-the-final-NMS schedule (bench.py --lanes 1 --plan-mode 0 --group 8 --caption-order 1): the
     # packed decode launches of a group of four are in this trace; durations per family + MFMA busy of its kernels
     if os.path.exists(os.path.join(d, "capnms_kernel_trace.csv")):
         cp = collections.OrderedDict()
@@ -243,8 +243,8 @@ def main():
                     gui = c["GRBM_GUI_ACTIVE"] / 8.0
                     cp[f]["mfma_util"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024.0)
                     cp[f]["clock_ghz"] = gui / c["_dur_us"] / 1e3
-        summ["_captions_after_final_nms_group4"] = cp
-        print("_captions_after_final_nms_group4 (bench.py --lanes 1 --plan-mode 0 --group 4 --caption-order 1)")
+        summ["_captions_after_final_nms_group8"] = cp
+        print("_captions_after_final_nms_group8 (bench.py --lanes 1 --plan-mode 0 --group 8 --caption-order 1)")
         for f, e in cp.items():
             if e["total_us"] > 50:
                 print("  %-52s calls=%4d avg_us=%9.1f %s" % (f[:52], e["calls"], e["avg_us"],
