@@ -450,7 +450,7 @@ def main():
 
     H, W, P, K, Wm = args.height, args.width, args.proposals, args.steps, args.warmup
     T, V = 15, 10497
-    n_img = max(K, Wm, args.lanes, 4, 1)
+    n_img = max(K, Wm, args.lanes, 8, 1)                      # (>= dc_set_group's maximum: a whole group is resident even for --steps 4)
     if on_gpu:
         from densecap_amd import DenseCapModel
         from densecap_amd._lib import check
@@ -902,9 +902,9 @@ def main():
         if args.group > 1:
             check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"plan_mode", 0), "dc_debug_set")
             model.setGroup(args.group)
-            model.forward_batch_device(imgs, args.group, H, W)
+            model.forward_batch_device(imgs, min(args.group, n_img), H, W)
             sync()
-            model.forward_batch_device(imgs, args.group, H, W)
+            model.forward_batch_device(imgs, min(args.group, n_img), H, W)
             sync()
             stage_group = model.stage_times()
             check(ctx.h, ctx.lib.dc_debug_set(ctx.h, b"plan_mode", args.plan_mode), "dc_debug_set")

@@ -790,7 +790,7 @@ def test_abi_edge_cases_report_errors_and_truncate(model, weights):
     assert lib.dc_forward_test(h, img.ctypes.data, 16, 16, 0, C.byref(r2)) == -1             # below 32 px
     assert lib.dc_forward_test(h, None, 224, 288, 0, C.byref(r2)) == -1
     assert lib.dc_set_lanes(h, 0) == -1 and lib.dc_set_lanes(h, 5) == -1
-    assert lib.dc_set_beam_size(h, -1) == -5 and lib.dc_set_group(h, 7) == -1                # DC_E_UNSUPPORTED / DC_E_INVALID
+    assert lib.dc_set_beam_size(h, -1) == -5 and lib.dc_set_group(h, 9) == -1                # DC_E_UNSUPPORTED / DC_E_INVALID
     assert lib.dc_debug_fetch(h, b"no_such_tensor", b.ctypes.data, b.nbytes) < 0
     # an image whose conv1 activation would pass the kernels' 32-bit operand offsets (~16 Mpx) is refused up front
     assert lib.dc_forward_test(h, img.ctypes.data, 4200, 4200, 0, C.byref(r2)) == -5
