@@ -567,7 +567,8 @@ __global__ __launch_bounds__(256) void nms_scan_band_kernel(const u64* __restric
                                                             const int32_t* __restrict__ order, int r0, int r1,
                                                             int max_boxes, const u64* __restrict__ removed0,
                                                             int32_t* __restrict__ picks, int32_t* __restrict__ pick_pos,
-                                                            NmsState* __restrict__ st, int32_t* __restrict__ count_out) {
+                                                            NmsState* __restrict__ st, int32_t* __restrict__ count_out,
+                                                            uint32_t* __restrict__ fault) {
   extern __shared__ __attribute__((aligned(16))) u64 band[];       // [NMS_BAND_WORDS][NMS_BAND_ROWS]
   __shared__ u64 removed[NMS_BAND_ROWS / 64];
   __shared__ int s_np[4];
@@ -580,6 +581,11 @@ __global__ __launch_bounds__(256) void nms_scan_band_kernel(const u64* __restric
   auto flag_store = [](int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
   __shared__ int s_result[2];             // {count, full}
   constexpr int kStop = 1 << 30;
+  // Every wait on another wave is BOUNDED (as the stream-K owners' waits are): a flag that does not arrive within ~2^20 sleeps
+  // (tens of milliseconds; a hand-off normally takes a microsecond) sets the sticky fault word -- the host then fails the call
+  // and falls back to the chunk scan instead of delivering a list built on a missing hand-off -- and the wave moves on.
+  constexpr unsigned kSpinLimit = 1u << 20;
+  auto give_up = [&]() { if (fault != nullptr && (threadIdx.x & 63) == 0) __hip_atomic_store(fault, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   const int ntot = *nvalid;
   if (st->done) return;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -621,7 +627,11 @@ __global__ __launch_bounds__(256) void nms_scan_band_kernel(const u64* __restric
     for (int w = 0; w < nw; ++w) {
       if (w >= 4) {                       // the far words of the picks of chunk w-4 (and, in order, of all before) are in
         const int p = w - 4;
-        while (flag_load(&s_applied[p % 3]) <= p / 3) __builtin_amdgcn_s_sleep(1);
+        unsigned spins = 0;
+        while (flag_load(&s_applied[p % 3]) <= p / 3) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > kSpinLimit) { give_up(); break; }
+        }
         NMS_COMPILER_FENCE();
       }
       const int row = w * 64 + lane;      // window-relative
@@ -669,7 +679,11 @@ __global__ __launch_bounds__(256) void nms_scan_band_kernel(const u64* __restric
     const int hw = wid - 1;
     for (int p = hw; p + 4 < nw; p += 3) {               // (chunks whose picks have no far word need no helper)
       int pub;
-      while ((pub = flag_load(&s_published)) <= p) __builtin_amdgcn_s_sleep(1);
+      unsigned spins = 0;
+      while ((pub = flag_load(&s_published)) <= p) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSpinLimit) { give_up(); pub = kStop; break; }
+      }
       if (pub >= kStop) break;                           // wave 0 is through: nobody reads `removed` any more
       NMS_COMPILER_FENCE();
       const int np = s_np[p & 3];
@@ -886,7 +900,7 @@ hipError_t nms_workspace_bind(NmsWorkspace& ws, void* base, int n) {
 
 hipError_t launch_nms(NmsWorkspace& ws, const float* boxes, const float* scores, const uint8_t* valid, int n,
                       const int32_t* n_dev, float thresh, int max_boxes, int32_t* picks, int32_t* count,
-                      hipStream_t s) {
+                      hipStream_t s, uint32_t* fault) {
   if (n > ws.n_cap) return hipErrorInvalidValue;
   hipError_t e;
   if (n <= 0) return hipMemsetAsync(count, 0, 4, s);
@@ -919,7 +933,7 @@ hipError_t launch_nms(NmsWorkspace& ws, const float* boxes, const float* scores,
       const void* fn = reinterpret_cast<const void*>(&nms_scan_band_kernel);
       if ((e = ensure_dyn_lds(fn, NMS_BAND_LDS)) != hipSuccess) return e;
       hipLaunchKernelGGL(nms_scan_band_kernel, dim3(1), dim3(256), NMS_BAND_LDS, s, ws.mask, wchunks, ws.nearband, ws.nvalid, ws.order, r0,
-                         r1, max_boxes, ws.removed0, picks, ws.pick_pos, st, count);
+                         r1, max_boxes, ws.removed0, picks, ws.pick_pos, st, count, fault);
     } else {
       hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(256), 0, s, ws.mask, wchunks, ws.nvalid, ws.order, r0, r1, max_boxes,
                          ws.removed0, picks, ws.pick_pos, st, count);

@@ -235,9 +235,11 @@ struct NmsWorkspace {
 size_t nms_workspace_bytes(int n);
 hipError_t nms_workspace_bind(NmsWorkspace& ws, void* base, int n);
 // n_dev (optional device int32) overrides n at run time (n is then the capacity)
+// fault (optional): the ctx's sticky device word; nms_scan_band_kernel stores 2 there when a hand-off between its waves did not
+// arrive within the spin bound (the host then fails the call and switches the band scan off)
 hipError_t launch_nms(NmsWorkspace& ws, const float* boxes, const float* scores, const uint8_t* valid, int n,
                       const int32_t* n_dev, float thresh, int max_boxes, int32_t* picks, int32_t* count,
-                      hipStream_t s);
+                      hipStream_t s, uint32_t* fault = nullptr);
 void nms_set_scan_band(int on);          // test hook: 0 = the per-chunk scan kernel for every window
 // out[i] = src[idx[i]] rows of `width` floats for i < *count (rows >= *count zero-filled up to cap)
 hipError_t launch_gather_rows(const float* src, const int32_t* idx, const int32_t* count, int cap, int width,

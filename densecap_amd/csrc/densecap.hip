@@ -214,6 +214,15 @@ struct Ws {
   size_t floats = 0;
 };
 
+// the ctx's sticky device fault word (stream-K owners and the NMS band scan report a hand-off that never arrived there; the
+// packed results carry it to the host): made on first need, before any capture of the forward
+static void ensure_fault_word(dc_ctx* ctx) {
+  if (ctx->fault_dev == nullptr && hipMalloc(reinterpret_cast<void**>(&ctx->fault_dev), 64) == hipSuccess) {
+    ctx->owned.push_back(ctx->fault_dev);
+    (void)hipMemset(ctx->fault_dev, 0, 64);
+  }
+}
+
 int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, const Ws& w = Ws()) {
   float* const ws = w.p;
   const size_t ws_floats = w.floats;
@@ -261,10 +270,7 @@ int run_gemm(dc_ctx* ctx, const GemmDesc& d_in, hipStream_t s, const Ws& w = Ws(
     if (e == hipSuccess) {
       GemmDesc b = d;
       b.m_begin = m_split; b.a_rows = d.M;
-      if (ctx->fault_dev == nullptr && hipMalloc(reinterpret_cast<void**>(&ctx->fault_dev), 64) == hipSuccess) {
-        ctx->owned.push_back(ctx->fault_dev);
-        (void)hipMemset(ctx->fault_dev, 0, 64);
-      }
+      ensure_fault_word(ctx);
       b.sk_fault = ctx->fault_dev;
       e = launch_mfma_gemm_sk(b, pl.sk_wgs, pl.sk_np, ws, s);
     }
@@ -675,9 +681,10 @@ int enqueue_body(dc_ctx* ctx, Lane& L, int g, bool features_only, bool events) {
                          L.rpn_boxes, nullptr, nullptr, L.rpn_xyxy, L.rpn_p, L.rpn_valid, ctx->clip_boxes ? 1 : 0, s));   // the whole group in one launch
   STAGE_EVENT(2);
   // ---- RPN NMS (LocalizationLayer.lua:318-338) ------------------------------------------------
+  ensure_fault_word(ctx);
   for (int i = 0; i < g; ++i)
     KCHK(launch_nms(L.nms, L.rpn_xyxy + (size_t)i * L.A * 4, L.rpn_p + (size_t)i * L.A, L.rpn_valid + (size_t)i * L.A, L.A,
-                    nullptr, ctx->rpn_nms_thresh, P, L.picks1 + (size_t)i * P, L.count1 + i * 64, s));
+                    nullptr, ctx->rpn_nms_thresh, P, L.picks1 + (size_t)i * P, L.count1 + i * 64, s, ctx->fault_dev));
   STAGE_EVENT(3);
   // ---- bilinear RoI pooling (LocalizationLayer.lua:338-349) -----------------------------------
   // one launch for the group; the picked RPN boxes are gathered by the kernel itself (and left in roi_boxes for the heads)
@@ -718,7 +725,7 @@ int enqueue_body(dc_ctx* ctx, Lane& L, int g, bool features_only, bool events) {
     // box_utils.nms unconditionally (DenseCapModel.lua:285-304)
     if (ctx->final_nms_thresh > 0.f || features_only) {
       KCHK(launch_nms(L.nms, L.final_xyxy + r0 * 4, L.obj + r0, nullptr, P, L.count1 + i * 64, ctx->final_nms_thresh, -1,
-                      L.picks2 + r0, L.count2 + i * 64, sn));
+                      L.picks2 + r0, L.count2 + i * 64, sn, ctx->fault_dev));
     } else {
       // DenseCapModel.lua:261: no final NMS when final_nms_thresh <= 0 -> all RoIs, in RPN order
       KCHK(launch_iota_count(L.picks2 + r0, L.count2 + i * 64, L.count1 + i * 64, P, sn));
@@ -858,10 +865,15 @@ int harvest(dc_ctx* ctx, Lane& L) {
   const size_t stride = pack_stride(ctx, P, L.pending_feats);
   for (int i = 0; i < L.g; ++i) {
     const char* hs = static_cast<const char*>(L.host_stage) + i * stride;
-    if (*reinterpret_cast<const uint32_t*>(hs + 68) != 0u) {
+    if (const uint32_t fw = *reinterpret_cast<const uint32_t*>(hs + 68); fw != 0u) {
       (void)hipMemset(ctx->fault_dev, 0, 64);
-      ctx->tail_mode = 1;           // stop sharing tiles between workgroups on this ctx
       L.pending = nullptr;
+      if (fw == 2u) {
+        nms_set_scan_band(0);       // every NMS window back on the chunk scan (process-wide)
+        return ctx->fail(DC_E_HIP, "NMS band scan: a hand-off between the waves of nms_scan_band_kernel did not arrive within the spin "
+                                   "bound; the band scan is now off (chunk scan for every window) -- repeat the call");
+      }
+      ctx->tail_mode = 1;           // stop sharing tiles between workgroups on this ctx
       return ctx->fail(DC_E_HIP, "stream-K: a workgroup's partner never published its partial tile within the spin bound (GPU "
                                  "shared with another job?); this ctx now uses the K-split tail plan -- repeat the call");
     }
@@ -1604,6 +1616,11 @@ static int check_sk_fault(dc_ctx* ctx, const char* who) {
   if (hipMemcpy(&f, ctx->fault_dev, 4, hipMemcpyDeviceToHost) != hipSuccess) return ctx->fail(DC_E_HIP, "%s: fault word read failed", who);
   if (f == 0) return DC_OK;
   (void)hipMemset(ctx->fault_dev, 0, 64);
+  if (f == 2u) {
+    nms_set_scan_band(0);
+    return ctx->fail(DC_E_HIP, "%s: a hand-off between the waves of nms_scan_band_kernel did not arrive within the spin bound; the band "
+                               "scan is now off -- repeat the call", who);
+  }
   ctx->tail_mode = 1;
   return ctx->fail(DC_E_HIP, "%s: stream-K partner never published its partial tile within the spin bound", who);
 }
@@ -1738,12 +1755,13 @@ int dc_op_nms(dc_ctx* ctx, const float* boxes, const float* scores, const uint8_
   HIPCHK(hipMalloc(&base, nms_workspace_bytes(n)));
   NmsWorkspace ws;
   nms_workspace_bind(ws, base, n);
-  hipError_t e = launch_nms(ws, boxes, scores, valid, n, nullptr, thresh, max_boxes, picks, count, s);
+  ensure_fault_word(ctx);
+  hipError_t e = launch_nms(ws, boxes, scores, valid, n, nullptr, thresh, max_boxes, picks, count, s, ctx->fault_dev);
   hipError_t e2 = hipStreamSynchronize(s);
   hipFree(base);
   if (e != hipSuccess) return ctx->fail(DC_E_HIP, "nms launch: %s", hipGetErrorString(e));
   if (e2 != hipSuccess) return ctx->fail(DC_E_HIP, "nms sync: %s", hipGetErrorString(e2));
-  return DC_OK;
+  return check_sk_fault(ctx, "dc_op_nms");
 }
 int dc_op_bilinear_roi_pool(dc_ctx* ctx, const float* feat_hwc, int h, int w, int C, const float* boxes, int B,
                             int img_h, int img_w, int HH, int WW, float* out, int out_layout) {
