@@ -470,7 +470,14 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
       group_with(0, TM + TN, [&](int k) { read_piece(st, 3, 1, k); });
       __builtin_amdgcn_sched_barrier(0);
 #ifndef ABL_NO_WAITCNT
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // Round 6: lgkmcnt(0) too.  The group-3 fragments just REQUESTED from this stage are consumed after the rendezvous, and right
+      // behind it tile kt+2 is requested INTO this stage: a fragment read still queued in a congested LDS (three workgroups per CU,
+      // plus whatever another stream's kernel does there) could be overtaken by LDS-DMA data that comes back from the L1 in ~150 ns
+      // -- one 16-byte chunk of tile kt+2 multiplied in place of tile kt's.  The three-stage ring requests into the PREVIOUS
+      // tile's stage and the K-split kernel has consumed its fragments by then; only this ring had the window (tools/soak.py:
+      // a wrong element about once in 100,000 images, only with kernels of several streams on the chip).  The reads were issued
+      // >= 3 MFMAs ago: the wait is normally already satisfied.
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
 #ifndef ABL_NO_BARRIER
       __builtin_amdgcn_s_barrier();
