@@ -463,8 +463,9 @@ __device__ __forceinline__ void v2_tile(const GemmDesc& d, const int m0, const i
     constexpr int stn = st == 0 ? NS - 1 : st - 1;     // stage of tile kt-1 == stage of tile kt+NS-1
     if constexpr (NS == 2) {
       // Two-stage ring (48 KiB for a 128x64 tile: THREE workgroups per CU instead of two): the rendezvous sits after
-      // group 2, when every fragment of tile kt is in registers -- its stage is then free for tile kt+2, requested a
-      // full tile ahead of its first use; tile kt+1 (requested during tile kt-1) is waited for at the same point.
+      // group 2, when every fragment of tile kt has been requested -- and, since round 6, is waited for (lgkmcnt) -- so that its
+      // stage is free for tile kt+2, requested a full tile ahead of its first use; tile kt+1 (requested during tile kt-1) is
+      // waited for at the same point.
       group_with(0, TM + TN, [&](int k) { read_piece(st, 1, 1, k); });
       group_with(1, TM + TN, [&](int k) { read_piece(st, 2, 0, k); });
       group_with(0, TM + TN, [&](int k) { read_piece(st, 3, 1, k); });
